@@ -1,0 +1,253 @@
+/*
+ * fmhip.h — C-ABI of the MI355X-native RandomVariable / BrownianMotion engine.
+ *
+ * This is the drop-in boundary.  It replaces the JCuda/JCurand JNI surface
+ * that the reference binds for this path:
+ *
+ *   reference (Java, JCuda)                                   this header
+ *   ---------------------------------------------------------------------------------------------
+ *   cuInit/cuDeviceGet/cuCtxCreate/cuModuleLoad               fmhip_init / fmhip_shutdown
+ *     (RandomVariableCuda.java:159-248)
+ *   DeviceMemoryPool.getDevicePointer(long)  (:280)           fmhip_vec_create_uninitialized
+ *   DeviceMemoryPool.getDevicePointer(float[]) (:457)         fmhip_vec_create_from_float / _from_double
+ *   DeviceMemoryPool.getValuesAsFloat        (:469)           fmhip_vec_read_float / _read_double
+ *   DeviceMemoryPool.callFunctionv1s0 … v2s1 (:483-557)       fmhip_call_v1s0 … fmhip_call_v3s0
+ *   DeviceMemoryPool.clean / purge           (:393,:424)      fmhip_pool_clean / fmhip_pool_purge
+ *   getDeviceFreeMemPercentage               (:435)           fmhip_pool_stats
+ *   getAverage/getVariance/getMin/getMax     (:830-901)       fmhip_reduce_moments (on device, 32 B back)
+ *   curandCreateGenerator/SetSeed/GenerateNormal/Destroy      fmhip_bm_generate
+ *     (BrownianMotionCudaWithRandomVariableCuda.java:141-182)
+ *   — (no equivalent: one launch per method call)             fmhip_program_* (fused op streams, batched)
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (0 = FMHIP_OK, <0 = error class);
+ *     a human-readable message for the calling thread's last error is returned by fmhip_last_error().
+ *   - a vector handle (fmhip_vec) is an opaque non-zero int64 owned by the caller; release it with
+ *     fmhip_vec_release.  Storage is fp32 on the device (README.md:100 of the reference), values cross
+ *     the boundary as double or float.
+ *   - scalars are passed as double and narrowed with (float) before use, as the reference does
+ *     (RandomVariableCuda.java:521,533).
+ *   - all entry points are thread-safe; device work is enqueued on one in-order stream per process,
+ *     only the read/reduce entry points block.
+ *   - one process drives one GPU (one rank per GPU under torch.distributed / RCCL).
+ */
+#ifndef FMHIP_H
+#define FMHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMHIP_ABI_VERSION 1
+
+typedef int64_t fmhip_vec;      /* 0 is never a valid handle */
+typedef int64_t fmhip_program;  /* 0 is never a valid handle */
+
+typedef enum fmhip_status {
+    FMHIP_OK                  =  0,
+    FMHIP_ERR_INVALID_HANDLE  = -1,
+    FMHIP_ERR_SIZE_MISMATCH   = -2,
+    FMHIP_ERR_OUT_OF_MEMORY   = -3,   /* maps to java.lang.OutOfMemoryError (RandomVariableCuda.java:375) */
+    FMHIP_ERR_HIP             = -4,   /* a HIP runtime call failed (CudaException in the reference, :167) */
+    FMHIP_ERR_INVALID_ARGUMENT= -5,
+    FMHIP_ERR_NOT_INITIALIZED = -6,
+    FMHIP_ERR_UNSUPPORTED     = -7,   /* UnsupportedOperationException in the reference */
+    FMHIP_ERR_PROGRAM_LIMIT   = -8    /* a fused program exceeds the register / input budget */
+} fmhip_status;
+
+/*
+ * Opcodes.  One per kernel of RandomVariableCudaKernel.cu (line numbers of the .cu given), plus the
+ * operations the reference defines only in its CPU twin RandomVariableFromFloatArray.java
+ * (choose :1264, isNaN :1441, sin :927, cos :942, addRatio :1395, subRatio :1418).
+ * Arithmetic contract for every opcode: each elementary operation rounds to fp32 separately
+ * (no FMA contraction — the reference compiles with `nvcc -fmad false`, JCudaUtils.java:69-70);
+ * exp/log/pow/sin/cos are evaluated in fp64 and narrowed, sqrt and division are correctly rounded.
+ */
+typedef enum fmhip_opcode {
+    /* vector (a) ∘ scalar (s):  fmhip_call_v1s1 */
+    FMHIP_OP_CAP_S      =  1,  /* min(a,s)        capByScalar   .cu:2   */
+    FMHIP_OP_FLOOR_S    =  2,  /* max(a,s)        floorByScalar .cu:13  */
+    FMHIP_OP_ADD_S      =  3,  /* a + s           addScalar     .cu:24  */
+    FMHIP_OP_SUB_S      =  4,  /* a - s           subScalar     .cu:34  */
+    FMHIP_OP_BUS_S      =  5,  /* -a + s          busScalar     .cu:44  */
+    FMHIP_OP_MULT_S     =  6,  /* a * s           multScalar    .cu:54  */
+    FMHIP_OP_DIV_S      =  7,  /* a / s           divScalar     .cu:65  */
+    FMHIP_OP_VID_S      =  8,  /* s / a           vidScalar     .cu:76  */
+    FMHIP_OP_POW_S      =  9,  /* pow(a,s)        cuPow         .cu:98  */
+    /* unary:  fmhip_call_v1s0 */
+    FMHIP_OP_SQUARED    = 10,  /* a * a           squared       .cu:87  */
+    FMHIP_OP_SQRT       = 11,  /* sqrt(a)         cuSqrt        .cu:109 */
+    FMHIP_OP_EXP        = 12,  /* exp(a)          cuExp         .cu:119 */
+    FMHIP_OP_LOG        = 13,  /* log(a)          cuLog         .cu:129 */
+    FMHIP_OP_INVERT     = 14,  /* 1.0f / a        invert        .cu:139 */
+    FMHIP_OP_ABS        = 15,  /* |a|             cuAbs         .cu:149 */
+    FMHIP_OP_SIN        = 16,  /* sin(a)          twin :927     */
+    FMHIP_OP_COS        = 17,  /* cos(a)          twin :942     */
+    FMHIP_OP_ISNAN      = 18,  /* a!=a ? 1 : 0    twin :1441    */
+    /* vector ∘ vector:  fmhip_call_v2s0 */
+    FMHIP_OP_CAP        = 19,  /* min(a,b)        cap           .cu:160 */
+    FMHIP_OP_FLOOR      = 20,  /* max(a,b)        cuFloor       .cu:170 */
+    FMHIP_OP_ADD        = 21,  /* a + b           add           .cu:180 */
+    FMHIP_OP_SUB        = 22,  /* a - b           sub           .cu:191 */
+    FMHIP_OP_MULT       = 23,  /* a * b           mult          .cu:202 */
+    FMHIP_OP_DIV        = 24,  /* a / b           cuDiv         .cu:213 */
+    /* two vectors and a scalar:  fmhip_call_v2s1 */
+    FMHIP_OP_ACCRUE     = 25,  /* a * (1 + b*s)   accrue        .cu:224 */
+    FMHIP_OP_DISCOUNT   = 26,  /* a / (1 + b*s)   discount      .cu:234 */
+    FMHIP_OP_ADDPRODUCT_VS = 27, /* a + b*s       addProduct_vs .cu:257 */
+    /* three vectors:  fmhip_call_v3s0 */
+    FMHIP_OP_ADDPRODUCT = 28,  /* a + b*c         addProduct    .cu:247 */
+    FMHIP_OP_ADDRATIO   = 29,  /* a + b/c         addRatio      .cu:267 */
+    FMHIP_OP_SUBRATIO   = 30,  /* a - b/c         subRatio      .cu:277 */
+    FMHIP_OP_CHOOSE     = 31,  /* a>=0 ? b : c    twin :1264    */
+    FMHIP_OP__COUNT     = 32
+} fmhip_opcode;
+
+/* Result of an on-device reduction over one vector (all fp64). */
+typedef struct fmhip_moments {
+    double sum;     /* Σ (x_i - shift)            */
+    double sumsq;   /* Σ (x_i - shift)^2          */
+    double min;     /* min x_i (NaN if any NaN, Java Math.min semantics) */
+    double max;     /* max x_i (NaN if any NaN)   */
+} fmhip_moments;
+
+typedef struct fmhip_pool_stats_t {
+    int64_t bytes_reserved;     /* device bytes obtained from hipMalloc and still held      */
+    int64_t bytes_in_use;       /* bytes handed out to live vectors                         */
+    int64_t bytes_cached;       /* bytes sitting in free lists                              */
+    int64_t device_bytes_free;  /* hipMemGetInfo free (queried here only, never on the hot path) */
+    int64_t device_bytes_total;
+    int64_t n_alloc_hits;       /* allocations served from a free list                      */
+    int64_t n_alloc_misses;     /* allocations that had to call hipMalloc                   */
+    int64_t n_live_vectors;
+    int64_t n_kernel_launches;  /* launches since init (fusion statistics)                  */
+    int64_t n_ops_executed;     /* element-wise ops executed inside those launches          */
+} fmhip_pool_stats_t;
+
+/* ---------------------------------------------------------------- lifecycle */
+
+/* Bind this process to one device and create the runtime (stream, pool, kernels).
+ * device_index < 0: use env FMHIP_DEVICE_INDEX, else LOCAL_RANK, else 0.
+ * Idempotent for the same device.  (RandomVariableCuda.java:159-248) */
+int fmhip_init(int device_index);
+int fmhip_shutdown(void);
+int fmhip_is_initialized(void);
+int fmhip_abi_version(void);
+/* Message of the calling thread's most recent failing call ("" if none). Never NULL. */
+const char* fmhip_last_error(void);
+/* Device name into buf (NUL-terminated, truncated), CU count, HBM bytes. Any pointer may be NULL. */
+int fmhip_device_info(char* name_buf, int name_buf_len, int* n_compute_units, int64_t* hbm_bytes);
+/* Block until all enqueued device work is complete (cuCtxSynchronize in the reference, :474). */
+int fmhip_synchronize(void);
+/* The HIP stream (hipStream_t as void*) all work is enqueued on — for interop with torch / RCCL. */
+int fmhip_get_stream(void** stream_out);
+
+/* ---------------------------------------------------------------- vectors */
+
+/* Narrow double→float on the host (RandomVariableCuda.java:768-774) and upload. n >= 0. */
+int fmhip_vec_create_from_double(const double* host_values, int64_t n, fmhip_vec* out);
+int fmhip_vec_create_from_float(const float* host_values, int64_t n, fmhip_vec* out);
+/* Device vector with every element = (float)value (twin ctor RandomVariableFromFloatArray.java:139-146). */
+int fmhip_vec_create_filled(int64_t n, double value, fmhip_vec* out);
+/* Pool allocation without initialisation (RandomVariableCuda.getDevicePointer(long), :737). */
+int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out);
+int fmhip_vec_retain(fmhip_vec v);
+int fmhip_vec_release(fmhip_vec v);
+int fmhip_vec_size(fmhip_vec v, int64_t* n_out);
+/* getRealizations(): materialise, D2H, widen float→double (RandomVariableCuda.java:1116-1123). */
+int fmhip_vec_read_double(fmhip_vec v, double* host_out, int64_t n);
+int fmhip_vec_read_float(fmhip_vec v, float* host_out, int64_t n);
+/* Raw device pointer of the (materialised) fp32 storage; valid until the handle is released. */
+int fmhip_vec_device_ptr(fmhip_vec v, void** device_ptr_out);
+
+/* ---------------------------------------------------------------- eager ops, one per reference launch helper */
+
+/* result = f(a)            callFunctionv1s0 (RandomVariableCuda.java:483) */
+int fmhip_call_v1s0(int opcode, fmhip_vec a, fmhip_vec* out);
+/* result = f(a, (float)s)  callFunctionv1s1 (:515) */
+int fmhip_call_v1s1(int opcode, fmhip_vec a, double s, fmhip_vec* out);
+/* result = f(a, b)         callFunctionv2s0 (:493) */
+int fmhip_call_v2s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec* out);
+/* result = f(a, b, (float)s) callFunctionv2s1 (:527) */
+int fmhip_call_v2s1(int opcode, fmhip_vec a, fmhip_vec b, double s, fmhip_vec* out);
+/* result = f(a, b, c)      callFunctionv3s0 (:504) */
+int fmhip_call_v3s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec c, fmhip_vec* out);
+
+/* Deferred execution of the five calls above: when enabled they only record a node and return a
+ * pending handle; chains are executed as ONE fused launch when a value is needed (read, reduce,
+ * device_ptr, fmhip_flush) — results are bit-identical to eager execution. Default: disabled (eager).
+ * Returns the previous setting through *previous (may be NULL). */
+int fmhip_set_fusion(int enabled, int* previous);
+/* Execute every pending node that is still referenced by a live handle (identical programs over
+ * different vectors are batched into one launch). */
+int fmhip_flush(void);
+
+/* ---------------------------------------------------------------- reductions */
+
+/* One pass over v on the device: Σ(x-shift), Σ(x-shift)², min, max with fp64 accumulation; 32 bytes
+ * come back.  Replaces the reference's D2H of the whole vector + host loops
+ * (RandomVariableCuda.java:830-901 → RandomVariableFromFloatArray.java:284-382). */
+int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out);
+/* Same, but the 4 doubles are written to caller-owned DEVICE memory (e.g. a torch tensor that is then
+ * all-reduced with RCCL); asynchronous on the runtime stream. */
+int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles);
+
+/* ---------------------------------------------------------------- fused programs */
+
+/* One SSA instruction. Values are numbered: 0 … n_inputs-1 are the program inputs, n_inputs+i is the
+ * result of ops[i]. Unused operands are -1. */
+typedef struct fmhip_prog_op {
+    int32_t opcode;     /* fmhip_opcode */
+    int32_t a, b, c;    /* operand value ids */
+    double  scalar;     /* narrowed to float, used by the *_S / v2s1 opcodes */
+} fmhip_prog_op;
+
+/* Compile an op stream once. out_values[n_outputs]: value ids materialised as new vectors;
+ * reduce_values[n_reduce] (n_reduce <= 2): value ids reduced to fmhip_moments inside the same launch. */
+int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs,
+                         const int32_t* out_values, int n_outputs,
+                         const int32_t* reduce_values, int n_reduce,
+                         fmhip_program* out);
+int fmhip_program_release(fmhip_program p);
+/* Number of kernel launches one run of p takes (1 unless the program had to be split). */
+int fmhip_program_launch_count(fmhip_program p, int* n_launches);
+/* Run p over `batch` independent input tuples in ONE launch (horizontal batching).
+ *   inputs  [batch * n_inputs ]  all of equal size
+ *   outputs [batch * n_outputs]  receives new handles (caller releases)
+ *   reduce_shift [n_reduce] or NULL (=0)
+ *   moments [batch * n_reduce] host results, or NULL to skip the host read-back
+ *   device_moments: optional device buffer of batch*n_reduce*4 doubles, or NULL */
+int fmhip_program_run(fmhip_program p, int batch,
+                      const fmhip_vec* inputs, fmhip_vec* outputs,
+                      const double* reduce_shift, fmhip_moments* moments, void* device_moments);
+/* As fmhip_program_run, but writes into caller-provided existing output vectors (no allocation);
+ * an output may alias an input of the same row. */
+int fmhip_program_run_into(fmhip_program p, int batch,
+                           const fmhip_vec* inputs, const fmhip_vec* outputs,
+                           const double* reduce_shift, fmhip_moments* moments, void* device_moments);
+
+/* ---------------------------------------------------------------- Brownian increments */
+
+/* Fill n_steps*n_factors new vectors of n_paths N(0, dt_step) increments:
+ *   out[step*n_factors + factor][p] = (float)sqrt(dt[step]) * Z(seed, step, factor, path_offset + p)
+ * Z is a counter-based Philox4x32-10 + Box–Muller normal: a pure function of (seed, step, factor,
+ * global path index), hence independent of launch geometry and of how paths are sharded over GPUs.
+ * Replaces curandGenerateNormal per (step,factor) (BrownianMotionCudaWithRandomVariableCuda.java:168-178). */
+int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
+                      const double* dt, fmhip_vec* out);
+
+/* ---------------------------------------------------------------- pool */
+
+/* Return cached (unused) device buffers to the driver (DeviceMemoryPool.clean, :393). */
+int fmhip_pool_clean(void);
+/* clean + drop every cached buffer; live vectors stay valid (DeviceMemoryPool.purge, :424). */
+int fmhip_pool_purge(void);
+int fmhip_pool_stats(fmhip_pool_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMHIP_H */
