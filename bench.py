@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the RandomVariable hot path on MI355X (BASELINE.json configs[1]).
+
+A step = ONE pass of the canonical fused RandomVariable stream S (SURVEY.md §8d config 2:
+    t = x.add(4).div(2).mult(y).sub(z);  u = t.exp().log().abs().sqrt();
+    v = u.cap(1.5).floor(0.25).addProduct(y,z);  w = t.choose(v,x);  {avg,var,min,max}(w)
+ — 12 path-ops, 3 input vectors, 1 escaping output, 1 fused reduction) over a batch of B independent
+(x,y,z) triples of N = 1 000 000 paths, executed as ONE horizontally batched launch through the C-ABI
+(fmhip_program_run_into).  B·16 MB ≫ 256 MB Infinity Cache, so the traffic is HBM traffic.
+Inputs are resident in HBM before the timed region starts.
+
+metric  path-ops/s = 12 · N · B · n_gpus / step time        (whole job, all ranks)
+roofline achieved = algorithmic bytes per launch (4 B · (3 in + 1 out) · N · B) / average device duration of the
+         fused-program kernel, measured live with HIP events on the runtime's own stream (fmhip_profile_*).
+cpu_baseline: the oracle (C restatement of the reference's CPU class, one single-threaded loop and one fresh
+         array per method call — the reference's cost model) timed on this host, rank 0, N=1 only.
+
+Multi-GPU (torchrun, one rank per GPU): independent Monte-Carlo path blocks per rank (weak scaling, no data-path
+collective); the only exchange is ONE small RCCL all-gather of the per-rank expectation partials per step.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_PATHS = 1_000_000
+N_OPS = 12
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4-copy ceiling ≈ 6290 GB/s
+
+
+def build_stream_s(fm):
+    p = fm.Program(3)
+    x, y, z = 0, 1, 2
+    t = p.op("SUB", p.op("MULT", p.op("DIV_S", p.op("ADD_S", x, s=4.0), s=2.0), y), z)
+    u = p.op("SQRT", p.op("ABS", p.op("LOG", p.op("EXP", t))))
+    v = p.op("ADDPRODUCT", p.op("FLOOR_S", p.op("CAP_S", u, s=1.5), s=0.25), y, z)
+    w = p.op("CHOOSE", t, v, x)
+    p.output(w)
+    p.reduce(w)
+    return p.compile()
+
+
+def synthetic_inputs(fm, batch, n, rank):
+    """Uniform [0,1) (+0.5 for y, z) generated ON the device from the Philox stream: BrownianMotionHip gives N(0,dt)
+    vectors; a fused program maps them to the ranges config 2 asks for.  Path offset = rank·n (distinct blocks)."""
+    bm = fm.BrownianMotionHip(fm.TimeDiscretization(0.0, batch, 1.0), 3, n, 31415, path_offset=rank * n)
+    rows = []
+    for b in range(batch):
+        g = [bm.getBrownianIncrement(b, f) for f in range(3)]
+        x = g[0].mult(0.25).add(0.5).cap(1.0).floor(0.0)
+        y = g[1].mult(0.25).add(1.0).cap(1.5).floor(0.5)
+        z = g[2].mult(0.25).add(1.0).cap(1.5).floor(0.5)
+        rows.append([x.realizations, y.realizations, z.realizations])
+    del bm
+    return rows
+
+
+def cpu_baseline(target_seconds=12.0):
+    """Stream S on the CPU oracle, one 1M-path triple per pass, repeated for ~target_seconds."""
+    import oracle as o
+    n = N_PATHS
+    x = o.f_from_double(o.java_random_doubles(31415, n))
+    y = o.f_from_double(o.java_random_doubles(27182, n) + 0.5)
+    z = o.f_from_double(o.java_random_doubles(16180, n) + 0.5)
+
+    def one_pass():
+        t = o.f_v2s0("SUB", o.f_v2s0("MULT", o.f_v1s1("DIV_S", o.f_v1s1("ADD_S", x, 4.0), 2.0), y), z)
+        u = o.f_v1s0("SQRT", o.f_v1s0("ABS", o.f_v1s0("LOG", o.f_v1s0("EXP", t))))
+        v = o.f_v3s0("ADDPRODUCT", o.f_v1s1("FLOOR_S", o.f_v1s1("CAP_S", u, 1.5), 0.25), y, z)
+        w = o.f_v3s0("CHOOSE", t, v, x)
+        return o.f_average(w), o.f_variance(w), o.f_min(w), o.f_max(w)
+
+    one_pass()
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        one_pass()
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or passes >= 2000:
+            break
+    return {"value": N_OPS * n * passes / dt, "unit": "path-ops/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} passes of stream S over one 1M-path (x,y,z) triple, {dt:.1f} s, "
+                      f"C restatement of RandomVariableFromFloatArray (one loop + one fresh array per op)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="independent (x,y,z) triples per launch")
+    ap.add_argument("--paths", type=int, default=N_PATHS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N …")
+    import torch                         # before libfmhip: one HIP runtime in the process (see _native.lib)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+    fm.init(local_rank)
+    dev_name, cus, hbm = fm.device_info()
+    n, B = args.paths, args.batch
+
+    prog = build_stream_s(fm)
+    rows = synthetic_inputs(fm, B, n, rank)
+    out_rows = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
+    fm.synchronize()
+
+    ext_stream = torch.cuda.ExternalStream(fm.stream_ptr(), device=torch.device("cuda", local_rank))
+    partial = torch.zeros(B * 4, dtype=torch.float64, device=f"cuda:{local_rank}")
+    gathered = torch.zeros(world * B * 4, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+
+    def step():
+        # one launch: 12 ops over B triples + fused reductions; moments stay on the device
+        prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
+        if world > 1:                    # the single exchange: expectation partials of all ranks
+            with torch.cuda.stream(ext_stream):
+                dist.all_gather_into_tensor(gathered, partial)
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        fm.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # combined expectations (sanity: finite, and identical on every rank by construction)
+    if world > 1:
+        g = gathered.view(world, B, 4)
+        mean_w = float((g[:, :, 0].sum(0) / (world * n)).mean().item())
+    else:
+        mean_w = float((partial.view(B, 4)[:, 0] / n).mean().item())
+    assert np.isfinite(mean_w)
+
+    # live kernel duration of the dominant kernel (HIP events on the runtime stream), separate short pass
+    fm.profile_enable(True)
+    for _ in range(max(5, min(args.steps, 20))):
+        prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
+    kernel_ms, n_launch = fm.profile_read()
+    fm.profile_enable(False)
+    avg_kernel_s = kernel_ms / 1e3 / max(1, n_launch)
+    alg_bytes = 4.0 * (3 + 1) * n * B
+    achieved = alg_bytes / avg_kernel_s / 1e9
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = N_OPS * n * B * world / (elapsed / args.steps)
+        line = {
+            "metric": "Monte-Carlo path-ops/sec (fused RandomVariable stream)",
+            "value": value, "unit": "path-ops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RandomVariableHipFactory 1M-path elementwise+reduction microbench: stream S "
+                                   "(12 fused path-ops, 3 inputs, 1 output) + fused {sum,sumsq,min,max}, "
+                                   f"batch of {B} independent (x,y,z) triples per launch",
+                       "paths_per_gpu": n, "batch": B, "ops_per_path": N_OPS,
+                       "parallelism": f"path-shard x{world}" if world > 1 else "single GPU",
+                       "device": dev_name, "compute_units": cus},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fm_program_kernel<1,false>", "avg_kernel_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "mean_w": mean_w,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    del rows, out_rows
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""finmath-hip: MI355X-native RandomVariable / RandomVariableFactory / BrownianMotion engine.
+
+Layers (bottom-up): csrc/kernels.hip (hand-written gfx950 kernels) → csrc/runtime.cpp (pool, handles,
+program compiler, lazy fusion) → csrc/abi.cpp = the C-ABI of include/fmhip.h (libfmhip.so) →
+this package: ctypes binding (_native) and the host-side mirror of the reference's Java classes.
+
+There is NO CPU fallback: every stochastic operation runs in libfmhip.so on the GPU or raises.
+The directory name contains hyphens; import it with
+``importlib.import_module("finmath-lib-cuda-extensions_amd")``.
+"""
+from __future__ import annotations
+
+import ctypes as _C
+
+from . import _native
+from ._native import FmhipError, Moments, PoolStats, ProgOp, build
+from .random_variable import OP, DeviceVector, RandomVariableHip, RandomVariableHipFactory
+from .brownian_motion import BrownianMotionHip, TimeDiscretization
+from .program import Program
+
+
+def lib():
+    return _native.lib()
+
+
+def init(device_index: int = -1) -> None:
+    """Bind this process to one GPU (one rank per GPU). -1: FMHIP_DEVICE_INDEX, LOCAL_RANK, else 0."""
+    _native.check(lib().fmhip_init(int(device_index)))
+
+
+def shutdown() -> None:
+    _native.check(lib().fmhip_shutdown())
+
+
+def synchronize() -> None:
+    _native.check(lib().fmhip_synchronize())
+
+
+def clean() -> None:
+    """RandomVariableCuda.clean() (RandomVariableCuda.java:750-752)."""
+    _native.check(lib().fmhip_pool_clean())
+
+
+def purge() -> None:
+    """RandomVariableCuda.purge() (RandomVariableCuda.java:754-756) — the reference's tests call it in @After."""
+    import gc
+    gc.collect()
+    _native.check(lib().fmhip_pool_purge())
+
+
+def set_fusion(enabled: bool) -> bool:
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_set_fusion(1 if enabled else 0, _C.byref(prev)))
+    return bool(prev.value)
+
+
+def flush() -> None:
+    _native.check(lib().fmhip_flush())
+
+
+def pool_stats() -> PoolStats:
+    s = PoolStats()
+    _native.check(lib().fmhip_pool_stats(_C.byref(s)))
+    return s
+
+
+def device_info():
+    name = _C.create_string_buffer(256)
+    cus, hbm = _C.c_int(0), _C.c_int64(0)
+    _native.check(lib().fmhip_device_info(name, 256, _C.byref(cus), _C.byref(hbm)))
+    return name.value.decode(), cus.value, hbm.value
+
+
+def stream_ptr() -> int:
+    p = _C.c_void_p(0)
+    _native.check(lib().fmhip_get_stream(_C.byref(p)))
+    return p.value or 0
+
+
+def profile_enable(enabled: bool) -> None:
+    _native.check(lib().fmhip_profile_enable(1 if enabled else 0))
+
+
+def profile_read():
+    """(sum of fused-program kernel durations in ms, number of launches) since the last read."""
+    ms, n = _C.c_double(0.0), _C.c_int64(0)
+    _native.check(lib().fmhip_profile_read(_C.byref(ms), _C.byref(n)))
+    return ms.value, n.value

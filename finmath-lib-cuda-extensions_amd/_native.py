@@ -1,0 +1,118 @@
+"""ctypes binding of libfmhip.so — the C-ABI declared in include/fmhip.h, nothing else.
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfmhip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/fmhip.h declares (tests/test_abi_symbols.py checks the header against this list)
+SYMBOLS = [
+    "fmhip_init", "fmhip_shutdown", "fmhip_is_initialized", "fmhip_abi_version", "fmhip_last_error",
+    "fmhip_device_info", "fmhip_synchronize", "fmhip_get_stream",
+    "fmhip_vec_create_from_double", "fmhip_vec_create_from_float", "fmhip_vec_create_filled",
+    "fmhip_vec_create_uninitialized", "fmhip_vec_retain", "fmhip_vec_release", "fmhip_vec_size",
+    "fmhip_vec_read_double", "fmhip_vec_read_float", "fmhip_vec_device_ptr",
+    "fmhip_call_v1s0", "fmhip_call_v1s1", "fmhip_call_v2s0", "fmhip_call_v2s1", "fmhip_call_v3s0",
+    "fmhip_set_fusion", "fmhip_flush",
+    "fmhip_reduce_moments", "fmhip_reduce_moments_device",
+    "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count",
+    "fmhip_program_run", "fmhip_program_run_into",
+    "fmhip_bm_generate",
+    "fmhip_pool_clean", "fmhip_pool_purge", "fmhip_pool_stats",
+    "fmhip_profile_enable", "fmhip_profile_read",
+]
+
+OK = 0
+ERR_INVALID_HANDLE, ERR_SIZE_MISMATCH, ERR_OUT_OF_MEMORY, ERR_HIP = -1, -2, -3, -4
+ERR_INVALID_ARGUMENT, ERR_NOT_INITIALIZED, ERR_UNSUPPORTED, ERR_PROGRAM_LIMIT = -5, -6, -7, -8
+
+
+class Moments(C.Structure):
+    _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("min", C.c_double), ("max", C.c_double)]
+
+
+class ProgOp(C.Structure):
+    _fields_ = [("opcode", C.c_int32), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("scalar", C.c_double)]
+
+
+class PoolStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "bytes_reserved", "bytes_in_use", "bytes_cached", "device_bytes_free", "device_bytes_total",
+        "n_alloc_hits", "n_alloc_misses", "n_live_vectors", "n_kernel_launches", "n_ops_executed")]
+
+
+class FmhipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"fmhip error {code}: {message}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 … → lib/libfmhip.so (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; builds it if the source tree is newer (never silently substitutes anything)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # NOTE: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).  A process that uses both
+    # must `import torch` BEFORE this library is loaded, so that the loader resolves our NEEDED
+    # libamdhip64.so.7 to the runtime already in the process (one HIP runtime, shared device pointers).
+    if not os.path.exists(LIB_PATH):
+        build()
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing — the HIP extension is required (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    vec, i64, i32, dbl, vp = C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p
+    pv = C.POINTER(C.c_int64)
+    sig = {
+        "fmhip_init": [i32], "fmhip_shutdown": [], "fmhip_is_initialized": [], "fmhip_abi_version": [],
+        "fmhip_device_info": [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)],
+        "fmhip_synchronize": [], "fmhip_get_stream": [C.POINTER(vp)],
+        "fmhip_vec_create_from_double": [C.POINTER(dbl), i64, pv],
+        "fmhip_vec_create_from_float": [C.POINTER(C.c_float), i64, pv],
+        "fmhip_vec_create_filled": [i64, dbl, pv], "fmhip_vec_create_uninitialized": [i64, pv],
+        "fmhip_vec_retain": [vec], "fmhip_vec_release": [vec], "fmhip_vec_size": [vec, C.POINTER(i64)],
+        "fmhip_vec_read_double": [vec, C.POINTER(dbl), i64], "fmhip_vec_read_float": [vec, C.POINTER(C.c_float), i64],
+        "fmhip_vec_device_ptr": [vec, C.POINTER(vp)],
+        "fmhip_call_v1s0": [i32, vec, pv], "fmhip_call_v1s1": [i32, vec, dbl, pv],
+        "fmhip_call_v2s0": [i32, vec, vec, pv], "fmhip_call_v2s1": [i32, vec, vec, dbl, pv],
+        "fmhip_call_v3s0": [i32, vec, vec, vec, pv],
+        "fmhip_set_fusion": [i32, C.POINTER(i32)], "fmhip_flush": [],
+        "fmhip_reduce_moments": [vec, dbl, C.POINTER(Moments)], "fmhip_reduce_moments_device": [vec, dbl, vp],
+        "fmhip_program_create": [C.POINTER(ProgOp), i32, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), i32, pv],
+        "fmhip_program_release": [i64], "fmhip_program_launch_count": [i64, C.POINTER(i32)],
+        "fmhip_program_run": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
+        "fmhip_program_run_into": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
+        "fmhip_bm_generate": [i64, i32, i32, i64, i64, C.POINTER(dbl), pv],
+        "fmhip_pool_clean": [], "fmhip_pool_purge": [], "fmhip_pool_stats": [C.POINTER(PoolStats)],
+        "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],
+    }
+    for name, args in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    L.fmhip_last_error.argtypes = []
+    L.fmhip_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(status: int) -> None:
+    if status != OK:
+        raise FmhipError(status, lib().fmhip_last_error().decode("utf-8", "replace"))

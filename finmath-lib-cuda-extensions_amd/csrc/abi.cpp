@@ -1,0 +1,152 @@
+// abi.cpp — the extern "C" surface declared in include/fmhip.h.  No logic: argument checks, the engine
+// lock, exception → status translation.  A JNI layer maps 1:1 onto these.
+#include "runtime.hpp"
+
+#include <cstring>
+#include <string>
+
+using fm::Engine;
+using fm::Error;
+
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guarded(F&& f) {
+    try {
+        std::lock_guard<std::recursive_mutex> lock(Engine::get().mu);
+        f();
+        return FMHIP_OK;
+    } catch (const Error& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "host allocation failed";
+        return FMHIP_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return FMHIP_ERR_HIP;
+    }
+}
+
+static void need(const void* p, const char* what) {
+    if (!p) throw Error(FMHIP_ERR_INVALID_ARGUMENT, std::string("null pointer: ") + what);
+}
+
+extern "C" {
+
+int fmhip_init(int device_index) { return guarded([&] { Engine::get().init(device_index); }); }
+int fmhip_shutdown(void) { return guarded([&] { Engine::get().shutdown(); }); }
+int fmhip_is_initialized(void) { return Engine::get().initialized() ? 1 : 0; }
+int fmhip_abi_version(void) { return FMHIP_ABI_VERSION; }
+const char* fmhip_last_error(void) { return g_last_error.c_str(); }
+
+int fmhip_device_info(char* name_buf, int name_buf_len, int* n_compute_units, int64_t* hbm_bytes) {
+    return guarded([&] { Engine::get().device_info(name_buf, name_buf_len, n_compute_units, hbm_bytes); });
+}
+int fmhip_synchronize(void) { return guarded([&] { Engine::get().synchronize(); }); }
+int fmhip_get_stream(void** stream_out) {
+    return guarded([&] { need(stream_out, "stream_out"); Engine::get().require_init(); *stream_out = (void*)Engine::get().stream(); });
+}
+
+int fmhip_vec_create_from_double(const double* host_values, int64_t n, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); *out = Engine::get().create_from_host(host_values, true, n); });
+}
+int fmhip_vec_create_from_float(const float* host_values, int64_t n, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); *out = Engine::get().create_from_host(host_values, false, n); });
+}
+int fmhip_vec_create_filled(int64_t n, double value, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); *out = Engine::get().create_filled(n, (float)value); });
+}
+int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
+}
+int fmhip_vec_retain(fmhip_vec v) { return guarded([&] { Engine::get().retain(v); }); }
+int fmhip_vec_release(fmhip_vec v) { return guarded([&] { Engine::get().release(v); }); }
+int fmhip_vec_size(fmhip_vec v, int64_t* n_out) {
+    return guarded([&] { need(n_out, "n_out"); Engine::get().require_init(); *n_out = Engine::get().node(v)->n; });
+}
+int fmhip_vec_read_double(fmhip_vec v, double* host_out, int64_t n) {
+    return guarded([&] { Engine::get().read(v, host_out, true, n); });
+}
+int fmhip_vec_read_float(fmhip_vec v, float* host_out, int64_t n) {
+    return guarded([&] { Engine::get().read(v, host_out, false, n); });
+}
+int fmhip_vec_device_ptr(fmhip_vec v, void** device_ptr_out) {
+    return guarded([&] { need(device_ptr_out, "device_ptr_out"); *device_ptr_out = Engine::get().device_ptr(v); });
+}
+
+int fmhip_call_v1s0(int opcode, fmhip_vec a, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, 0.0, false); });
+}
+int fmhip_call_v1s1(int opcode, fmhip_vec a, double s, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, s, true); });
+}
+int fmhip_call_v2s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, 0.0, false); });
+}
+int fmhip_call_v2s1(int opcode, fmhip_vec a, fmhip_vec b, double s, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, s, true); });
+}
+int fmhip_call_v3s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec c, fmhip_vec* out) {
+    return guarded([&] { need(out, "out"); const fmhip_vec in[3] = { a, b, c }; *out = Engine::get().call(opcode, 3, in, 0.0, false); });
+}
+
+int fmhip_set_fusion(int enabled, int* previous) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        e.require_init();
+        if (previous) *previous = e.fusion ? 1 : 0;
+        if (e.fusion && !enabled) e.flush_all();
+        e.fusion = enabled != 0;
+    });
+}
+int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); }); }
+
+int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
+    return guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr); });
+}
+int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
+    return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
+}
+
+int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, const int32_t* out_values, int n_outputs,
+                         const int32_t* reduce_values, int n_reduce, fmhip_program* out) {
+    return guarded([&] {
+        need(out, "out");
+        *out = Engine::get().program_create(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce);
+    });
+}
+int fmhip_program_release(fmhip_program p) { return guarded([&] { Engine::get().program_release(p); }); }
+int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
+    return guarded([&] {
+        need(n_launches, "n_launches");
+        Engine::get().require_init();
+        *n_launches = 1 + (Engine::get().program(p)->n_red > 0 ? 1 : 0);
+    });
+}
+int fmhip_program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs,
+                      const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
+    return guarded([&] { Engine::get().program_run(p, batch, inputs, outputs, false, reduce_shift, moments, device_moments); });
+}
+int fmhip_program_run_into(fmhip_program p, int batch, const fmhip_vec* inputs, const fmhip_vec* outputs,
+                           const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
+    return guarded([&] {
+        Engine::get().program_run(p, batch, inputs, const_cast<fmhip_vec*>(outputs), true, reduce_shift, moments, device_moments);
+    });
+}
+
+int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
+                      const double* dt, fmhip_vec* out) {
+    return guarded([&] { Engine::get().bm_generate(seed, n_steps, n_factors, n_paths, path_offset, dt, out); });
+}
+
+int fmhip_pool_clean(void) { return guarded([&] { Engine::get().pool_clean(); }); }
+int fmhip_pool_purge(void) { return guarded([&] { Engine::get().pool_purge(); }); }
+int fmhip_pool_stats(fmhip_pool_stats_t* out) { return guarded([&] { Engine::get().pool_stats(out); }); }
+
+int fmhip_profile_enable(int enabled) { return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
+int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches) {
+    return guarded([&] { Engine::get().profile_read(kernel_ms_total, n_launches); });
+}
+
+} // extern "C"

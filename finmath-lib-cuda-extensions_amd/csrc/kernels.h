@@ -1,0 +1,25 @@
+// kernels.h — host-callable launchers of the gfx950 kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "fm_program.h"
+
+namespace fm {
+
+struct DevBmArgs {
+    float*       slab;           // n_streams vectors, `stride_floats` apart (stride is a multiple of 64 floats)
+    const float* sqrt_dt;        // [n_steps]  (float)sqrt(dt[step])
+    int64_t      stride_floats;
+    int64_t      n_paths;        // paths held by this process
+    int64_t      path_offset;    // global index of local path 0 (path sharding over GPUs)
+    uint32_t     key0, key1;     // lo32(seed), hi32(seed)
+    uint32_t     n_factors;
+    uint32_t     stream0;        // global stream index (step*n_factors+factor) of local stream 0
+};
+
+hipError_t launch_program(const DevProgramArgs& a, uint32_t blocks_per_row, uint32_t batch, hipStream_t st);
+hipError_t launch_finalize(const DevFinalizeArgs& a, uint32_t n_results, hipStream_t st);
+hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st);
+hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st);
+
+} // namespace fm

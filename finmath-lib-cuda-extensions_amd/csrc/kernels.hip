@@ -1,0 +1,364 @@
+// kernels.hip — the hand-written gfx950 (CDNA4) kernels of the RandomVariable / BrownianMotion hot path.
+//
+//   fm_program_kernel   one launch = a whole chain of RandomVariable methods over `batch` independent
+//                       vector tuples (replaces the reference's one-launch-per-method scheme,
+//                       RandomVariableCuda.java:483-557 + the 27 kernels of RandomVariableCudaKernel.cu),
+//                       optionally ending in fused {Σ, Σ², min, max} reductions (replaces the
+//                       D2H-and-host-loop reductions, RandomVariableCuda.java:830-901).
+//   fm_finalize_kernel  deterministic combine of the per-workgroup reduction partials.
+//   fm_bm_kernel        counter-based Philox4x32-10 + Box–Muller normal increments (replaces
+//                       curandGenerateNormal, BrownianMotionCudaWithRandomVariableCuda.java:168-178).
+//   fm_fill_kernel      constant fill.
+//
+// All four are HBM-bandwidth bound; nothing here is a contraction, MFMA is not used.
+// Design for CDNA4: 64-wide waves, 256-thread workgroups, one 128-bit access per lane per vector
+// (1 KiB per wave-instruction, fully coalesced), every input load of a tile issued before the first
+// use so ≥ n_in KiB per wave are in flight, virtual registers in VGPRs (s_set_gpr_idx — no scratch,
+// no LDS traffic), wave64 shuffles + LDS only for the 4-wave reduction epilogue.
+#include <hip/hip_runtime.h>
+#include "fm_program.h"
+#include "fm_device_math.hpp"
+#include "kernels.h"
+
+namespace fm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Fused program interpreter
+// ---------------------------------------------------------------------------------------------
+
+#define FM_CASE(CODE)                                                                         \
+    case CODE:                                                                                \
+        r0 = eval<CODE>(a0, b0, c0, s); r1 = eval<CODE>(a1, b1, c1, s);                       \
+        r2 = eval<CODE>(a2, b2, c2, s); r3 = eval<CODE>(a3, b3, c3, s);                       \
+        break;
+
+template <int NRED, bool INLINE_ROW>
+__global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A)
+{
+    const uint32_t row = blockIdx.y;
+    // Row block: wave-uniform, read with scalar loads (kernarg segment when INLINE_ROW).
+    const uint64_t* __restrict__ rowp = INLINE_ROW ? A.inline_row : (A.rows + (size_t)row * A.row_words);
+    const uint32_t n_in = A.n_in, n_out = A.n_out, n_ops = A.n_ops;
+    const int64_t n = A.n;
+    const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + n_in + n_out + A.n_red);
+
+    double acc_sum[NRED > 0 ? NRED : 1], acc_sq[NRED > 0 ? NRED : 1];
+    float  acc_min[NRED > 0 ? NRED : 1], acc_max[NRED > 0 ? NRED : 1];
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+        acc_sum[r] = 0.0; acc_sq[r] = 0.0;
+        acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
+    }
+
+    f32x16 R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;     // virtual register file, one vector per element lane
+
+    for (uint32_t tile = blockIdx.x; tile < A.tiles_per_row; tile += gridDim.x) {
+        const int64_t i4 = (int64_t)tile * FM_BLOCK + threadIdx.x;      // float4 index inside the vector
+        const int64_t e0 = i4 * FM_VEC;
+        if (e0 >= n) continue;      // vectors are padded to 256 B: a partially valid float4 is still in bounds
+
+        // ---- preload: every input vector, 16 B per lane, all loads in flight before the first use
+#pragma unroll
+        for (int k = 0; k < FM_MAX_IN; ++k) {
+            if (k < (int)n_in) {
+                const float4* __restrict__ p = reinterpret_cast<const float4*>(rowp[k]);
+                const float4 v = p[i4];
+                R0[k] = v.x; R1[k] = v.y; R2[k] = v.z; R3[k] = v.w;
+            }
+        }
+
+        // ---- interpret: one wave-uniform decode per instruction, four elements per lane
+        for (uint32_t pc = 0; pc < n_ops; ++pc) {
+            const uint32_t w = A.ops[pc].w;
+            const uint32_t code = w & 0xffu;
+            const uint32_t d = (w >> 8) & 15u, ia = (w >> 12) & 15u, ib = (w >> 16) & 15u, ic = (w >> 20) & 15u;
+            const float s = scal[w >> 24];
+            const float a0 = R0[ia], a1 = R1[ia], a2 = R2[ia], a3 = R3[ia];
+            const float b0 = R0[ib], b1 = R1[ib], b2 = R2[ib], b3 = R3[ib];
+            const float c0 = R0[ic], c1 = R1[ic], c2 = R2[ic], c3 = R3[ic];
+            float r0, r1, r2, r3;
+            switch (code) {
+                FM_CASE(FMHIP_OP_CAP_S) FM_CASE(FMHIP_OP_FLOOR_S) FM_CASE(FMHIP_OP_ADD_S) FM_CASE(FMHIP_OP_SUB_S)
+                FM_CASE(FMHIP_OP_BUS_S) FM_CASE(FMHIP_OP_MULT_S) FM_CASE(FMHIP_OP_DIV_S) FM_CASE(FMHIP_OP_VID_S)
+                FM_CASE(FMHIP_OP_POW_S) FM_CASE(FMHIP_OP_SQUARED) FM_CASE(FMHIP_OP_SQRT) FM_CASE(FMHIP_OP_EXP)
+                FM_CASE(FMHIP_OP_LOG) FM_CASE(FMHIP_OP_INVERT) FM_CASE(FMHIP_OP_ABS) FM_CASE(FMHIP_OP_SIN)
+                FM_CASE(FMHIP_OP_COS) FM_CASE(FMHIP_OP_ISNAN) FM_CASE(FMHIP_OP_CAP) FM_CASE(FMHIP_OP_FLOOR)
+                FM_CASE(FMHIP_OP_ADD) FM_CASE(FMHIP_OP_SUB) FM_CASE(FMHIP_OP_MULT) FM_CASE(FMHIP_OP_DIV)
+                FM_CASE(FMHIP_OP_ACCRUE) FM_CASE(FMHIP_OP_DISCOUNT) FM_CASE(FMHIP_OP_ADDPRODUCT_VS)
+                FM_CASE(FMHIP_OP_ADDPRODUCT) FM_CASE(FMHIP_OP_ADDRATIO) FM_CASE(FMHIP_OP_SUBRATIO)
+                FM_CASE(FMHIP_OP_CHOOSE)
+                default: r0 = a0; r1 = a1; r2 = a2; r3 = a3; break;
+            }
+            R0[d] = r0; R1[d] = r1; R2[d] = r2; R3[d] = r3;
+        }
+
+        // ---- materialise the escaping values
+        for (uint32_t k = 0; k < n_out; ++k) {
+            const uint32_t reg = A.out_reg[k];
+            float4* __restrict__ q = reinterpret_cast<float4*>(rowp[n_in + k]);
+            q[i4] = make_float4(R0[reg], R1[reg], R2[reg], R3[reg]);
+        }
+
+        // ---- fused reductions (fp64 accumulation of fp32 values, as the twin does: :325-333, :373-381)
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) {
+            const uint32_t reg = A.red_reg[r];
+            const double shift = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
+            const float x[4] = { R0[reg], R1[reg], R2[reg], R3[reg] };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (e0 + j < n) {
+                    const double dv = (double)x[j] - shift;
+                    acc_sum[r] += dv;
+                    acc_sq[r]  += dv * dv;
+                    acc_min[r] = jmin(x[j], acc_min[r]);
+                    acc_max[r] = jmax(x[j], acc_max[r]);
+                }
+            }
+        }
+    }
+
+    // ---- workgroup combine: wave64 shuffles, then 4 waves through LDS, one partial per workgroup
+    if constexpr (NRED > 0) {
+        __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
+        __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) {
+            double s1 = acc_sum[r], s2 = acc_sq[r];
+            float mn = acc_min[r], mx = acc_max[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                s1 += __shfl_down(s1, off, 64);
+                s2 += __shfl_down(s2, off, 64);
+                mn = jmin(mn, __shfl_down(mn, off, 64));
+                mx = jmax(mx, __shfl_down(mx, off, 64));
+            }
+            if (lane == 0) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int r = 0; r < NRED; ++r) {
+                double s1 = lds_sum[r][0], s2 = lds_sq[r][0];
+                float mn = lds_min[r][0], mx = lds_max[r][0];
+#pragma unroll
+                for (int wv = 1; wv < FM_BLOCK / 64; ++wv) {
+                    s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
+                    mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
+                }
+                double* __restrict__ out = A.partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
+                out[0] = s1; out[1] = s2; out[2] = (double)mn; out[3] = (double)mx;
+            }
+        }
+    }
+}
+
+// Deterministic second stage: one workgroup per (row, reduction) sums the block partials in a fixed order.
+__device__ __forceinline__ double jmin_d(double a, double b) {
+    if (a != a) return a;
+    if (a == 0.0 && b == 0.0 && (__double_as_longlong(b) < 0)) return b;
+    return (a <= b) ? a : b;
+}
+__device__ __forceinline__ double jmax_d(double a, double b) {
+    if (a != a) return a;
+    if (a == 0.0 && b == 0.0 && (__double_as_longlong(a) < 0)) return b;
+    return (a >= b) ? a : b;
+}
+
+__global__ void __launch_bounds__(FM_BLOCK) fm_finalize_kernel(const DevFinalizeArgs A)
+{
+    __shared__ double sh[4][FM_BLOCK];
+    const double* __restrict__ p = A.partials + (size_t)blockIdx.x * A.n_blocks * 4;
+    double s1 = 0.0, s2 = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+    for (uint32_t b = threadIdx.x; b < A.n_blocks; b += FM_BLOCK) {
+        s1 += p[b * 4 + 0]; s2 += p[b * 4 + 1];
+        mn = jmin_d(mn, p[b * 4 + 2]); mx = jmax_d(mx, p[b * 4 + 3]);
+    }
+    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = mn; sh[3][threadIdx.x] = mx;
+    __syncthreads();
+    for (int stride = FM_BLOCK / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + stride];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + stride];
+            sh[2][threadIdx.x] = jmin_d(sh[2][threadIdx.x], sh[2][threadIdx.x + stride]);
+            sh[3][threadIdx.x] = jmax_d(sh[3][threadIdx.x], sh[3][threadIdx.x + stride]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* __restrict__ o = A.out + (size_t)blockIdx.x * 4;
+        o[0] = sh[0][0]; o[1] = sh[1][0]; o[2] = sh[2][0]; o[3] = sh[3][0];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box–Muller normal increments.  Normative definition: oracle/philox_normal.c —
+// the operation order below must not be changed without changing that file (bit-for-bit parity).
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float spec_logf(float u)
+{
+    const uint32_t b = __float_as_uint(u);
+    int e = (int)(b >> 23) - 127;
+    float f = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
+    if (f > 1.41421354f) { f = f * 0.5f; e += 1; }
+    const float s = (f - 1.0f) / (f + 1.0f);
+    const float z = s * s;
+    float p = 0.222222224f;
+    p = __builtin_fmaf(p, z, 0.285714298f);
+    p = __builtin_fmaf(p, z, 0.400000006f);
+    p = __builtin_fmaf(p, z, 0.666666687f);
+    p = p * z;
+    const float lnf = __builtin_fmaf(s, p, s + s);
+    const float ef = (float)e;
+    return __builtin_fmaf(ef, 0.693145751953125f, __builtin_fmaf(ef, 1.42860677e-06f, lnf));
+}
+
+__device__ __forceinline__ void spec_box_muller(uint32_t ra, uint32_t rb, float& za, float& zb)
+{
+    const float u1 = __builtin_fmaf((float)ra, 0x1p-32f, 0x1p-33f);
+    const float radius = __fsqrt_rn(-2.0f * spec_logf(u1));
+    const float t = (float)(rb >> 8) * 0x1p-22f;
+    const int q = (int)t;
+    const float fr = t - (float)q;
+    const bool swap = fr > 0.5f;
+    const float g = swap ? 1.0f - fr : fr;
+    const float x = g * 1.57079637f;
+    const float x2 = x * x;
+    float ps = 2.75573188e-06f;
+    ps = __builtin_fmaf(ps, x2, -1.98412701e-04f);
+    ps = __builtin_fmaf(ps, x2, 8.33333377e-03f);
+    ps = __builtin_fmaf(ps, x2, -1.66666672e-01f);
+    ps = ps * x2;
+    const float sinx = __builtin_fmaf(x, ps, x);
+    float pc = -2.75573192e-07f;
+    pc = __builtin_fmaf(pc, x2, 2.48015876e-05f);
+    pc = __builtin_fmaf(pc, x2, -1.38888892e-03f);
+    pc = __builtin_fmaf(pc, x2, 4.16666679e-02f);
+    pc = __builtin_fmaf(pc, x2, -0.5f);
+    const float cosx = __builtin_fmaf(pc, x2, 1.0f);
+    const float sp = swap ? cosx : sinx;
+    const float cp = swap ? sinx : cosx;
+    float c, s;
+    switch (q & 3) {
+    case 0:  c =  cp; s =  sp; break;
+    case 1:  c = -sp; s =  cp; break;
+    case 2:  c = -cp; s = -sp; break;
+    default: c =  sp; s = -cp; break;
+    }
+    za = radius * c;
+    zb = radius * s;
+}
+
+__device__ __forceinline__ void normal4(uint32_t k0, uint32_t k1, uint64_t pb, uint32_t stream, float z[4])
+{
+    uint32_t r[4];
+    philox4x32_10((uint32_t)pb, (uint32_t)(pb >> 32), stream, 0x464D4850u, k0, k1, r);
+    spec_box_muller(r[0], r[1], z[0], z[1]);
+    spec_box_muller(r[2], r[3], z[2], z[3]);
+}
+
+// grid = (tiles of 256 float4, n_streams).  Vector `stream` lives at slab + stream * stride_floats.
+__global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A)
+{
+    const uint32_t stream = blockIdx.y;
+    const float sq = A.sqrt_dt[stream / A.n_factors];
+    float4* __restrict__ out = reinterpret_cast<float4*>(A.slab + (size_t)stream * A.stride_floats);
+    const int64_t n4 = (A.n_paths + 3) >> 2;
+    const uint32_t gstream = A.stream0 + stream;
+    for (int64_t i4 = (int64_t)blockIdx.x * FM_BLOCK + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * FM_BLOCK) {
+        const uint64_t g0 = (uint64_t)(A.path_offset + i4 * 4);    // global index of this lane's first path
+        float z[4];
+        if ((g0 & 3u) == 0) {
+            normal4(A.key0, A.key1, g0 >> 2, gstream, z);
+        } else {                                                   // shard offset not a multiple of 4: two blocks
+            float za[4], zb[4];
+            normal4(A.key0, A.key1, g0 >> 2, gstream, za);
+            normal4(A.key0, A.key1, (g0 >> 2) + 1, gstream, zb);
+            const uint32_t sft = (uint32_t)(g0 & 3u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t idx = sft + j;
+                float v = 0.0f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { if (idx == (uint32_t)m) v = za[m]; if (idx == (uint32_t)(m + 4)) v = zb[m]; }
+                z[j] = v;
+            }
+        }
+        out[i4] = make_float4(sq * z[0], sq * z[1], sq * z[2], sq * z[3]);
+    }
+}
+
+__global__ void __launch_bounds__(FM_BLOCK) fm_fill_kernel(float4* __restrict__ p, float v, int64_t n4)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FM_BLOCK + threadIdx.x; i < n4; i += (int64_t)gridDim.x * FM_BLOCK)
+        p[i] = make_float4(v, v, v, v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers (the only functions the runtime calls)
+// ---------------------------------------------------------------------------------------------
+
+template <int NRED>
+static hipError_t launch_program_nred(const DevProgramArgs& a, dim3 grid, hipStream_t st)
+{
+    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true>),  grid, dim3(FM_BLOCK), 0, st, a);
+    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false>), grid, dim3(FM_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_program(const DevProgramArgs& a, uint32_t blocks_per_row, uint32_t batch, hipStream_t st)
+{
+    const dim3 grid(blocks_per_row, batch, 1);
+    switch (a.n_red) {
+    case 0:  return launch_program_nred<0>(a, grid, st);
+    case 1:  return launch_program_nred<1>(a, grid, st);
+    case 2:  return launch_program_nred<2>(a, grid, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_finalize(const DevFinalizeArgs& a, uint32_t n_results, hipStream_t st)
+{
+    hipLaunchKernelGGL(fm_finalize_kernel, dim3(n_results), dim3(FM_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st)
+{
+    const int64_t n4 = (a.n_paths + 3) >> 2;
+    int64_t bx = (n4 + FM_BLOCK - 1) / FM_BLOCK;
+    if (bx > 4096) bx = 4096;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(fm_bm_kernel, dim3((uint32_t)bx, n_streams, 1), dim3(FM_BLOCK), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st)
+{
+    const int64_t n4 = n_padded >> 2;
+    int64_t bx = (n4 + FM_BLOCK - 1) / FM_BLOCK;
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(fm_fill_kernel, dim3((uint32_t)bx), dim3(FM_BLOCK), 0, st, reinterpret_cast<float4*>(p), v, n4);
+    return hipGetLastError();
+}
+
+} // namespace fm

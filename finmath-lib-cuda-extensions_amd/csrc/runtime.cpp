@@ -1,0 +1,849 @@
+// runtime.cpp — see runtime.hpp.  Host-only C++; all device work goes through kernels.h.
+#include "runtime.hpp"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <unordered_set>
+
+namespace fm {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return;
+    (void)hipGetLastError();
+    const int code = (e == hipErrorOutOfMemory) ? FMHIP_ERR_OUT_OF_MEMORY : FMHIP_ERR_HIP;
+    throw Error(code, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---------------------------------------------------------------- opcode table
+
+struct OpInfo { int n_vec; bool scalar; };
+static OpInfo op_info(int opcode) {
+    if (opcode >= FMHIP_OP_CAP_S && opcode <= FMHIP_OP_POW_S) return {1, true};
+    if (opcode >= FMHIP_OP_SQUARED && opcode <= FMHIP_OP_ISNAN) return {1, false};
+    if (opcode >= FMHIP_OP_CAP && opcode <= FMHIP_OP_DIV) return {2, false};
+    if (opcode >= FMHIP_OP_ACCRUE && opcode <= FMHIP_OP_ADDPRODUCT_VS) return {2, true};
+    if (opcode >= FMHIP_OP_ADDPRODUCT && opcode <= FMHIP_OP_CHOOSE) return {3, false};
+    return {0, false};
+}
+
+// ---------------------------------------------------------------- pool
+
+static size_t round_cap(size_t bytes) {
+    size_t cap = (bytes + 255) & ~size_t(255);
+    return cap ? cap : 256;
+}
+
+void* Pool::alloc(size_t bytes, size_t* cap_out) {
+    const size_t cap = round_cap(bytes);
+    *cap_out = cap;
+    auto it = free_.find(cap);
+    if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        hits++; cached -= (int64_t)cap; in_use += (int64_t)cap;
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) {              // last resort of the reference pool (:340): drop every cached buffer, retry once
+        (void)hipGetLastError();
+        purge();
+        e = hipMalloc(&p, cap);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e));
+    }
+    misses++; reserved += (int64_t)cap; in_use += (int64_t)cap;
+    return p;
+}
+
+void Pool::release(void* p, size_t cap) {
+    free_[cap].push_back(p);
+    in_use -= (int64_t)cap; cached += (int64_t)cap;
+}
+
+void Pool::purge() {
+    for (auto& kv : free_) {
+        for (void* p : kv.second) { (void)hipFree(p); reserved -= (int64_t)kv.first; cached -= (int64_t)kv.first; }
+        kv.second.clear();
+    }
+    free_.clear();
+}
+
+// ---------------------------------------------------------------- engine lifecycle
+
+Engine& Engine::get() { static Engine* e = new Engine(); return *e; }
+
+void Engine::require_init() const {
+    if (!initialized_) throw Error(FMHIP_ERR_NOT_INITIALIZED, "fmhip_init has not been called");
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+}
+
+void Engine::init(int device_index) {
+    if (device_index < 0) {
+        const char* e = std::getenv("FMHIP_DEVICE_INDEX");
+        if (!e) e = std::getenv("LOCAL_RANK");
+        device_index = e ? std::atoi(e) : 0;
+    }
+    int count = 0;
+    hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    if (count <= 0) throw Error(FMHIP_ERR_HIP, "no HIP device visible");
+    if (device_index >= count) device_index = device_index % count;
+    if (initialized_) {
+        if (device_index != device_) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "already initialised on another device");
+        return;
+    }
+    hip_check(hipSetDevice(device_index), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    ring_cap_ = size_t(4) << 20;
+    hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
+    hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
+    ring_off_ = 0;
+    device_ = device_index;
+    initialized_ = true;
+}
+
+void Engine::shutdown() {
+    if (!initialized_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(stream_);
+    for (auto& kv : nodes_) {           // leak-safe teardown: free storage of every live vector
+        Node* nd = kv.second;
+        if (nd->buf && --nd->buf->refs == 0) {
+            Buffer* b = nd->buf;
+            if (b->parent) { if (--b->parent->refs == 0) { (void)hipFree(b->parent->ptr); delete b->parent; } }
+            else (void)hipFree(b->ptr);
+            delete b;
+        }
+    }
+    nodes_.clear();
+    for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
+    programs_.clear();
+    for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
+    program_cache_.clear();
+    pool_.purge();
+    pool_ = Pool();
+    if (stage_) (void)hipHostFree(stage_);
+    if (ring_host_) (void)hipHostFree(ring_host_);
+    if (ring_dev_) (void)hipFree(ring_dev_);
+    stage_ = ring_host_ = ring_dev_ = nullptr; stage_cap_ = ring_cap_ = ring_off_ = 0;
+    (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+    initialized_ = false;
+    device_ = -1;
+}
+
+void Engine::synchronize() { require_init(); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+
+void Engine::device_info(char* name, int len, int* cus, int64_t* hbm) {
+    require_init();
+    hipDeviceProp_t prop;
+    hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+    if (name && len > 0) { std::strncpy(name, prop.name, (size_t)len - 1); name[len - 1] = 0; }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+}
+
+void* Engine::ensure_stage(size_t bytes) {
+    if (bytes > stage_cap_) {
+        if (stage_) { hip_check(hipStreamSynchronize(stream_), "sync"); (void)hipHostFree(stage_); stage_ = nullptr; stage_cap_ = 0; }
+        size_t cap = std::max(bytes, size_t(1) << 20);
+        hip_check(hipHostMalloc(&stage_, cap, hipHostMallocDefault), "hipHostMalloc(stage)");
+        stage_cap_ = cap;
+    }
+    return stage_;
+}
+
+size_t Engine::ring_reserve(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes > ring_cap_) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch too large for the row-table ring");
+    if (ring_off_ + bytes > ring_cap_) {        // wrap: earlier tables may still be read by queued kernels
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(ring wrap)");
+        ring_off_ = 0;
+    }
+    const size_t off = ring_off_;
+    ring_off_ += bytes;
+    return off;
+}
+
+// ---------------------------------------------------------------- buffers / nodes
+
+Buffer* Engine::new_buffer(int64_t n_floats) {
+    Buffer* b = new Buffer();
+    size_t cap = 0;
+    try { b->ptr = (float*)pool_.alloc((size_t)n_floats * 4, &cap); }
+    catch (...) { delete b; throw; }
+    b->cap = cap; b->refs = 1;
+    return b;
+}
+
+void Engine::buffer_unref(Buffer* b) {
+    if (--b->refs > 0) return;
+    if (b->parent) buffer_unref(b->parent);
+    else pool_.release(b->ptr, b->cap);
+    delete b;
+}
+
+Node* Engine::new_node(int64_t n) {
+    Node* nd = new Node();
+    nd->id = next_id_++;
+    nd->n = n;
+    nd->refs_ext = 1;
+    nodes_[nd->id] = nd;
+    return nd;
+}
+
+Node* Engine::node(fmhip_vec h) {
+    auto it = nodes_.find(h);
+    if (it == nodes_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid vector handle " + std::to_string(h));
+    return it->second;
+}
+
+void Engine::drop_expression(Node* nd) {
+    for (int i = 0; i < nd->n_in; ++i) {
+        Node* in = nd->in[i];
+        nd->in[i] = nullptr;
+        if (in) node_unref_int(in);
+    }
+    nd->n_in = 0; nd->opcode = 0; nd->weight = 0;
+}
+
+void Engine::node_unref_int(Node* nd) { nd->refs_int--; node_maybe_free(nd); }
+
+void Engine::node_maybe_free(Node* nd) {
+    if (nd->refs_ext > 0 || nd->refs_int > 0) return;
+    if (nd->buf) buffer_unref(nd->buf);
+    else drop_expression(nd);
+    delete nd;
+}
+
+void Engine::retain(fmhip_vec h) { require_init(); node(h)->refs_ext++; }
+
+void Engine::release(fmhip_vec h) {
+    require_init();
+    Node* nd = node(h);
+    if (--nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
+}
+
+static void check_n(int64_t n) {
+    if (n < 0 || n > (int64_t(1) << 40)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "invalid vector size " + std::to_string(n));
+}
+
+fmhip_vec Engine::create_uninitialized(int64_t n) {
+    require_init(); check_n(n);
+    Buffer* b = new_buffer(n);
+    Node* nd = new_node(n);
+    nd->buf = b;
+    return nd->id;
+}
+
+fmhip_vec Engine::create_from_host(const void* src, bool is_double, int64_t n) {
+    require_init(); check_n(n);
+    if (n > 0 && !src) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null host pointer");
+    Buffer* b = new_buffer(n);
+    try {
+        const int64_t chunk = int64_t(16) << 20;            // floats per staging round (64 MiB)
+        for (int64_t off = 0; off < n; off += chunk) {
+            const int64_t m = std::min(chunk, n - off);
+            float* st = (float*)ensure_stage((size_t)m * 4);
+            if (is_double) {                                // (float)arrayOfDouble[i], RandomVariableCuda.java:768-774
+                const double* s = (const double*)src + off;
+                for (int64_t i = 0; i < m; ++i) st[i] = (float)s[i];
+            } else std::memcpy(st, (const float*)src + off, (size_t)m * 4);
+            hip_check(hipMemcpyAsync(b->ptr + off, st, (size_t)m * 4, hipMemcpyHostToDevice, stream_), "H2D");
+            hip_check(hipStreamSynchronize(stream_), "H2D sync");
+        }
+    } catch (...) { buffer_unref(b); throw; }
+    Node* nd = new_node(n);
+    nd->buf = b;
+    return nd->id;
+}
+
+fmhip_vec Engine::create_filled(int64_t n, float v) {
+    require_init(); check_n(n);
+    Buffer* b = new_buffer(n);
+    if (n > 0) {
+        hipError_t e = launch_fill(b->ptr, v, (int64_t)(round_cap((size_t)n * 4) / 4), stream_);
+        if (e != hipSuccess) { buffer_unref(b); hip_check(e, "fill"); }
+        n_launches_++;
+    }
+    Node* nd = new_node(n);
+    nd->buf = b;
+    return nd->id;
+}
+
+void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
+    require_init();
+    Node* nd = node(h);
+    if (n != nd->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "read of " + std::to_string(n) + " elements from a vector of " + std::to_string(nd->n));
+    if (n > 0 && !dst) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null host pointer");
+    if (!nd->buf) materialize({nd});
+    const int64_t chunk = int64_t(16) << 20;
+    for (int64_t off = 0; off < n; off += chunk) {
+        const int64_t m = std::min(chunk, n - off);
+        float* st = (float*)ensure_stage((size_t)m * 4);
+        hip_check(hipMemcpyAsync(st, nd->buf->ptr + off, (size_t)m * 4, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "D2H sync");
+        if (as_double) { double* d = (double*)dst + off; for (int64_t i = 0; i < m; ++i) d[i] = st[i]; }
+        else std::memcpy((float*)dst + off, st, (size_t)m * 4);
+    }
+}
+
+void* Engine::device_ptr(fmhip_vec h) {
+    require_init();
+    Node* nd = node(h);
+    if (!nd->buf) materialize({nd});
+    return nd->buf->ptr;
+}
+
+// ---------------------------------------------------------------- program compiler (SSA → register bytecode)
+
+Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
+                         std::vector<float>* scalars_out)
+{
+    const int n_ops = (int)ops.size();
+    if (n_in < 0 || n_in > FM_MAX_IN) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many inputs for one launch");
+    if (n_ops > FM_MAX_OPS) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many ops for one launch");
+    if ((int)outs.size() > FM_MAX_OUT) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many outputs for one launch");
+    if ((int)reds.size() > FM_MAX_RED) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many fused reductions for one launch");
+    if (n_in == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a program needs at least one input vector");
+    const int n_val = n_in + n_ops;
+    std::vector<int> last_use(n_val, -1);
+    for (int i = 0; i < n_ops; ++i) {
+        const OpInfo inf = op_info(ops[i].opcode);
+        if (inf.n_vec == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown opcode " + std::to_string(ops[i].opcode));
+        const int v[3] = { ops[i].a, ops[i].b, ops[i].c };
+        for (int k = 0; k < inf.n_vec; ++k) {
+            if (v[k] < 0 || v[k] >= n_in + i) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "op " + std::to_string(i) + ": bad operand id");
+            last_use[v[k]] = i;
+        }
+    }
+    for (int v : outs) { if (v < 0 || v >= n_val) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad output value id"); last_use[v] = n_ops; }
+    for (int v : reds) { if (v < 0 || v >= n_val) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad reduce value id"); last_use[v] = n_ops; }
+
+    std::vector<int> reg_of(n_val, -1);
+    std::vector<int> free_regs;
+    for (int r = FM_NREG - 1; r >= n_in; --r) free_regs.push_back(r);        // lowest register on top
+    for (int k = 0; k < n_in; ++k) { reg_of[k] = k; }
+    auto give_back = [&](int r) { free_regs.push_back(r); std::sort(free_regs.begin(), free_regs.end(), std::greater<int>()); };
+    for (int k = 0; k < n_in; ++k) if (last_use[k] < 0) give_back(k);
+
+    Program* p = new Program();
+    p->n_in = n_in; p->n_out = (int)outs.size(); p->n_red = (int)reds.size(); p->n_ops = n_ops;
+    std::vector<float> scal;
+    for (int i = 0; i < n_ops; ++i) {
+        const OpInfo inf = op_info(ops[i].opcode);
+        const int v[3] = { ops[i].a, ops[i].b, ops[i].c };
+        int r[3] = { 0, 0, 0 };
+        for (int k = 0; k < inf.n_vec; ++k) r[k] = reg_of[v[k]];
+        for (int k = inf.n_vec; k < 3; ++k) r[k] = r[0];
+        for (int k = 0; k < inf.n_vec; ++k) {               // operands that die here free their register first
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= (v[j] == v[k]);
+            if (!dup && last_use[v[k]] == i) give_back(r[k]);
+        }
+        if (free_regs.empty()) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "register budget of one launch exceeded"); }
+        const int d = free_regs.back(); free_regs.pop_back();
+        reg_of[n_in + i] = d;
+        unsigned slot = 0;
+        if (inf.scalar) {
+            if ((int)scal.size() >= FM_MAX_SCAL) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many scalar operands for one launch"); }
+            slot = (unsigned)scal.size();
+            scal.push_back((float)ops[i].scalar);           // "(float)value", RandomVariableCuda.java:521
+        }
+        p->proto.ops[i].w = fm_pack_op((unsigned)ops[i].opcode, (unsigned)d, (unsigned)r[0], (unsigned)r[1], (unsigned)r[2], slot);
+        if (last_use[n_in + i] < 0) give_back(d);
+    }
+    for (size_t k = 0; k < outs.size(); ++k) p->proto.out_reg[k] = (uint8_t)reg_of[outs[k]];
+    for (size_t k = 0; k < reds.size(); ++k) p->proto.red_reg[k] = (uint8_t)reg_of[reds[k]];
+    if (scal.empty()) scal.push_back(0.0f);
+    p->n_scal = (int)scal.size();
+    p->proto.n_ops = (uint32_t)n_ops; p->proto.n_in = (uint32_t)n_in; p->proto.n_out = (uint32_t)outs.size();
+    p->proto.n_red = (uint32_t)reds.size(); p->proto.n_scal = (uint32_t)p->n_scal;
+    p->proto.row_words = (uint32_t)(n_in + (int)outs.size() + (int)reds.size() + (p->n_scal + 1) / 2);
+    p->scalars = scal;
+    if (scalars_out) *scalars_out = scal;
+    return p;
+}
+
+// ---------------------------------------------------------------- launch
+
+void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments)
+{
+    const int batch = (int)rows.size();
+    if (batch <= 0) return;
+    if (batch > 65535) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch too large");
+    const int n_red = p->n_red;
+    if (n == 0) {       // nothing to compute; reductions of an empty vector as the twin's loops leave them (:288,:303,:325)
+        if (host_moments) for (int i = 0; i < batch * n_red; ++i) host_moments[i] = { 0.0, 0.0, DBL_MAX, -DBL_MAX };
+        if (dev_moments && n_red > 0) {
+            std::vector<double> z((size_t)batch * n_red * 4);
+            for (int i = 0; i < batch * n_red; ++i) { z[i * 4 + 0] = 0; z[i * 4 + 1] = 0; z[i * 4 + 2] = DBL_MAX; z[i * 4 + 3] = -DBL_MAX; }
+            double* st = (double*)ensure_stage(z.size() * 8);
+            std::memcpy(st, z.data(), z.size() * 8);
+            hip_check(hipMemcpyAsync(dev_moments, st, z.size() * 8, hipMemcpyHostToDevice, stream_), "H2D");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+        }
+        return;
+    }
+    DevProgramArgs args = p->proto;
+    const int64_t n4 = (n + 3) / 4;
+    const int64_t tiles = (n4 + FM_BLOCK - 1) / FM_BLOCK;
+    if (tiles > int64_t(0x7fffffff)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "vector too long");
+    int64_t bpr = std::max<int64_t>(1, 2048 / batch);
+    bpr = std::min(bpr, tiles);
+    args.n = n;
+    args.tiles_per_row = (uint32_t)tiles;
+    const size_t rw = args.row_words;
+    const size_t table_bytes = (size_t)batch * rw * 8;
+    uint64_t* table;
+    std::vector<uint64_t> inline_tmp;
+    size_t ring_off = 0;
+    if (batch == 1) { inline_tmp.assign(rw, 0); table = inline_tmp.data(); args.use_inline = 1; }
+    else { ring_off = ring_reserve(table_bytes); table = (uint64_t*)((char*)ring_host_ + ring_off); args.use_inline = 0; }
+    for (int b = 0; b < batch; ++b) {
+        uint64_t* r = table + (size_t)b * rw;
+        const RowSpec& rs = rows[b];
+        for (int k = 0; k < p->n_in; ++k) r[k] = (uint64_t)(uintptr_t)rs.in[k];
+        for (int k = 0; k < p->n_out; ++k) r[p->n_in + k] = (uint64_t)(uintptr_t)rs.out[k];
+        for (int k = 0; k < n_red; ++k) { const double s = rs.shifts ? rs.shifts[k] : 0.0; std::memcpy(&r[p->n_in + p->n_out + k], &s, 8); }
+        float* sc = (float*)(r + p->n_in + p->n_out + n_red);
+        const float* src = rs.scalars ? rs.scalars : p->scalars.data();
+        for (int k = 0; k < p->n_scal; ++k) sc[k] = src[k];
+        if (p->n_scal & 1) sc[p->n_scal] = 0.0f;
+    }
+    if (batch == 1) std::memcpy(args.inline_row, table, rw * 8);
+    else {
+        hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, table, table_bytes, hipMemcpyHostToDevice, stream_), "row table H2D");
+        args.rows = (const uint64_t*)((char*)ring_dev_ + ring_off);
+    }
+
+    void* partials = nullptr; size_t partials_cap = 0;
+    void* results = nullptr;  size_t results_cap = 0;
+    if (n_red > 0) {
+        partials = pool_.alloc((size_t)batch * n_red * bpr * 32, &partials_cap);
+        args.partials = (double*)partials;
+        if (dev_moments) results = dev_moments;
+        else { try { results = pool_.alloc((size_t)batch * n_red * 32, &results_cap); } catch (...) { pool_.release(partials, partials_cap); throw; } }
+    }
+    auto cleanup = [&]() {
+        if (partials) pool_.release(partials, partials_cap);
+        if (results && !dev_moments) pool_.release(results, results_cap);
+    };
+    try {
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (profiling_) {
+            hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate");
+            hip_check(hipEventRecord(ev0, stream_), "hipEventRecord");
+        }
+        hip_check(launch_program(args, (uint32_t)bpr, (uint32_t)batch, stream_), "launch fm_program_kernel");
+        if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 }); }
+        n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
+        if (n_red > 0) {
+            DevFinalizeArgs fa{ (const double*)partials, (double*)results, (uint32_t)bpr };
+            hip_check(launch_finalize(fa, (uint32_t)(batch * n_red), stream_), "launch fm_finalize_kernel");
+            n_launches_++;
+            if (host_moments) {
+                const size_t bytes = (size_t)batch * n_red * 32;
+                void* st = ensure_stage(bytes);
+                hip_check(hipMemcpyAsync(st, results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H");
+                hip_check(hipStreamSynchronize(stream_), "moments sync");
+                std::memcpy(host_moments, st, bytes);
+            }
+        }
+    } catch (...) { cleanup(); throw; }
+    cleanup();
+}
+
+// ---------------------------------------------------------------- lazy front-end
+
+static const int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is executed on its own accord
+
+fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
+    require_init();
+    const OpInfo inf = op_info(opcode);
+    if (inf.n_vec == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown opcode " + std::to_string(opcode));
+    if (inf.n_vec != n_in || inf.scalar != has_scalar)
+        throw Error(FMHIP_ERR_INVALID_ARGUMENT, "opcode " + std::to_string(opcode) + " does not match this call shape");
+    Node* ins[3] = { nullptr, nullptr, nullptr };
+    for (int i = 0; i < n_in; ++i) ins[i] = node(in[i]);
+    for (int i = 1; i < n_in; ++i)
+        if (ins[i]->n != ins[0]->n)
+            throw Error(FMHIP_ERR_SIZE_MISMATCH, "operand sizes differ: " + std::to_string(ins[0]->n) + " vs " + std::to_string(ins[i]->n));
+    Node* nd = new_node(ins[0]->n);
+    nd->opcode = opcode; nd->n_in = n_in; nd->scalar = scalar;
+    int w = 1;
+    for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
+    nd->weight = w;
+    if (!fusion || w > FUSION_MAX_WEIGHT) {
+        try { materialize({nd}); }
+        catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
+    }
+    return nd->id;
+}
+
+struct Engine::Dag {
+    Node* target = nullptr;
+    std::vector<Node*> order;       // pending nodes, operands before users, target last
+    std::vector<Node*> leaves;      // distinct materialised inputs
+    std::vector<Node*> outs;        // target first, then escaping intermediates
+    std::vector<SsaOp> ops;
+    std::vector<int> out_ids;
+    std::vector<float> scalars;
+    std::string sig;
+};
+
+// Linearise the pending expression below `target`.  Returns false when it cannot run as one launch.
+bool Engine::build_dag(Node* target, Dag& dag) {
+    dag.target = target;
+    std::unordered_map<Node*, int> id_of;           // value id per node (leaves first — assigned in a second pass)
+    std::unordered_map<Node*, int> in_dag_uses;
+    std::unordered_set<Node*> seen;
+    // iterative post-order
+    std::vector<std::pair<Node*, int>> stack;
+    stack.push_back({ target, 0 });
+    seen.insert(target);
+    while (!stack.empty()) {
+        auto& top = stack.back();
+        Node* nd = top.first;
+        if (top.second < nd->n_in) {
+            Node* c = nd->in[top.second++];
+            if (c->buf) {
+                if (!seen.count(c)) { seen.insert(c); dag.leaves.push_back(c); }
+            } else {
+                in_dag_uses[c]++;
+                if (!seen.count(c)) { seen.insert(c); stack.push_back({ c, 0 }); }
+            }
+        } else {
+            dag.order.push_back(nd);
+            stack.pop_back();
+        }
+    }
+    if ((int)dag.leaves.size() > FM_MAX_IN || (int)dag.order.size() > FM_MAX_OPS) return false;
+    const int n_in = (int)dag.leaves.size();
+    for (int k = 0; k < n_in; ++k) id_of[dag.leaves[k]] = k;
+    dag.sig.reserve(dag.order.size() * 12 + 16);
+    dag.sig += "i" + std::to_string(n_in) + ";";
+    for (size_t i = 0; i < dag.order.size(); ++i) {
+        Node* nd = dag.order[i];
+        id_of[nd] = n_in + (int)i;
+        SsaOp op{ nd->opcode, -1, -1, -1, nd->scalar };
+        int* slots[3] = { &op.a, &op.b, &op.c };
+        for (int k = 0; k < nd->n_in; ++k) *slots[k] = id_of[nd->in[k]];
+        dag.ops.push_back(op);
+        if (op_info(nd->opcode).scalar) dag.scalars.push_back((float)nd->scalar);
+        dag.sig += std::to_string(nd->opcode) + "," + std::to_string(op.a) + "," + std::to_string(op.b) + "," + std::to_string(op.c) + ";";
+    }
+    if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
+    // outputs: the target, plus every intermediate somebody else still needs
+    dag.outs.push_back(target);
+    dag.out_ids.push_back(id_of[target]);
+    for (Node* nd : dag.order) {
+        if (nd == target) continue;
+        const int inside = in_dag_uses.count(nd) ? in_dag_uses[nd] : 0;
+        if (nd->refs_ext > 0 || nd->refs_int > inside) { dag.outs.push_back(nd); dag.out_ids.push_back(id_of[nd]); }
+    }
+    if ((int)dag.outs.size() > FM_MAX_OUT) return false;
+    dag.sig += "o";
+    for (int v : dag.out_ids) dag.sig += std::to_string(v) + ",";
+    return true;
+}
+
+// Execute a set of mutually independent expression DAGs with the same structure as ONE launch.
+bool Engine::try_fused(const std::vector<Node*>& targets) {
+    std::vector<Dag> dags(targets.size());
+    for (size_t i = 0; i < targets.size(); ++i) {
+        if (!build_dag(targets[i], dags[i])) return false;
+        if (dags[i].sig != dags[0].sig || targets[i]->n != targets[0]->n) return false;
+    }
+    Dag& d0 = dags[0];
+    Program* prog = nullptr;
+    auto it = program_cache_.find(d0.sig);
+    if (it != program_cache_.end()) prog = it->second;
+    else {
+        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, {}, nullptr); }
+        catch (const Error& e) { if (e.code == FMHIP_ERR_PROGRAM_LIMIT) return false; throw; }
+        program_cache_[d0.sig] = prog;
+    }
+    // allocate outputs
+    std::vector<std::vector<Buffer*>> out_bufs(dags.size());
+    std::vector<RowSpec> rows(dags.size());
+    try {
+        for (size_t i = 0; i < dags.size(); ++i) {
+            for (Node* l : dags[i].leaves) rows[i].in.push_back(l->buf->ptr);
+            for (size_t k = 0; k < dags[i].outs.size(); ++k) {
+                Buffer* b = new_buffer(targets[0]->n);
+                out_bufs[i].push_back(b);
+                rows[i].out.push_back(b->ptr);
+            }
+            rows[i].scalars = dags[i].scalars.data();
+            rows[i].shifts = nullptr;
+        }
+        launch(prog, targets[0]->n, rows, nullptr, nullptr);
+    } catch (...) {
+        for (auto& v : out_bufs) for (Buffer* b : v) buffer_unref(b);
+        throw;
+    }
+    // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
+    for (size_t i = 0; i < dags.size(); ++i)
+        for (size_t k = 0; k < dags[i].outs.size(); ++k) dags[i].outs[k]->buf = out_bufs[i][k];
+    for (size_t i = 0; i < dags.size(); ++i)
+        for (size_t k = 0; k < dags[i].outs.size(); ++k) {
+            Node* nd = dags[i].outs[k];
+            nd->refs_int++;                 // keep alive while its expression is dismantled
+            drop_expression(nd);
+            nd->refs_int--;
+        }
+    return true;
+}
+
+void Engine::materialize(const std::vector<Node*>& targets) {
+    for (Node* t : targets) {
+        if (t->buf) continue;
+        if (try_fused({ t })) continue;
+        // Too large for one launch: execute the operands' expressions first, then this node alone.
+        std::vector<Node*> ins;
+        for (int k = 0; k < t->n_in; ++k) if (!t->in[k]->buf) ins.push_back(t->in[k]);
+        if (ins.empty()) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "a single op does not fit one launch");
+        for (Node* in : ins) { in->refs_int++; }
+        try { materialize(ins); } catch (...) { for (Node* in : ins) in->refs_int--; throw; }
+        for (Node* in : ins) in->refs_int--;
+        if (!try_fused({ t })) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "expression does not fit one launch after splitting");
+    }
+}
+
+void Engine::flush_all() {
+    require_init();
+    for (;;) {
+        // roots: live pending vectors nobody pending depends on
+        std::vector<Node*> roots;
+        for (auto& kv : nodes_) if (!kv.second->buf && kv.second->refs_int == 0) roots.push_back(kv.second);
+        if (roots.empty()) {
+            // only pending nodes with pending consumers but no live root can remain if handles were released; done
+            bool any = false;
+            for (auto& kv : nodes_) if (!kv.second->buf) { any = true; materialize({ kv.second }); break; }
+            if (!any) return;
+            continue;
+        }
+        std::sort(roots.begin(), roots.end(), [](Node* a, Node* b) { return a->id < b->id; });
+        // group structurally identical, mutually disjoint DAGs
+        std::unordered_set<Node*> claimed;
+        std::unordered_map<std::string, std::vector<Node*>> groups;
+        std::vector<std::string> group_order;
+        std::vector<Node*> singles;
+        for (Node* r : roots) {
+            Dag d;
+            if (!build_dag(r, d)) { singles.push_back(r); continue; }
+            bool overlap = false;
+            for (Node* nd : d.order) if (claimed.count(nd)) { overlap = true; break; }
+            if (overlap) continue;                  // next round, after the shared part has been materialised
+            for (Node* nd : d.order) claimed.insert(nd);
+            const std::string key = d.sig + "#" + std::to_string(r->n);
+            if (!groups.count(key)) group_order.push_back(key);
+            groups[key].push_back(r);
+        }
+        for (const std::string& key : group_order) {
+            std::vector<Node*>& g = groups[key];
+            const size_t max_batch = 1024;
+            for (size_t off = 0; off < g.size(); off += max_batch) {
+                std::vector<Node*> part(g.begin() + off, g.begin() + std::min(g.size(), off + max_batch));
+                if (!try_fused(part)) materialize(part);
+            }
+        }
+        if (!singles.empty()) materialize(singles);
+    }
+}
+
+// ---------------------------------------------------------------- reductions
+
+void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out) {
+    require_init();
+    Node* nd = node(h);
+    if (!nd->buf) materialize({ nd });
+    static const char* key = "__reduce1";
+    Program* prog;
+    auto it = program_cache_.find(key);
+    if (it != program_cache_.end()) prog = it->second;
+    else { prog = compile({}, 1, {}, { 0 }, nullptr); program_cache_[key] = prog; }
+    std::vector<RowSpec> rows(1);
+    rows[0].in.push_back(nd->buf->ptr);
+    rows[0].scalars = nullptr;
+    rows[0].shifts = &shift;
+    launch(prog, nd->n, rows, host_out, dev_out);
+}
+
+// ---------------------------------------------------------------- explicit programs
+
+fmhip_program Engine::program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,
+                                     const int32_t* reds, int n_red) {
+    require_init();
+    if (n_ops < 0 || n_out < 0 || n_red < 0 || (n_ops > 0 && !ops) || (n_out > 0 && !outs) || (n_red > 0 && !reds))
+        throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad program description");
+    if (n_out == 0 && n_red == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a program needs an output or a reduction");
+    std::vector<SsaOp> s(n_ops);
+    for (int i = 0; i < n_ops; ++i) s[i] = { ops[i].opcode, ops[i].a, ops[i].b, ops[i].c, ops[i].scalar };
+    Program* p = compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr);
+    const int64_t id = next_id_++;
+    programs_[id] = p;
+    return id;
+}
+
+Program* Engine::program(fmhip_program h) {
+    auto it = programs_.find(h);
+    if (it == programs_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid program handle " + std::to_string(h));
+    return it->second;
+}
+
+void Engine::program_release(fmhip_program h) {
+    require_init();
+    Program* p = program(h);
+    programs_.erase(h);
+    if (--p->refs == 0) delete p;
+}
+
+void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
+                         const double* shifts, fmhip_moments* moments, void* dev_moments) {
+    require_init();
+    Program* p = program(h);
+    if (batch <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch must be positive");
+    if (!inputs || (p->n_out > 0 && !outputs)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null handle array");
+    std::vector<RowSpec> rows(batch);
+    std::vector<Node*> in_nodes((size_t)batch * p->n_in);
+    int64_t n = -1;
+    for (int b = 0; b < batch; ++b)
+        for (int k = 0; k < p->n_in; ++k) {
+            Node* nd = node(inputs[(size_t)b * p->n_in + k]);
+            if (n < 0) n = nd->n;
+            if (nd->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program inputs differ in size");
+            in_nodes[(size_t)b * p->n_in + k] = nd;
+        }
+    for (Node* nd : in_nodes) if (!nd->buf) materialize({ nd });
+    std::vector<Buffer*> fresh;
+    std::vector<Node*> out_nodes;
+    try {
+        for (int b = 0; b < batch; ++b) {
+            for (int k = 0; k < p->n_in; ++k) rows[b].in.push_back(in_nodes[(size_t)b * p->n_in + k]->buf->ptr);
+            for (int k = 0; k < p->n_out; ++k) {
+                if (into) {
+                    Node* o = node(outputs[(size_t)b * p->n_out + k]);
+                    if (o->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program output differs in size");
+                    if (!o->buf) materialize({ o });
+                    rows[b].out.push_back(o->buf->ptr);
+                } else {
+                    Buffer* bf = new_buffer(n);
+                    fresh.push_back(bf);
+                    rows[b].out.push_back(bf->ptr);
+                }
+            }
+            rows[b].scalars = nullptr;
+            rows[b].shifts = shifts;
+        }
+        launch(p, n, rows, moments, dev_moments);
+    } catch (...) { for (Buffer* b : fresh) buffer_unref(b); throw; }
+    if (!into)
+        for (size_t i = 0; i < fresh.size(); ++i) { Node* nd = new_node(n); nd->buf = fresh[i]; outputs[i] = nd->id; }
+}
+
+// ---------------------------------------------------------------- brownian increments
+
+void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
+                         const double* dt, fmhip_vec* out) {
+    require_init(); check_n(n_paths);
+    if (n_steps <= 0 || n_factors <= 0 || !dt || !out || path_offset < 0)
+        throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad Brownian motion description");
+    const int64_t n_streams = (int64_t)n_steps * n_factors;
+    const int64_t stride = (n_paths + 63) & ~int64_t(63);              // every vector 256-B aligned
+    Buffer* slab = new_buffer(std::max<int64_t>(stride, 64) * n_streams);
+    slab->refs = 0;
+    void* sq_dev = nullptr; size_t sq_cap = 0;
+    try {
+        float* st = (float*)ensure_stage((size_t)n_steps * 4);
+        for (int i = 0; i < n_steps; ++i) {
+            if (!(dt[i] >= 0.0)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "negative time step");
+            st[i] = (float)std::sqrt(dt[i]);        // (float)Math.sqrt(timeStep), BrownianMotionCudaWithRandomVariableCuda.java:170
+        }
+        sq_dev = pool_.alloc((size_t)n_steps * 4, &sq_cap);
+        hip_check(hipMemcpyAsync(sq_dev, st, (size_t)n_steps * 4, hipMemcpyHostToDevice, stream_), "sqrt_dt H2D");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        if (n_paths > 0) {
+            const int64_t chunk = 32768 - (32768 % n_factors);         // grid.y limit; keep whole steps together
+            for (int64_t s0 = 0; s0 < n_streams; s0 += chunk) {
+                const int64_t ns = std::min(chunk, n_streams - s0);
+                DevBmArgs a{};
+                a.slab = slab->ptr + s0 * stride;
+                a.sqrt_dt = (const float*)sq_dev + s0 / n_factors;
+                a.stride_floats = stride; a.n_paths = n_paths; a.path_offset = path_offset;
+                a.key0 = (uint32_t)(uint64_t)seed; a.key1 = (uint32_t)((uint64_t)seed >> 32);
+                a.n_factors = (uint32_t)n_factors; a.stream0 = (uint32_t)s0;
+                hip_check(launch_bm(a, (uint32_t)ns, stream_), "launch fm_bm_kernel");
+                n_launches_++;
+            }
+        }
+    } catch (...) {
+        if (sq_dev) pool_.release(sq_dev, sq_cap);
+        slab->refs = 1; buffer_unref(slab);
+        throw;
+    }
+    pool_.release(sq_dev, sq_cap);
+    for (int64_t s = 0; s < n_streams; ++s) {
+        Buffer* v = new Buffer();
+        v->ptr = slab->ptr + s * stride; v->cap = 0; v->refs = 1; v->parent = slab;
+        slab->refs++;
+        Node* nd = new_node(n_paths);
+        nd->buf = v;
+        out[s] = nd->id;
+    }
+}
+
+// ---------------------------------------------------------------- pool entry points
+
+void Engine::pool_clean() { require_init(); hip_check(hipStreamSynchronize(stream_), "sync"); pool_.purge(); }
+
+void Engine::pool_purge() {
+    require_init();
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    pool_.purge();
+    for (auto it = program_cache_.begin(); it != program_cache_.end();) { if (--it->second->refs == 0) delete it->second; it = program_cache_.erase(it); }
+}
+
+void Engine::pool_stats(fmhip_pool_stats_t* out) {
+    require_init();
+    if (!out) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null stats pointer");
+    size_t fr = 0, tot = 0;
+    hip_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
+    out->bytes_reserved = pool_.reserved; out->bytes_in_use = pool_.in_use; out->bytes_cached = pool_.cached;
+    out->device_bytes_free = (int64_t)fr; out->device_bytes_total = (int64_t)tot;
+    out->n_alloc_hits = pool_.hits; out->n_alloc_misses = pool_.misses;
+    out->n_live_vectors = (int64_t)nodes_.size();
+    out->n_kernel_launches = n_launches_; out->n_ops_executed = n_ops_executed_;
+}
+
+// ---------------------------------------------------------------- measurement
+
+void Engine::profile_enable(bool on) {
+    require_init();
+    if (!on) { for (auto& p : profile_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } profile_events_.clear(); }
+    profiling_ = on;
+}
+
+void Engine::profile_read(double* ms_total, int64_t* n) {
+    require_init();
+    hip_check(hipStreamSynchronize(stream_), "sync");
+    double total = 0.0;
+    for (auto& p : profile_events_) {
+        float ms = 0.0f;
+        hip_check(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime");
+        total += ms;
+        (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+    }
+    if (ms_total) *ms_total = total;
+    if (n) *n = (int64_t)profile_events_.size();
+    profile_events_.clear();
+}
+
+} // namespace fm

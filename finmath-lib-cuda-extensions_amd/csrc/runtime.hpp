@@ -1,0 +1,171 @@
+// runtime.hpp — process-wide engine behind the C-ABI: device binding, stream, pooling allocator,
+// vector handles, program compiler (SSA → register bytecode), lazy fusion front-end.
+//
+// Replaces the reference's DeviceMemoryPool inner class (RandomVariableCuda.java:119-558):
+//   reference                                         here
+//   ------------------------------------------------------------------------------------------
+//   pool keyed by GC reachability (WeakReference +    explicit retain/release, size-class free lists,
+//   ReferenceQueue, System.gc(), cudaMemGetInfo on    no GC polling, no hipMemGetInfo on the hot path
+//   every miss: :280-390)
+//   single-thread executor serialising all CUDA       any thread may call; one in-order HIP stream,
+//   calls (:155)                                      one mutex around the (short) enqueue paths
+//   one launch per method (:539-557)                  op streams compiled to one launch (Program)
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fmhip.h"
+#include "fm_program.h"
+
+namespace fm {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---------------------------------------------------------------- device memory
+
+class Pool {
+public:
+    void* alloc(size_t bytes, size_t* cap_out);       // throws Error(OOM)
+    void  release(void* p, size_t cap);               // back to the free list (stream-ordered reuse)
+    void  purge();                                    // hipFree everything cached
+    int64_t reserved = 0, in_use = 0, cached = 0, hits = 0, misses = 0;
+private:
+    std::unordered_map<size_t, std::vector<void*>> free_;
+};
+
+struct Buffer {                 // refcounted device storage; views keep their parent alive
+    float*  ptr = nullptr;
+    size_t  cap = 0;            // bytes owned (0 for views)
+    int     refs = 0;
+    Buffer* parent = nullptr;
+};
+
+// ---------------------------------------------------------------- vectors / lazy nodes
+
+struct Node {
+    int64_t id = 0;
+    int64_t n = 0;
+    int     refs_ext = 0;       // handles held by the caller
+    int     refs_int = 0;       // references from pending consumer nodes
+    Buffer* buf = nullptr;      // non-null ⇔ materialised
+    // pending expression (valid while buf == nullptr)
+    int     opcode = 0;
+    int     n_in = 0;
+    Node*   in[3] = { nullptr, nullptr, nullptr };
+    double  scalar = 0.0;
+    int     weight = 0;         // upper bound of pending ops below this node (fusion budget)
+};
+
+// ---------------------------------------------------------------- compiled programs
+
+struct Program {
+    int n_in = 0, n_out = 0, n_red = 0, n_ops = 0, n_scal = 1;
+    DevProgramArgs proto{};                 // ops / out_reg / red_reg / counts filled in
+    std::vector<float> scalars;             // default scalar operands (explicit API)
+    int refs = 1;
+};
+
+struct SsaOp { int opcode; int a, b, c; double scalar; };
+
+class Engine {
+public:
+    static Engine& get();
+    std::recursive_mutex mu;
+
+    void init(int device_index);
+    void shutdown();
+    bool initialized() const { return initialized_; }
+    void require_init() const;
+    void synchronize();
+    hipStream_t stream() const { return stream_; }
+    void device_info(char* name, int len, int* cus, int64_t* hbm);
+
+    // vectors
+    Node* node(fmhip_vec h);                                   // throws INVALID_HANDLE
+    fmhip_vec create_from_host(const void* src, bool is_double, int64_t n);
+    fmhip_vec create_filled(int64_t n, float v);
+    fmhip_vec create_uninitialized(int64_t n);
+    void retain(fmhip_vec h);
+    void release(fmhip_vec h);
+    void read(fmhip_vec h, void* dst, bool as_double, int64_t n);
+    void* device_ptr(fmhip_vec h);
+
+    // ops
+    fmhip_vec call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar);
+    bool fusion = false;
+    void flush_all();
+    void materialize(const std::vector<Node*>& targets);
+
+    // reductions
+    void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out);
+
+    // programs
+    fmhip_program program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,
+                                 const int32_t* reds, int n_red);
+    void program_release(fmhip_program p);
+    Program* program(fmhip_program p);
+    void program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
+                     const double* shifts, fmhip_moments* moments, void* dev_moments);
+
+    // brownian increments
+    void bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
+                     const double* dt, fmhip_vec* out);
+
+    // pool
+    void pool_clean();
+    void pool_purge();
+    void pool_stats(fmhip_pool_stats_t* out);
+
+    // measurement
+    void profile_enable(bool on);
+    void profile_read(double* ms_total, int64_t* n);
+
+private:
+    Engine() = default;
+    bool initialized_ = false;
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    Pool pool_;
+    int64_t next_id_ = 1;
+    std::unordered_map<int64_t, Node*> nodes_;
+    std::unordered_map<int64_t, Program*> programs_;
+    std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
+    int64_t n_launches_ = 0, n_ops_executed_ = 0;
+    bool profiling_ = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events_;
+
+    // pinned staging for H2D/D2H and the row-table ring
+    void*  stage_ = nullptr;  size_t stage_cap_ = 0;
+    void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
+    void*  ensure_stage(size_t bytes);
+    size_t ring_reserve(size_t bytes);
+
+    Node* new_node(int64_t n);
+    Buffer* new_buffer(int64_t n_floats);
+    void buffer_unref(Buffer* b);
+    void node_unref_int(Node* nd);
+    void node_maybe_free(Node* nd);
+    void drop_expression(Node* nd);
+
+    Program* compile(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
+                     std::vector<float>* scalars_out);
+    // rows: per batch row, n_in input buffers + n_out output buffers (+ per-row scalars, shifts)
+    struct RowSpec { std::vector<const float*> in; std::vector<float*> out; const float* scalars; const double* shifts; };
+    void launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments);
+    bool try_fused(const std::vector<Node*>& targets);
+    struct Dag;
+    bool build_dag(Node* target, Dag& dag);
+};
+
+void hip_check(hipError_t e, const char* what);
+
+} // namespace fm

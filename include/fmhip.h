@@ -247,6 +247,15 @@ int fmhip_pool_clean(void);
 int fmhip_pool_purge(void);
 int fmhip_pool_stats(fmhip_pool_stats_t* out);
 
+/* ---------------------------------------------------------------- measurement */
+
+/* While enabled, every launch of the fused-program kernel is bracketed by a pair of HIP events on the
+ * runtime stream.  fmhip_profile_read blocks until the recorded launches have finished, returns the sum
+ * of their device durations (ms) and their count, and clears the record.  Used by bench.py for the live
+ * roofline figure; adds two event records per launch, so leave it off in production. */
+int fmhip_profile_enable(int enabled);
+int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""GPU parity, reductions: fmhip_reduce_moments / getAverage / getVariance / getMin / getMax vs the twin's
+Kahan-in-double loops (RandomVariableFromFloatArray.java:284-382).
+
+Tolerance: the device sums fp32 values in fp64 in a tree; the twin sums sequentially with Kahan
+compensation.  Both carry O(1e-16) relative error w.r.t. Σ|x|, so |gpu - twin| ≤ 1e-13 · Σ|x| / n is asserted
+(min/max: exact, including NaN propagation and -0.0 < +0.0 of java.lang.Math.min/max)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SIZES = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 2049, 100000, 1000003]
+
+
+def dv(gpu, a):
+    return gpu.DeviceVector.from_host(np.asarray(a, dtype=np.float32))
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_moments_vs_oracle(gpu, oracle, n):
+    x = oracle.f_from_double(oracle.java_random_doubles(100 + n, n) * 10.0 - 3.0)
+    v = dv(gpu, x)
+    scale = float(np.abs(x.astype(np.float64)).sum())
+    for shift in (0.0, float(oracle.f_average(x))):
+        m = v.moments(shift)
+        want = oracle.f_moments(x, shift)
+        assert abs(m.sum - want[0]) <= 1e-13 * scale + 1e-300
+        assert abs(m.sumsq - want[1]) <= 1e-13 * float(((x.astype(np.float64) - shift) ** 2).sum()) + 1e-300
+        assert m.min == want[2] and m.max == want[3]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_rv_reductions_vs_twin(gpu, oracle, n):
+    d = oracle.java_random_doubles(200 + n, n) * 2.0 - 0.5
+    xo = oracle.RandomVariableFloatFactory().createRandomVariable(0.0, d) if n > 0 else None
+    xg = gpu.RandomVariableHipFactory().createRandomVariable(0.0, d)
+    assert abs(xg.getAverage() - xo.getAverage()) <= 1e-13
+    assert abs(xg.getVariance() - xo.getVariance()) <= 1e-13
+    assert abs(xg.getSampleVariance() - xo.getSampleVariance()) <= 1e-13
+    assert abs(xg.getStandardDeviation() - xo.getStandardDeviation()) <= 1e-13
+    assert abs(xg.getStandardError() - xo.getStandardError()) <= 1e-13
+    assert xg.getMin() == xo.getMin() and xg.getMax() == xo.getMax()
+
+
+def test_min_max_special_values(gpu, oracle):
+    cases = [
+        [1.0, float("nan"), 3.0], [float("nan")], [0.0, -0.0], [-0.0, 0.0], [float("inf"), -float("inf"), 1.0],
+        [5.0] * 1000 + [float("nan")] + [7.0] * 1000, [-0.0] * 300 + [0.0] + [-0.0] * 300,
+    ]
+    for c in cases:
+        x = np.array(c, dtype=np.float32)
+        m = dv(gpu, x).moments()
+        wmin, wmax = oracle.f_min(x), oracle.f_max(x)
+        for got, want in ((m.min, wmin), (m.max, wmax)):
+            assert (math.isnan(got) and math.isnan(want)) or (got == want and math.copysign(1, got) == math.copysign(1, want)), (c[:4], got, want)
+
+
+def test_empty_vector(gpu):
+    v = dv(gpu, np.zeros(0))
+    m = v.moments()
+    assert m.sum == 0.0 and m.sumsq == 0.0 and m.min == 1.7976931348623157e308 and m.max == -1.7976931348623157e308
+    rv = gpu.RandomVariableHip(0.0, v)
+    assert math.isnan(rv.getAverage()) and math.isnan(rv.getVariance())     # twin:318-320, :364-366
+
+
+def test_weighted_and_quantiles(gpu, oracle):
+    d = oracle.java_random_doubles(77, 50001)
+    w = oracle.java_random_doubles(78, 50001)
+    xo, wo = [oracle.RandomVariableFloatFactory().createRandomVariable(0.0, a) for a in (d, w)]
+    xg, wg = [gpu.RandomVariableHipFactory().createRandomVariable(0.0, a) for a in (d, w)]
+    # fp32 product rounding (GPU class) vs exact product (twin): fp32 tolerance
+    assert abs(xg.getAverage(wg) - xo.getAverage(wo)) <= 1e-7
+    assert abs(xg.getVariance(wg) - xo.getVariance(wo)) <= 1e-6 * xo.getVariance(wo)
+    # RandomVariableCuda.getQuantile uses (1 - quantile) (:983); the twin uses quantile (twin:484)
+    for q in (0.0, 0.05, 0.5, 0.95, 1.0):
+        assert xg.getQuantile(q) == xo.getQuantile(1.0 - q)
+    assert abs(xg.getQuantileExpectation(0.1, 0.9) - np.sort(xo.getRealizations())[
+        max(int(math.floor(50002 * 0.1 - 1 + 0.5)), 0):int(math.floor(50002 * 0.9 - 1 + 0.5)) + 1].mean()) <= 1e-12
+    h = xg.getHistogram([0.25, 0.5, 0.75])
+    assert abs(h.sum() - 1.0) < 1e-12 and all(abs(v - 0.25) < 0.01 for v in h)
+    anchors, hist = xg.getHistogram(5, 2.0)
+    assert len(anchors) == 6 and len(hist) == 6
+
+
+def test_large_vector_closed_form(gpu):
+    """Full-size property check (no oracle pass needed): 2^24+3 elements, values k mod 7 → exact sums."""
+    n = (1 << 24) + 3
+    x = (np.arange(n, dtype=np.int64) % 7).astype(np.float32)
+    m = dv(gpu, x).moments()
+    xs = x.astype(np.float64)
+    assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == 0.0 and m.max == 6.0
