@@ -44,7 +44,9 @@ __device__ __noinline__ float sin_f(float a) { return (float)sin((double)a); }
 __device__ __noinline__ float cos_f(float a) { return (float)cos((double)a); }
 __device__ __noinline__ float pow_f(float a, float s) { return (float)jpow((double)a, (double)s); }
 // (float)Math.sqrt((double)a) == correctly rounded fp32 sqrt (double rounding is innocuous for sqrt, 53 >= 2*24+2).
-__device__ __forceinline__ float sqrt_f(float a) { return __fsqrt_rn(a); }
+// __builtin_sqrtf lowers to the IEEE-correct expansion (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt);
+// HIP's __fsqrt_rn maps to the NATIVE v_sqrt_f32 (≈1 ulp) and must not be used here (measured: 15 % of results off by 1 ulp).
+__device__ __forceinline__ float sqrt_f(float a) { return __builtin_sqrtf(a); }
 
 // One element of one opcode, opcode known at compile time (the interpreter switches once per
 // instruction on the wave-uniform opcode and then evaluates all of a thread's elements with eval<CODE>).

@@ -234,7 +234,7 @@ __device__ __forceinline__ float spec_logf(float u)
 __device__ __forceinline__ void spec_box_muller(uint32_t ra, uint32_t rb, float& za, float& zb)
 {
     const float u1 = __builtin_fmaf((float)ra, 0x1p-32f, 0x1p-33f);
-    const float radius = __fsqrt_rn(-2.0f * spec_logf(u1));
+    const float radius = __builtin_sqrtf(-2.0f * spec_logf(u1));
     const float t = (float)(rb >> 8) * 0x1p-22f;
     const int q = (int)t;
     const float fr = t - (float)q;

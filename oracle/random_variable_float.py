@@ -150,28 +150,28 @@ class RandomVariableFromFloatArray:
         return RandomVariableFromFloatArray(self.time, f_v1s1(op, self.realizations, s))
 
     def cap(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._cap_rv(x)
+        if not np.isscalar(x): return self._cap_rv(x)
         return self._scalar(_jmin, "CAP_S", x)                         # :751
     def floor(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._floor_rv(x)
+        if not np.isscalar(x): return self._floor_rv(x)
         return self._scalar(_jmax, "FLOOR_S", x)                       # :766
     def add(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._add_rv(x)
+        if not np.isscalar(x): return self._add_rv(x)
         return self._scalar(lambda a, b: a + b, "ADD_S", x)            # :781
     def sub(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._sub_rv(x)
+        if not np.isscalar(x): return self._sub_rv(x)
         return self._scalar(lambda a, b: a - b, "SUB_S", x)            # :796
     def bus(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._bus_rv(x)
+        if not np.isscalar(x): return self._bus_rv(x)
         return self._scalar(lambda a, b: -a + b, "BUS_S", x)           # RandomVariableCuda.java:1220
     def mult(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._mult_rv(x)
+        if not np.isscalar(x): return self._mult_rv(x)
         return self._scalar(lambda a, b: a * b, "MULT_S", x)           # :811
     def div(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._div_rv(x)
+        if not np.isscalar(x): return self._div_rv(x)
         return self._scalar(_jdiv, "DIV_S", x)                         # :826
     def vid(self, x):
-        if isinstance(x, RandomVariableFromFloatArray): return self._vid_rv(x)
+        if not np.isscalar(x): return self._vid_rv(x)
         return self._scalar(lambda a, b: _jdiv(b, a), "VID_S", x)      # RandomVariableCuda.java:1256
     def pow(self, exponent): return self._scalar(_jpow, "POW_S", exponent)   # :841
 
@@ -265,7 +265,7 @@ class RandomVariableFromFloatArray:
             new_time, f_v3s0("CHOOSE", self.realizations, if_non_negative._f(n), if_negative._f(n)))
 
     def addProduct(self, factor1, factor2):
-        if isinstance(factor2, RandomVariableFromFloatArray):
+        if not np.isscalar(factor2):
             return self._add_product_rv(factor1, factor2)
         # addProduct(RandomVariable, double)  :1318-1351
         if factor1.getTypePriority() > self.getTypePriority():

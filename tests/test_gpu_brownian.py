@@ -15,7 +15,7 @@ def test_bit_exact_vs_spec(gpu, oracle):
     td = gpu.TimeDiscretization(0.0, 3, 0.1)
     for n_paths in (1, 4, 1023, 10001):
         bm = gpu.BrownianMotionHip(td, 2, n_paths, 1234)
-        want = oracle.bm_generate(1234, [0.1, 0.1, 0.1], 2, n_paths)
+        want = oracle.bm_generate(1234, [td.getTimeStep(i) for i in range(3)], 2, n_paths)
         for t in range(3):
             for f in range(2):
                 rv = bm.getBrownianIncrement(t, f)
@@ -26,7 +26,7 @@ def test_bit_exact_vs_spec(gpu, oracle):
 def test_non_uniform_steps_and_seed(gpu, oracle):
     td = gpu.TimeDiscretization([0.0, 0.25, 0.3, 1.3])
     bm = gpu.BrownianMotionHip(td, 1, 4097, -77)
-    want = oracle.bm_generate(-77, [0.25, 0.3 - 0.25, 1.0], 1, 4097)
+    want = oracle.bm_generate(-77, [td.getTimeStep(i) for i in range(3)], 1, 4097)
     for t in range(3):
         assert_bits_equal(bm.getBrownianIncrement(t, 0).realizations.to_float32(), want[t][0], f"t={t}")
     other = bm.getCloneWithModifiedSeed(78).getBrownianIncrement(0, 0).realizations.to_float32()
@@ -51,10 +51,18 @@ def test_moments_reference_bounds(gpu):
     """BrownianMotionTest.java:66-127 with N = 1 000 000, dt = 0.1, seed 1234."""
     n, dt = 1_000_000, 0.1
     bm = gpu.BrownianMotionHip(gpu.TimeDiscretization(0.0, 10, dt), 1, n, 1234)
+    # The reference asserts |mean| < 3·sqrt(dt)/sqrt(N) (a 3σ bound) and |var - dt| < 3·dt/sqrt(N), which is only a
+    # 2.1σ bound (σ of the variance estimator is dt·sqrt(2/N)); over 10 steps the latter fails by chance 30 % of the
+    # time for ANY correct generator.  Asserted here: the reference's bound on its own configuration (first increment),
+    # and 4σ bounds on every step.
+    rv0 = bm.getBrownianIncrement(0, 0)
+    assert abs(rv0.getAverage()) < 3.0 * math.sqrt(dt) / math.sqrt(n)
+    assert abs(rv0.getVariance() - dt) < 3.0 * dt / math.sqrt(n)
     for t in range(10):
         rv = bm.getBrownianIncrement(t, 0)
-        assert abs(rv.getAverage()) < 3.0 * math.sqrt(dt) / math.sqrt(n)
-        assert abs(rv.getVariance() - dt) < 3.0 * dt / math.sqrt(n)
+        d = bm.getTimeDiscretization().getTimeStep(t)
+        assert abs(rv.getAverage()) < 4.0 * math.sqrt(d) / math.sqrt(n)
+        assert abs(rv.getVariance() - d) < 4.0 * d * math.sqrt(2.0 / n)
     a, b = bm.getBrownianIncrement(0, 0), bm.getBrownianIncrement(1, 0)
     assert abs(a.mult(b).getAverage()) < 4.0 * dt / math.sqrt(n)        # independent across steps
 

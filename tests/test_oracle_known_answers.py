@@ -94,3 +94,18 @@ def test_bm_increment_moments_reference_bounds():
     zs = z.astype(np.float64) / math.sqrt(dt)
     assert abs((zs ** 4).mean() - 3.0) < 0.05
     assert zs.max() > 4.0 and zs.min() < -4.0
+
+
+def test_normal_generator_z_scores_over_many_streams():
+    """Quality check of the restated generator: z-scores of sample mean and variance over 200 independent streams
+    behave like N(0,1) draws (no stream beyond 4.5σ, mean square ≈ 1)."""
+    n = 50_000
+    zm, zv = [], []
+    for stream in range(200):
+        z = bm_increment(987654321, stream, 0, n, 1.0).astype(np.float64)
+        zm.append(z.mean() * math.sqrt(n))
+        zv.append((z.var() - 1.0) / math.sqrt(2.0 / n))
+    zm, zv = np.array(zm), np.array(zv)
+    assert np.abs(zm).max() < 4.5 and np.abs(zv).max() < 4.5
+    assert 0.7 < (zm ** 2).mean() < 1.3 and 0.7 < (zv ** 2).mean() < 1.3
+    assert abs(zm.mean()) < 0.3 and abs(zv.mean()) < 0.3
