@@ -1,31 +1,33 @@
-// fm_device_math.hpp — per-element arithmetic of every opcode, gfx950 device code.
+// fm_device_math.hpp — per-element arithmetic of every micro-op, gfx950 device code.
 //
 // Contract (DESIGN.md §"Arithmetic contract"): results are bit-identical to the reference's CPU twin
 // RandomVariableFromFloatArray.java for + - * / min max abs sqrt choose accrue discount addProduct
 // (each elementary operation rounds to fp32 once: this file is compiled with -ffp-contract=off, the
 // counterpart of the reference's `nvcc -fmad false`, JCudaUtils.java:69-70), and exp/log/pow/sin/cos are
-// evaluated in fp64 and narrowed — the twin computes `(float)Math.exp(realizations[i])` (:905) — so they
-// differ from the twin only where two fp64 libms disagree in the last fp64 ulp AND that ulp straddles an
-// fp32 rounding boundary (probability ≈ 2^-28 per element).
+// evaluated in fp64 and narrowed ONCE — the twin computes `(float)Math.exp(realizations[i])` (:905).  The fp64
+// intermediate is accurate to ≈2^-47, so the narrowed result differs from the twin's only when the exact value
+// lies within ≈2^-47 (relative) of an fp32 rounding boundary: ≈2^-23 of the elements, and then by one fp32 ulp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/fmhip.h"
+#include "fm_program.h"
 
 namespace fm {
 
 // java.lang.Math.min/max(float,float): NaN-propagating, -0.0f < +0.0f (RandomVariableFromFloatArray.java:759,774).
 // The reference's CUDA kernels use `a < b ? a : b` (RandomVariableCudaKernel.cu:2-21), which differs from
 // its own CPU twin for NaN and signed zeros; the twin (and finmath-lib's double class) is followed here.
+// Written as selects (no early returns) so that they stay branch-free v_cmp/v_cndmask sequences.
 __device__ __forceinline__ float jmin(float a, float b) {
-    if (a != a) return a;
-    if (a == 0.0f && b == 0.0f && (__float_as_uint(b) >> 31)) return b;
-    return (a <= b) ? a : b;
+    float r = (a <= b) ? a : b;                                                        // b if b is NaN
+    r = ((a == 0.0f) & (b == 0.0f) & ((__float_as_uint(b) >> 31) != 0u)) ? b : r;      // min(+0,-0) = -0
+    return (a != a) ? a : r;
 }
 __device__ __forceinline__ float jmax(float a, float b) {
-    if (a != a) return a;
-    if (a == 0.0f && b == 0.0f && (__float_as_uint(a) >> 31)) return b;
-    return (a >= b) ? a : b;
+    float r = (a >= b) ? a : b;
+    r = ((a == 0.0f) & (b == 0.0f) & ((__float_as_uint(a) >> 31) != 0u)) ? b : r;      // max(-0,+0) = +0
+    return (a != a) ? a : r;
 }
 // java.lang.Math.pow special cases that differ from C99 pow (see oracle/rv_float.c jpow).
 __device__ __forceinline__ double jpow(double x, double y) {
@@ -35,55 +37,126 @@ __device__ __forceinline__ double jpow(double x, double y) {
     return pow(x, y);
 }
 
-// fp64 exp for an fp32 argument, narrowed once.  `(float)Math.exp(realizations[i])`, twin :905.
-__device__ __forceinline__ float exp_f(float a) { return (float)exp((double)a); }
-__device__ __forceinline__ float log_f(float a) { return (float)log((double)a); }
-// The rarely used, register-hungry fp64 functions are kept out of line so that they do not set the VGPR
+// ---- exp: fp64 evaluation for an fp32 argument, narrowed once (`(float)Math.exp(realizations[i])`, twin :905).
+// x = k·ln2 + r, |r| <= ln2/2;  e^r by a degree-11 Taylor polynomial (truncation 0.3466^12/12! = 2^-47);
+// 2^k applied with ldexp; the final fp64→fp32 conversion rounds once (RNE, denormals honoured).
+// 17 fp64 instructions instead of the ≈45 of the generic library exp — exp/log dominate the VALU budget of a
+// fused stream, and the kernel has to stay under the HBM roofline.
+__device__ __forceinline__ float exp_f(float a) {
+    double x = (double)a;
+    x = __builtin_fmin(__builtin_fmax(x, -110.0), 90.0);           // ±inf and huge arguments: result is 0 / +inf anyway
+    const double k = __builtin_rint(x * 1.4426950408889634);       // log2(e)
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);   // ln2 hi (low 32 bits zero: k*hi exact)
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);          // ln2 lo
+    double p = 2.50521083854417187751e-08;                         // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);           // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);           // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);           // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);           // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);           // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);           // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);           // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);           // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const float res = (float)__builtin_ldexp(p, (int)k);
+    return (a != a) ? a : res;
+}
+
+// ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).
+// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) (fp32 reciprocal seed + one Newton step + one residual
+// correction: no fp64 division);  log m = 2s·(1 + z/3 + z²/5 + … + z^8/17), z = s² <= 0.0295 (truncation 2^-50).
+__device__ __forceinline__ float log_f(float a) {
+    const double x = (double)a;                                     // denormal floats become normal doubles
+    double m = __builtin_amdgcn_frexp_mant(x);                      // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;                                       // exact
+    const double d = m + 1.0;                                       // exact (m carries <= 24 significant bits)
+    const double q0 = (double)__builtin_amdgcn_rcpf((float)d);      // ≈ 1/d, 2^-22
+    const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);   // Newton: 2^-44
+    const double s0 = f * q1;
+    const double s = __builtin_fma(__builtin_fma(-d, s0, f), q1, s0);      // residual correction: ≈ 2^-52
+    const double z = s * s;
+    double p = 1.0 / 17.0;
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double s2 = s + s;
+    const double lm = __builtin_fma(s2, p * z, s2);
+    const double ed = (double)e;
+    const double r = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+    float res = (float)r;
+    res = (a == 0.0f) ? -__builtin_huge_valf() : res;               // log(±0) = -inf
+    res = (a < 0.0f) ? __builtin_nanf("") : res;                    // log(negative) = NaN
+    res = (a == __builtin_huge_valf()) ? a : res;                   // log(+inf) = +inf
+    return (a != a) ? a : res;
+}
+
+// The rarely used, register-hungry fp64 library functions are kept out of line so that they do not set the VGPR
 // budget (and with it the occupancy) of the whole interpreter kernel.
 __device__ __noinline__ float sin_f(float a) { return (float)sin((double)a); }
 __device__ __noinline__ float cos_f(float a) { return (float)cos((double)a); }
 __device__ __noinline__ float pow_f(float a, float s) { return (float)jpow((double)a, (double)s); }
+
 // (float)Math.sqrt((double)a) == correctly rounded fp32 sqrt (double rounding is innocuous for sqrt, 53 >= 2*24+2).
 // __builtin_sqrtf lowers to the IEEE-correct expansion (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt);
 // HIP's __fsqrt_rn maps to the NATIVE v_sqrt_f32 (≈1 ulp) and must not be used here (measured: 15 % of results off by 1 ulp).
 __device__ __forceinline__ float sqrt_f(float a) { return __builtin_sqrtf(a); }
 
-// One element of one opcode, opcode known at compile time (the interpreter switches once per
-// instruction on the wave-uniform opcode and then evaluates all of a thread's elements with eval<CODE>).
-template <int CODE>
-__device__ __forceinline__ float eval(float a, float b, float c, float s) {
-    if constexpr (CODE == FMHIP_OP_CAP_S)         return jmin(a, s);
-    else if constexpr (CODE == FMHIP_OP_FLOOR_S)  return jmax(a, s);
-    else if constexpr (CODE == FMHIP_OP_ADD_S)    return a + s;
-    else if constexpr (CODE == FMHIP_OP_SUB_S)    return a - s;
-    else if constexpr (CODE == FMHIP_OP_BUS_S)    return -a + s;
-    else if constexpr (CODE == FMHIP_OP_MULT_S)   return a * s;
-    else if constexpr (CODE == FMHIP_OP_DIV_S)    return a / s;
-    else if constexpr (CODE == FMHIP_OP_VID_S)    return s / a;
-    else if constexpr (CODE == FMHIP_OP_POW_S)    return pow_f(a, s);
-    else if constexpr (CODE == FMHIP_OP_SQUARED)  return a * a;
-    else if constexpr (CODE == FMHIP_OP_SQRT)     return sqrt_f(a);
-    else if constexpr (CODE == FMHIP_OP_EXP)      return exp_f(a);
-    else if constexpr (CODE == FMHIP_OP_LOG)      return log_f(a);
-    else if constexpr (CODE == FMHIP_OP_INVERT)   return 1.0f / a;
-    else if constexpr (CODE == FMHIP_OP_ABS)      return __uint_as_float(__float_as_uint(a) & 0x7fffffffu);
-    else if constexpr (CODE == FMHIP_OP_SIN)      return sin_f(a);
-    else if constexpr (CODE == FMHIP_OP_COS)      return cos_f(a);
-    else if constexpr (CODE == FMHIP_OP_ISNAN)    return (a != a) ? 1.0f : 0.0f;
-    else if constexpr (CODE == FMHIP_OP_CAP)      return jmin(a, b);
-    else if constexpr (CODE == FMHIP_OP_FLOOR)    return jmax(a, b);
-    else if constexpr (CODE == FMHIP_OP_ADD)      return a + b;
-    else if constexpr (CODE == FMHIP_OP_SUB)      return a - b;
-    else if constexpr (CODE == FMHIP_OP_MULT)     return a * b;
-    else if constexpr (CODE == FMHIP_OP_DIV)      return a / b;
-    else if constexpr (CODE == FMHIP_OP_ACCRUE)   { float p = b * s; float d = 1.0f + p; return a * d; }   // .cu:224-231
-    else if constexpr (CODE == FMHIP_OP_DISCOUNT) { float p = b * s; float d = 1.0f + p; return a / d; }   // .cu:234-244
-    else if constexpr (CODE == FMHIP_OP_ADDPRODUCT_VS) { float p = b * s; return a + p; }                  // .cu:257-264
-    else if constexpr (CODE == FMHIP_OP_ADDPRODUCT)    { float p = b * c; return a + p; }                  // .cu:247-254
-    else if constexpr (CODE == FMHIP_OP_ADDRATIO) { float q = b / c; return a + q; }                       // twin :1411
-    else if constexpr (CODE == FMHIP_OP_SUBRATIO) { float q = b / c; return a - q; }                       // twin :1434
-    else if constexpr (CODE == FMHIP_OP_CHOOSE)   return (a >= 0.0f) ? b : c;                              // twin :1281
-    else return a;
+// One element of one micro-op (fm_program.h: UOp), micro-op known at compile time: the interpreter switches
+// once per instruction on the wave-uniform code and evaluates all of a thread's elements with ueval<CODE>.
+//   acc = accumulator, r1/r2 = fetched register operands, s = narrowed scalar.
+template <uint32_t CODE>
+__device__ __forceinline__ float ueval(float acc, float r1, float r2, float s) {
+    if constexpr (CODE == U_LDA)            return r1;
+    else if constexpr (CODE == U_SQUARED)   return acc * acc;                                   // twin :875
+    else if constexpr (CODE == U_SQRT)      return sqrt_f(acc);                                 // twin :890
+    else if constexpr (CODE == U_EXP)       return exp_f(acc);                                  // twin :905
+    else if constexpr (CODE == U_LOG)       return log_f(acc);                                  // twin :920
+    else if constexpr (CODE == U_INVERT)    return 1.0f / acc;                                  // twin :1296
+    else if constexpr (CODE == U_ABS)       return __uint_as_float(__float_as_uint(acc) & 0x7fffffffu);
+    else if constexpr (CODE == U_SIN)       return sin_f(acc);
+    else if constexpr (CODE == U_COS)       return cos_f(acc);
+    else if constexpr (CODE == U_ISNAN)     return (acc != acc) ? 1.0f : 0.0f;                  // twin :1447
+    else if constexpr (CODE == U_CAP_S)     return jmin(acc, s);                                // twin :759
+    else if constexpr (CODE == U_FLOOR_S)   return jmax(acc, s);                                // twin :774
+    else if constexpr (CODE == U_ADD_S)     return acc + s;
+    else if constexpr (CODE == U_SUB_S)     return acc - s;
+    else if constexpr (CODE == U_BUS_S)     return -acc + s;                                    // .cu:44-51
+    else if constexpr (CODE == U_MULT_S)    return acc * s;
+    else if constexpr (CODE == U_DIV_S)     return acc / s;
+    else if constexpr (CODE == U_VID_S)     return s / acc;
+    else if constexpr (CODE == U_POW_S)     return pow_f(acc, s);                               // twin :849
+    else if constexpr (CODE == U_CAP)       return jmin(acc, r1);
+    else if constexpr (CODE == U_FLOOR)     return jmax(acc, r1);
+    else if constexpr (CODE == U_ADD)       return acc + r1;
+    else if constexpr (CODE == U_MULT)      return acc * r1;
+    else if constexpr (CODE == U_SUB)       return acc - r1;
+    else if constexpr (CODE == U_BUS)       return r1 - acc;
+    else if constexpr (CODE == U_DIV)       return acc / r1;
+    else if constexpr (CODE == U_VID)       return r1 / acc;
+    else if constexpr (CODE == U_ACCRUE_A)  { float p = r1 * s;  float d = 1.0f + p; return acc * d; }   // .cu:224-231
+    else if constexpr (CODE == U_ACCRUE_B)  { float p = acc * s; float d = 1.0f + p; return r1 * d; }
+    else if constexpr (CODE == U_DISCOUNT_A){ float p = r1 * s;  float d = 1.0f + p; return acc / d; }   // .cu:234-244
+    else if constexpr (CODE == U_DISCOUNT_B){ float p = acc * s; float d = 1.0f + p; return r1 / d; }
+    else if constexpr (CODE == U_ADDPRODUCT_VS_A) { float p = r1 * s;  return acc + p; }                  // .cu:257-264
+    else if constexpr (CODE == U_ADDPRODUCT_VS_B) { float p = acc * s; return r1 + p; }
+    else if constexpr (CODE == U_ADDPRODUCT_A)    { float p = r1 * r2;  return acc + p; }                 // .cu:247-254
+    else if constexpr (CODE == U_ADDPRODUCT_B)    { float p = acc * r2; return r1 + p; }
+    else if constexpr (CODE == U_ADDRATIO_A)      { float q = r1 / r2; return acc + q; }                  // twin :1411
+    else if constexpr (CODE == U_SUBRATIO_A)      { float q = r1 / r2; return acc - q; }                  // twin :1434
+    else if constexpr (CODE == U_CHOOSE_T)  return (acc >= 0.0f) ? r1 : r2;                               // twin :1281
+    else if constexpr (CODE == U_CHOOSE_P)  return (r1 >= 0.0f) ? acc : r2;
+    else if constexpr (CODE == U_CHOOSE_N)  return (r1 >= 0.0f) ? r2 : acc;
+    else return acc;
 }
 
 } // namespace fm

@@ -1,9 +1,13 @@
 // fm_program.h — the device-visible form of a fused RandomVariable op stream (shared host/device).
 //
-// A program is a short register-machine bytecode executed per path by ONE kernel (kernels.hip):
-//   - FM_NREG virtual fp32 registers per element, held in VGPRs (indexed through s_set_gpr_idx);
-//   - inputs are preloaded into registers 0 … n_in-1 with 128-bit loads, all in flight together;
-//   - each instruction is wave-uniform: {opcode, dst, a, b, c, scalar slot};
+// A program is a short ACCUMULATOR-machine bytecode executed per path by ONE kernel (kernels.hip):
+//   - an accumulator A and FM_NREG virtual fp32 registers R[] per element, all in VGPRs (R is indexed
+//     through s_set_gpr_idx; no scratch, no LDS);
+//   - inputs are preloaded into R[0 … n_in-1] with 128-bit loads, all in flight together;
+//   - each micro-op is wave-uniform: A = f(A [, R[r1] [, R[r2]]] [, scalar]), optionally followed by
+//     R[st] = A.  A chain x.add(4).div(2).exp() never touches R: operands are fetched from R only where an
+//     instruction really has a second/third vector operand (this is what makes interpretation cheap: the
+//     first design, a 3-address register machine, spent 16 v_mov per op and ran at 1.5 TB/s);
 //   - up to FM_MAX_OUT registers are stored as new vectors, up to FM_MAX_RED registers are reduced
 //     (Σ, Σ², min, max in fp64) inside the same launch.
 // Everything that differs between the rows of a horizontally batched launch (vector pointers, scalar
@@ -15,7 +19,7 @@
 namespace fm {
 
 constexpr int FM_NREG     = 16;    // virtual registers per element lane
-constexpr int FM_MAX_OPS  = 96;    // instructions per launch
+constexpr int FM_MAX_OPS  = 128;   // micro-ops per launch (one extra slot is kept for the prefetch of ops[pc+1])
 constexpr int FM_MAX_IN   = 12;    // preloaded input vectors per launch
 constexpr int FM_MAX_OUT  = 8;     // materialised output vectors per launch
 constexpr int FM_MAX_RED  = 2;     // fused reductions per launch
@@ -23,10 +27,32 @@ constexpr int FM_MAX_SCAL = 64;    // scalar operand slots per launch
 constexpr int FM_BLOCK    = 256;   // threads per workgroup (4 waves)
 constexpr int FM_VEC      = 4;     // elements per thread per tile (one 128-bit access per vector)
 
-// Instruction word: code[0:7] dst[8:11] a[12:15] b[16:19] c[20:23] scalar_slot[24:31]
+// Micro-ops.  "_A/_B/_T/_P/_N" name which operand of the public opcode sits in the accumulator.
+enum UOp : uint32_t {
+    U_NOP = 0, U_LDA,                                                       // A = R[r1]
+    // A = f(A)
+    U_SQUARED, U_SQRT, U_EXP, U_LOG, U_INVERT, U_ABS, U_SIN, U_COS, U_ISNAN,
+    // A = f(A, s)
+    U_CAP_S, U_FLOOR_S, U_ADD_S, U_SUB_S, U_BUS_S, U_MULT_S, U_DIV_S, U_VID_S, U_POW_S,
+    // A = f(A, R[r1])
+    U_CAP, U_FLOOR, U_ADD, U_MULT, U_SUB /*A-R*/, U_BUS /*R-A*/, U_DIV /*A/R*/, U_VID /*R/A*/,
+    // A = f(A, R[r1], s)
+    U_ACCRUE_A /*A*(1+R*s)*/, U_ACCRUE_B /*R*(1+A*s)*/, U_DISCOUNT_A /*A/(1+R*s)*/, U_DISCOUNT_B /*R/(1+A*s)*/,
+    U_ADDPRODUCT_VS_A /*A+R*s*/, U_ADDPRODUCT_VS_B /*R+A*s*/,
+    // A = f(A, R[r1], R[r2])
+    U_ADDPRODUCT_A /*A+R1*R2*/, U_ADDPRODUCT_B /*R1+A*R2*/, U_ADDRATIO_A /*A+R1/R2*/, U_SUBRATIO_A /*A-R1/R2*/,
+    U_CHOOSE_T /*A>=0?R1:R2*/, U_CHOOSE_P /*R1>=0?A:R2*/, U_CHOOSE_N /*R1>=0?R2:A*/,
+    U__COUNT
+};
+
+// Instruction word: code[0:7] r1[8:11] r2[12:15] store[16:19] scalar_slot[24:31].
+// Every micro-op writes A to R[store]; R[15] is a dummy that is never allocated ("no store") — an unconditional
+// write is cheaper for the compiler than a conditional one (see the kernel).
 struct DevOp { uint32_t w; };
-static inline uint32_t fm_pack_op(unsigned code, unsigned d, unsigned a, unsigned b, unsigned c, unsigned sslot) {
-    return (code & 0xffu) | ((d & 15u) << 8) | ((a & 15u) << 12) | ((b & 15u) << 16) | ((c & 15u) << 20) | ((sslot & 0xffu) << 24);
+constexpr unsigned FM_NO_STORE = 15;
+constexpr int FM_NREG_ALLOC = 15;      // registers the allocator may hand out (R[15] is the dummy)
+static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsigned st, unsigned sslot) {
+    return (code & 0xffu) | ((r1 & 15u) << 8) | ((r2 & 15u) << 12) | ((st & 15u) << 16) | ((sslot & 0xffu) << 24);
 }
 
 // Row block layout (one per batch row), in units of 8 bytes:
@@ -41,12 +67,9 @@ struct DevProgramArgs {
     uint32_t n_scal, row_words;          // row stride in 8-byte words
     uint32_t tiles_per_row, use_inline;  // tiles of FM_BLOCK*FM_VEC elements; batch==1 → row block inline
     int64_t  n;                          // elements per vector
-    const uint64_t* rows;                // device table [batch][row_words] (when !use_inline)
-    double*  partials;                   // [batch][n_red][gridDim.x][4] block partials of the fused reductions
-    uint8_t  out_reg[FM_MAX_OUT];
-    uint8_t  red_reg[FM_MAX_RED];
-    uint8_t  pad_[6];
-    DevOp    ops[FM_MAX_OPS];
+    uint32_t out_reg[FM_MAX_OUT];        // 32-bit so that they are fetched with scalar loads (gfx9 has no s_load_u8)
+    uint32_t red_reg[FM_MAX_RED];
+    DevOp    ops[FM_MAX_OPS + 2];            // two slack entries: the kernel prefetches ops[pc+1], ops[pc+2]
     uint64_t inline_row[FM_ROW_WORDS_MAX];
 };
 

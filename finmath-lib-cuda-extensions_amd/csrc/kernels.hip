@@ -23,23 +23,40 @@
 namespace fm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Vector pointers arrive as 64-bit integers in the row block; casting them to the GLOBAL address space keeps the
+// data path on global_load/global_store_dwordx4 (a plain C++ pointer would be "generic" → flat_load, which also
+// ties up lgkmcnt).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 __attribute__((address_space(1))) gfloat4;
 
 // ---------------------------------------------------------------------------------------------
 // Fused program interpreter
 // ---------------------------------------------------------------------------------------------
 
-#define FM_CASE(CODE)                                                                         \
-    case CODE:                                                                                \
-        r0 = eval<CODE>(a0, b0, c0, s); r1 = eval<CODE>(a1, b1, c1, s);                       \
-        r2 = eval<CODE>(a2, b2, c2, s); r3 = eval<CODE>(a3, b3, c3, s);                       \
-        break;
+// One case of the dispatch switch: NR = number of register operands fetched from R (0, 1 or 2).
+#define FM_U0(CODE) case CODE:                                                                          \
+        a0 = ueval<CODE>(a0, 0.f, 0.f, s); a1 = ueval<CODE>(a1, 0.f, 0.f, s);                          \
+        a2 = ueval<CODE>(a2, 0.f, 0.f, s); a3 = ueval<CODE>(a3, 0.f, 0.f, s); break;
+#define FM_U1(CODE) case CODE: {                                                                        \
+        const float p0 = R0[r1], p1 = R1[r1], p2 = R2[r1], p3 = R3[r1];                                \
+        a0 = ueval<CODE>(a0, p0, 0.f, s); a1 = ueval<CODE>(a1, p1, 0.f, s);                            \
+        a2 = ueval<CODE>(a2, p2, 0.f, s); a3 = ueval<CODE>(a3, p3, 0.f, s); } break;
+#define FM_U2(CODE) case CODE: {                                                                        \
+        const float p0 = R0[r1], p1 = R1[r1], p2 = R2[r1], p3 = R3[r1];                                \
+        const float q0 = R0[r2], q1 = R1[r2], q2 = R2[r2], q3 = R3[r2];                                \
+        a0 = ueval<CODE>(a0, p0, q0, s); a1 = ueval<CODE>(a1, p1, q1, s);                              \
+        a2 = ueval<CODE>(a2, p2, q2, s); a3 = ueval<CODE>(a3, p3, q3, s); } break;
 
 template <int NRED, bool INLINE_ROW>
-__global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A)
+__global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A,
+                                                               const uint64_t* __restrict__ rows,     // [batch][row_words]
+                                                               double* __restrict__ partials)         // [batch][NRED][grid.x][4]
 {
     const uint32_t row = blockIdx.y;
-    // Row block: wave-uniform, read with scalar loads (kernarg segment when INLINE_ROW).
-    const uint64_t* __restrict__ rowp = INLINE_ROW ? A.inline_row : (A.rows + (size_t)row * A.row_words);
+    // Row block: wave-uniform, read with SCALAR loads — kernarg segment when INLINE_ROW, else the row table, which
+    // must be a `const __restrict__` kernel parameter of its own: fetched through a pointer stored inside the
+    // argument struct the compiler cannot prove it read-only and falls back to vector loads + v_readfirstlane.
+    const uint64_t* __restrict__ rowp = INLINE_ROW ? A.inline_row : (rows + (size_t)row * A.row_words);
     const uint32_t n_in = A.n_in, n_out = A.n_out, n_ops = A.n_ops;
     const int64_t n = A.n;
     const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + n_in + n_out + A.n_red);
@@ -57,48 +74,63 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     for (uint32_t tile = blockIdx.x; tile < A.tiles_per_row; tile += gridDim.x) {
         const int64_t i4 = (int64_t)tile * FM_BLOCK + threadIdx.x;      // float4 index inside the vector
         const int64_t e0 = i4 * FM_VEC;
-        if (e0 >= n) continue;      // vectors are padded to 256 B: a partially valid float4 is still in bounds
+        // No divergent branch around the interpreter (it would make the compiler fetch instruction words and scalar
+        // operands with VECTOR loads — measured: one global_load + 500 cycles per micro-op).  Lanes past the end read
+        // element 0 and are masked at the stores / reductions.  Vectors are padded to 256 B, so a partially valid
+        // float4 is in bounds.
+        const bool lane_valid = e0 < n;
+        const int64_t i4c = lane_valid ? i4 : 0;
 
-        // ---- preload: every input vector, 16 B per lane, all loads in flight before the first use
+        // ---- preload: every input vector, 16 B per lane, all loads in flight before the first use.
+        // The conditional part is confined to the 4 loaded floats; the insertion into the register-file vectors is
+        // unconditional (a conditional insert makes every one of the 64 file registers a PHI at each branch and
+        // wrecks register allocation: 253 VGPRs + scratch instead of 118).
 #pragma unroll
         for (int k = 0; k < FM_MAX_IN; ++k) {
+            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
             if (k < (int)n_in) {
-                const float4* __restrict__ p = reinterpret_cast<const float4*>(rowp[k]);
-                const float4 v = p[i4];
-                R0[k] = v.x; R1[k] = v.y; R2[k] = v.z; R3[k] = v.w;
+                const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[k]);
+                v = p[i4c];
             }
+            R0[k] = v.x; R1[k] = v.y; R2[k] = v.z; R3[k] = v.w;
         }
 
-        // ---- interpret: one wave-uniform decode per instruction, four elements per lane
+        // ---- interpret: one wave-uniform decode per micro-op, four elements per lane, accumulator in a0..a3.
+        // The next instruction word is fetched before the current one executes (scalar-load latency hidden).
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        // Two-deep software pipeline of the scalar fetches: while micro-op pc executes, the scalar operand of pc+1 and
+        // the instruction word of pc+2 are in flight (ops[] carries two slack entries).
+        uint32_t w = A.ops[0].w;
+        uint32_t w1 = A.ops[1].w;
+        float s = scal[w >> 24];
         for (uint32_t pc = 0; pc < n_ops; ++pc) {
-            const uint32_t w = A.ops[pc].w;
+            const float s_next = scal[w1 >> 24];
+            const uint32_t w2 = A.ops[pc + 2].w;
             const uint32_t code = w & 0xffu;
-            const uint32_t d = (w >> 8) & 15u, ia = (w >> 12) & 15u, ib = (w >> 16) & 15u, ic = (w >> 20) & 15u;
-            const float s = scal[w >> 24];
-            const float a0 = R0[ia], a1 = R1[ia], a2 = R2[ia], a3 = R3[ia];
-            const float b0 = R0[ib], b1 = R1[ib], b2 = R2[ib], b3 = R3[ib];
-            const float c0 = R0[ic], c1 = R1[ic], c2 = R2[ic], c3 = R3[ic];
-            float r0, r1, r2, r3;
+            const uint32_t r1 = (w >> 8) & 15u, r2 = (w >> 12) & 15u, st = (w >> 16) & 15u;
             switch (code) {
-                FM_CASE(FMHIP_OP_CAP_S) FM_CASE(FMHIP_OP_FLOOR_S) FM_CASE(FMHIP_OP_ADD_S) FM_CASE(FMHIP_OP_SUB_S)
-                FM_CASE(FMHIP_OP_BUS_S) FM_CASE(FMHIP_OP_MULT_S) FM_CASE(FMHIP_OP_DIV_S) FM_CASE(FMHIP_OP_VID_S)
-                FM_CASE(FMHIP_OP_POW_S) FM_CASE(FMHIP_OP_SQUARED) FM_CASE(FMHIP_OP_SQRT) FM_CASE(FMHIP_OP_EXP)
-                FM_CASE(FMHIP_OP_LOG) FM_CASE(FMHIP_OP_INVERT) FM_CASE(FMHIP_OP_ABS) FM_CASE(FMHIP_OP_SIN)
-                FM_CASE(FMHIP_OP_COS) FM_CASE(FMHIP_OP_ISNAN) FM_CASE(FMHIP_OP_CAP) FM_CASE(FMHIP_OP_FLOOR)
-                FM_CASE(FMHIP_OP_ADD) FM_CASE(FMHIP_OP_SUB) FM_CASE(FMHIP_OP_MULT) FM_CASE(FMHIP_OP_DIV)
-                FM_CASE(FMHIP_OP_ACCRUE) FM_CASE(FMHIP_OP_DISCOUNT) FM_CASE(FMHIP_OP_ADDPRODUCT_VS)
-                FM_CASE(FMHIP_OP_ADDPRODUCT) FM_CASE(FMHIP_OP_ADDRATIO) FM_CASE(FMHIP_OP_SUBRATIO)
-                FM_CASE(FMHIP_OP_CHOOSE)
-                default: r0 = a0; r1 = a1; r2 = a2; r3 = a3; break;
+                FM_U1(U_LDA)
+                FM_U0(U_SQUARED) FM_U0(U_SQRT) FM_U0(U_EXP) FM_U0(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
+                FM_U0(U_SIN) FM_U0(U_COS) FM_U0(U_ISNAN)
+                FM_U0(U_CAP_S) FM_U0(U_FLOOR_S) FM_U0(U_ADD_S) FM_U0(U_SUB_S) FM_U0(U_BUS_S) FM_U0(U_MULT_S)
+                FM_U0(U_DIV_S) FM_U0(U_VID_S) FM_U0(U_POW_S)
+                FM_U1(U_CAP) FM_U1(U_FLOOR) FM_U1(U_ADD) FM_U1(U_MULT) FM_U1(U_SUB) FM_U1(U_BUS) FM_U1(U_DIV) FM_U1(U_VID)
+                FM_U1(U_ACCRUE_A) FM_U1(U_ACCRUE_B) FM_U1(U_DISCOUNT_A) FM_U1(U_DISCOUNT_B)
+                FM_U1(U_ADDPRODUCT_VS_A) FM_U1(U_ADDPRODUCT_VS_B)
+                FM_U2(U_ADDPRODUCT_A) FM_U2(U_ADDPRODUCT_B) FM_U2(U_ADDRATIO_A) FM_U2(U_SUBRATIO_A)
+                FM_U2(U_CHOOSE_T) FM_U2(U_CHOOSE_P) FM_U2(U_CHOOSE_N)
+                default: break;
             }
-            R0[d] = r0; R1[d] = r1; R2[d] = r2; R3[d] = r3;
+            R0[st] = a0; R1[st] = a1; R2[st] = a2; R3[st] = a3;   // st == FM_NO_STORE (15) is a dummy register: unconditional on purpose
+            w = w1; w1 = w2; s = s_next;
         }
 
         // ---- materialise the escaping values
         for (uint32_t k = 0; k < n_out; ++k) {
             const uint32_t reg = A.out_reg[k];
-            float4* __restrict__ q = reinterpret_cast<float4*>(rowp[n_in + k]);
-            q[i4] = make_float4(R0[reg], R1[reg], R2[reg], R3[reg]);
+            gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(rowp[n_in + k]);
+            const f32x4 v = { R0[reg], R1[reg], R2[reg], R3[reg] };
+            if (lane_valid) q[i4] = v;
         }
 
         // ---- fused reductions (fp64 accumulation of fp32 values, as the twin does: :325-333, :373-381)
@@ -149,7 +181,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
                     s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
                     mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
                 }
-                double* __restrict__ out = A.partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
+                double* __restrict__ out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
                 out[0] = s1; out[1] = s2; out[2] = (double)mn; out[3] = (double)mx;
             }
         }
@@ -317,20 +349,21 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_fill_kernel(float4* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 
 template <int NRED>
-static hipError_t launch_program_nred(const DevProgramArgs& a, dim3 grid, hipStream_t st)
+static hipError_t launch_program_nred(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
 {
-    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true>),  grid, dim3(FM_BLOCK), 0, st, a);
-    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false>), grid, dim3(FM_BLOCK), 0, st, a);
+    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true>),  grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
+    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false>), grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
     return hipGetLastError();
 }
 
-hipError_t launch_program(const DevProgramArgs& a, uint32_t blocks_per_row, uint32_t batch, hipStream_t st)
+hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double* partials,
+                          uint32_t blocks_per_row, uint32_t batch, hipStream_t st)
 {
     const dim3 grid(blocks_per_row, batch, 1);
     switch (a.n_red) {
-    case 0:  return launch_program_nred<0>(a, grid, st);
-    case 1:  return launch_program_nred<1>(a, grid, st);
-    case 2:  return launch_program_nred<2>(a, grid, st);
+    case 0:  return launch_program_nred<0>(a, rows, partials, grid, st);
+    case 1:  return launch_program_nred<1>(a, rows, partials, grid, st);
+    case 2:  return launch_program_nred<2>(a, rows, partials, grid, st);
     default: return hipErrorInvalidValue;
     }
 }
