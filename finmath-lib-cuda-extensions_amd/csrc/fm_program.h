@@ -46,11 +46,12 @@ enum UOp : uint32_t {
 };
 
 // Instruction word: code[0:7] r1[8:11] r2[12:15] store[16:19] scalar_slot[24:31].
-// Every micro-op writes A to R[store]; R[15] is a dummy that is never allocated ("no store") — an unconditional
-// write is cheaper for the compiler than a conditional one (see the kernel).
+// Every micro-op writes A to R[store]; the LAST register of the file is a dummy that is never allocated ("no
+// store") — an unconditional write is cheaper for the compiler than a conditional one (see the kernel).
+// Two kernel variants: variant 0 = 4 elements per lane, 16 registers; variant 1 = 8 elements per lane, 10 registers.
 struct DevOp { uint32_t w; };
-constexpr unsigned FM_NO_STORE = 15;
-constexpr int FM_NREG_ALLOC = 15;      // registers the allocator may hand out (R[15] is the dummy)
+constexpr int FM_VARIANT_NREG[2] = { 16, 10 };
+constexpr int FM_VARIANT_ELEMS[2] = { 4, 8 };
 static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsigned st, unsigned sslot) {
     return (code & 0xffu) | ((r1 & 15u) << 8) | ((r2 & 15u) << 12) | ((st & 15u) << 16) | ((sslot & 0xffu) << 24);
 }
@@ -65,7 +66,8 @@ constexpr int FM_ROW_WORDS_MAX = FM_MAX_IN + FM_MAX_OUT + FM_MAX_RED + FM_MAX_SC
 struct DevProgramArgs {
     uint32_t n_ops, n_in, n_out, n_red;
     uint32_t n_scal, row_words;          // row stride in 8-byte words
-    uint32_t tiles_per_row, use_inline;  // tiles of FM_BLOCK*FM_VEC elements; batch==1 → row block inline
+    uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; batch==1 → row block inline
+    uint32_t variant, pad0_;             // kernel variant (FM_VARIANT_*)
     int64_t  n;                          // elements per vector
     uint32_t out_reg[FM_MAX_OUT];        // 32-bit so that they are fetched with scalar loads (gfx9 has no s_load_u8)
     uint32_t red_reg[FM_MAX_RED];

@@ -23,6 +23,7 @@
 namespace fm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x10 __attribute__((ext_vector_type(10)));   // > 8 elements: dynamic indexing stays on s_set_gpr_idx (<= 8 would be expanded into v_cndmask chains)
 // Vector pointers arrive as 64-bit integers in the row block; casting them to the GLOBAL address space keeps the
 // data path on global_load/global_store_dwordx4 (a plain C++ pointer would be "generic" → flat_load, which also
 // ties up lgkmcnt).
@@ -33,25 +34,64 @@ typedef f32x4 __attribute__((address_space(1))) gfloat4;
 // Fused program interpreter
 // ---------------------------------------------------------------------------------------------
 
-// One case of the dispatch switch: NR = number of register operands fetched from R (0, 1 or 2).
+// One case of the dispatch switch: number of register operands fetched from R = 0, 1 or 2.  E elements per lane.
 #define FM_U0(CODE) case CODE:                                                                          \
-        a0 = ueval<CODE>(a0, 0.f, 0.f, s); a1 = ueval<CODE>(a1, 0.f, 0.f, s);                          \
-        a2 = ueval<CODE>(a2, 0.f, 0.f, s); a3 = ueval<CODE>(a3, 0.f, 0.f, s); break;
+        _Pragma("unroll") for (int j = 0; j < E; ++j) a[j] = ueval<CODE>(a[j], 0.f, 0.f, s);           \
+        break;
 #define FM_U1(CODE) case CODE: {                                                                        \
-        const float p0 = R0[r1], p1 = R1[r1], p2 = R2[r1], p3 = R3[r1];                                \
-        a0 = ueval<CODE>(a0, p0, 0.f, s); a1 = ueval<CODE>(a1, p1, 0.f, s);                            \
-        a2 = ueval<CODE>(a2, p2, 0.f, s); a3 = ueval<CODE>(a3, p3, 0.f, s); } break;
+        float p[E];                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < E; ++j) p[j] = R[j][r1];                                  \
+        _Pragma("unroll") for (int j = 0; j < E; ++j) a[j] = ueval<CODE>(a[j], p[j], 0.f, s);           \
+        } break;
 #define FM_U2(CODE) case CODE: {                                                                        \
-        const float p0 = R0[r1], p1 = R1[r1], p2 = R2[r1], p3 = R3[r1];                                \
-        const float q0 = R0[r2], q1 = R1[r2], q2 = R2[r2], q3 = R3[r2];                                \
-        a0 = ueval<CODE>(a0, p0, q0, s); a1 = ueval<CODE>(a1, p1, q1, s);                              \
-        a2 = ueval<CODE>(a2, p2, q2, s); a3 = ueval<CODE>(a3, p3, q3, s); } break;
+        float p[E], q[E];                                                                               \
+        _Pragma("unroll") for (int j = 0; j < E; ++j) { p[j] = R[j][r1]; q[j] = R[j][r2]; }             \
+        _Pragma("unroll") for (int j = 0; j < E; ++j) a[j] = ueval<CODE>(a[j], p[j], q[j], s);          \
+        } break;
 
-template <int NRED, bool INLINE_ROW>
+// wave64 data movement without LDS: v_mov_b32 with a DPP control (quad_perm / row_mirror / row_bcast).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(x), (int)__float_as_uint(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)b, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(b >> 32), (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// Full wave64 reduction of {Σ, Σ², min, max}; the result is valid in lane 63.  Fixed combination order ⇒ deterministic.
+__device__ __forceinline__ void wave_reduce(double& s1, double& s2, float& mn, float& mx) {
+#define FM_STEP(CTRL, MASK)                                                                             \
+    { const double t1 = dpp_d<CTRL, MASK>(s1), t2 = dpp_d<CTRL, MASK>(s2);                              \
+      const float tn = dpp_f<CTRL, MASK>(mn), tx = dpp_f<CTRL, MASK>(mx);                               \
+      s1 += t1; s2 += t2; mn = jmin(mn, tn); mx = jmax(mx, tx); }
+    FM_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    FM_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    FM_STEP(0x141, 0xf)     // row_half_mirror
+    FM_STEP(0x140, 0xf)     // row_mirror  → every lane of a row holds the row total
+    // across the four rows of 16: row_bcast15 into rows 1,3 then row_bcast31 into rows 2,3 (gfx9 DPP)
+    { const double t1 = dpp_d<0x142, 0xa>(s1), t2 = dpp_d<0x142, 0xa>(s2);
+      const float tn = dpp_f<0x142, 0xa>(mn), tx = dpp_f<0x142, 0xa>(mx);
+      const bool on = ((threadIdx.x >> 4) & 1) != 0;                       // rows 1 and 3 received data
+      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
+    { const double t1 = dpp_d<0x143, 0xc>(s1), t2 = dpp_d<0x143, 0xc>(s2);
+      const float tn = dpp_f<0x143, 0xc>(mn), tx = dpp_f<0x143, 0xc>(mx);
+      const bool on = ((threadIdx.x >> 5) & 1) != 0;                       // rows 2 and 3 received data
+      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
+#undef FM_STEP
+}
+
+// E elements per lane (E/4 tiles of 1024 elements per pass), RegVec = register-file vector (NREG floats).
+//   variant 0: E = 4, 16 registers  — programs with many live values
+//   variant 1: E = 8,  8 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
+template <int NRED, bool INLINE_ROW, int E, int NREG, typename RegVec>
 __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A,
                                                                const uint64_t* __restrict__ rows,     // [batch][row_words]
                                                                double* __restrict__ partials)         // [batch][NRED][grid.x][4]
 {
+    constexpr int T = E / FM_VEC;                   // float4 per lane per pass
     const uint32_t row = blockIdx.y;
     // Row block: wave-uniform, read with SCALAR loads — kernarg segment when INLINE_ROW, else the row table, which
     // must be a `const __restrict__` kernel parameter of its own: fetched through a pointer stored inside the
@@ -69,35 +109,49 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
     }
 
-    f32x16 R0 = 0.0f, R1 = 0.0f, R2 = 0.0f, R3 = 0.0f;     // virtual register file, one vector per element lane
+    RegVec R[E];                                    // virtual register file, one vector per element lane (static indices only)
+#pragma unroll
+    for (int j = 0; j < E; ++j) R[j] = 0.0f;
 
+    // A.tiles_per_row counts passes of FM_BLOCK*E elements.
     for (uint32_t tile = blockIdx.x; tile < A.tiles_per_row; tile += gridDim.x) {
-        const int64_t i4 = (int64_t)tile * FM_BLOCK + threadIdx.x;      // float4 index inside the vector
-        const int64_t e0 = i4 * FM_VEC;
         // No divergent branch around the interpreter (it would make the compiler fetch instruction words and scalar
         // operands with VECTOR loads — measured: one global_load + 500 cycles per micro-op).  Lanes past the end read
         // element 0 and are masked at the stores / reductions.  Vectors are padded to 256 B, so a partially valid
         // float4 is in bounds.
-        const bool lane_valid = e0 < n;
-        const int64_t i4c = lane_valid ? i4 : 0;
-
-        // ---- preload: every input vector, 16 B per lane, all loads in flight before the first use.
-        // The conditional part is confined to the 4 loaded floats; the insertion into the register-file vectors is
-        // unconditional (a conditional insert makes every one of the 64 file registers a PHI at each branch and
-        // wrecks register allocation: 253 VGPRs + scratch instead of 118).
+        int64_t i4[T], i4c[T];
+        bool lane_valid[T];
 #pragma unroll
-        for (int k = 0; k < FM_MAX_IN; ++k) {
-            f32x4 v = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (k < (int)n_in) {
-                const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[k]);
-                v = p[i4c];
-            }
-            R0[k] = v.x; R1[k] = v.y; R2[k] = v.z; R3[k] = v.w;
+        for (int t = 0; t < T; ++t) {
+            i4[t] = ((int64_t)tile * T + t) * FM_BLOCK + threadIdx.x;   // float4 index inside the vector, unit stride across lanes
+            lane_valid[t] = i4[t] * FM_VEC < n;
+            i4c[t] = lane_valid[t] ? i4[t] : 0;
         }
 
-        // ---- interpret: one wave-uniform decode per micro-op, four elements per lane, accumulator in a0..a3.
-        // The next instruction word is fetched before the current one executes (scalar-load latency hidden).
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        // ---- preload: every input vector, 16 B per lane and tile, all loads in flight before the first use.
+        // The conditional part is confined to the loaded floats; the insertion into the register-file vectors is
+        // unconditional (a conditional insert makes every file register a PHI at each branch and wrecks register
+        // allocation: 253 VGPRs + scratch instead of ~110).
+#pragma unroll
+        for (int k = 0; k < FM_MAX_IN; ++k) {
+            if (k < NREG - 1) {                    // the last register is the dummy; inputs never live there
+                f32x4 v[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) v[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+                if (k < (int)n_in) {
+                    const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[k]);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) v[t] = p[i4c[t]];
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) { R[4 * t + 0][k] = v[t].x; R[4 * t + 1][k] = v[t].y; R[4 * t + 2][k] = v[t].z; R[4 * t + 3][k] = v[t].w; }
+            }
+        }
+
+        // ---- interpret: one wave-uniform decode per micro-op, E elements per lane, accumulator in a[].
+        float a[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = 0.0f;
         // Two-deep software pipeline of the scalar fetches: while micro-op pc executes, the scalar operand of pc+1 and
         // the instruction word of pc+2 are in flight (ops[] carries two slack entries).
         uint32_t w = A.ops[0].w;
@@ -121,7 +175,9 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
                 FM_U2(U_CHOOSE_T) FM_U2(U_CHOOSE_P) FM_U2(U_CHOOSE_N)
                 default: break;
             }
-            R0[st] = a0; R1[st] = a1; R2[st] = a2; R3[st] = a3;   // st == FM_NO_STORE (15) is a dummy register: unconditional on purpose
+            // unconditional on purpose: "no store" is a dummy register (the last one of the file)
+#pragma unroll
+            for (int j = 0; j < E; ++j) R[j][st] = a[j];
             w = w1; w1 = w2; s = s_next;
         }
 
@@ -129,8 +185,11 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         for (uint32_t k = 0; k < n_out; ++k) {
             const uint32_t reg = A.out_reg[k];
             gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(rowp[n_in + k]);
-            const f32x4 v = { R0[reg], R1[reg], R2[reg], R3[reg] };
-            if (lane_valid) q[i4] = v;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const f32x4 v = { R[4 * t + 0][reg], R[4 * t + 1][reg], R[4 * t + 2][reg], R[4 * t + 3][reg] };
+                if (lane_valid[t]) q[i4[t]] = v;
+            }
         }
 
         // ---- fused reductions (fp64 accumulation of fp32 values, as the twin does: :325-333, :373-381)
@@ -138,21 +197,21 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         for (int r = 0; r < NRED; ++r) {
             const uint32_t reg = A.red_reg[r];
             const double shift = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
-            const float x[4] = { R0[reg], R1[reg], R2[reg], R3[reg] };
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (e0 + j < n) {
-                    const double dv = (double)x[j] - shift;
+            for (int j = 0; j < E; ++j) {
+                const float x = R[j][reg];
+                if (i4[j / 4] * FM_VEC + (j & 3) < n) {
+                    const double dv = (double)x - shift;
                     acc_sum[r] += dv;
                     acc_sq[r]  += dv * dv;
-                    acc_min[r] = jmin(x[j], acc_min[r]);
-                    acc_max[r] = jmax(x[j], acc_max[r]);
+                    acc_min[r] = jmin(x, acc_min[r]);
+                    acc_max[r] = jmax(x, acc_max[r]);
                 }
             }
         }
     }
 
-    // ---- workgroup combine: wave64 shuffles, then 4 waves through LDS, one partial per workgroup
+    // ---- workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup
     if constexpr (NRED > 0) {
         __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
         __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
@@ -161,14 +220,8 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         for (int r = 0; r < NRED; ++r) {
             double s1 = acc_sum[r], s2 = acc_sq[r];
             float mn = acc_min[r], mx = acc_max[r];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                s1 += __shfl_down(s1, off, 64);
-                s2 += __shfl_down(s2, off, 64);
-                mn = jmin(mn, __shfl_down(mn, off, 64));
-                mx = jmax(mx, __shfl_down(mx, off, 64));
-            }
-            if (lane == 0) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
+            wave_reduce(s1, s2, mn, mx);
+            if (lane == 63) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -348,12 +401,19 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_fill_kernel(float4* __restrict__ 
 // Host-side launchers (the only functions the runtime calls)
 // ---------------------------------------------------------------------------------------------
 
+template <int NRED, int E, int NREG, typename RegVec>
+static hipError_t launch_program_v(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
+{
+    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true, E, NREG, RegVec>),  grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
+    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false, E, NREG, RegVec>), grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
+    return hipGetLastError();
+}
+
 template <int NRED>
 static hipError_t launch_program_nred(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
 {
-    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true>),  grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
-    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false>), grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
-    return hipGetLastError();
+    if (a.variant == 1) return launch_program_v<NRED, 8, 10, f32x10>(a, rows, partials, grid, st);
+    return launch_program_v<NRED, 4, 16, f32x16>(a, rows, partials, grid, st);
 }
 
 hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double* partials,

@@ -364,8 +364,20 @@ static int acc_position(const SsaOp& op, int n_vec, int v) {
 Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
                          std::vector<float>* scalars_out)
 {
+    // Prefer the 8-elements-per-lane kernel (8 registers); fall back to 4 elements / 16 registers when the program
+    // keeps more values alive.
+    try { return compile_variant(ops, n_in, outs, reds, scalars_out, 1); }
+    catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; }
+    return compile_variant(ops, n_in, outs, reds, scalars_out, 0);
+}
+
+Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
+                                 std::vector<float>* scalars_out, int variant)
+{
+    const int nreg_alloc = FM_VARIANT_NREG[variant] - 1;        // the last register is the "no store" dummy
+    const unsigned no_store = (unsigned)nreg_alloc;
     const int n_ops = (int)ops.size();
-    if (n_in < 0 || n_in > FM_MAX_IN) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many inputs for one launch");
+    if (n_in < 0 || n_in > FM_MAX_IN || n_in > nreg_alloc) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many inputs for one launch");
     if (n_ops > FM_MAX_OPS) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many ops for one launch");
     if ((int)outs.size() > FM_MAX_OUT) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many outputs for one launch");
     if ((int)reds.size() > FM_MAX_RED) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many fused reductions for one launch");
@@ -406,7 +418,7 @@ Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vec
     // Pass 2: emit micro-ops with register allocation (a register is released after the value's last read from R).
     std::vector<int> reg_of(n_val, -1);
     std::vector<int> free_regs;
-    for (int r = FM_NREG_ALLOC - 1; r >= n_in; --r) free_regs.push_back(r);  // lowest register on top; R[15] is the dummy
+    for (int r = nreg_alloc - 1; r >= n_in; --r) free_regs.push_back(r);     // lowest register on top
     for (int k = 0; k < n_in; ++k) reg_of[k] = k;
     auto give_back = [&](int r) { free_regs.push_back(r); std::sort(free_regs.begin(), free_regs.end(), std::greater<int>()); };
     for (int k = 0; k < n_in; ++k) if (last_r_use[k] < 0) give_back(k);
@@ -423,7 +435,7 @@ Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vec
         const int v[3] = { ops[i].a, ops[i].b, ops[i].c };
         int ap = apos[i];
         if (ap < 0) {                               // accumulator does not hold an operand: load position 0
-            emit(fm_pack_op(U_LDA, (unsigned)reg_of[v[0]], 0, FM_NO_STORE, 0));
+            emit(fm_pack_op(U_LDA, (unsigned)reg_of[v[0]], 0, no_store, 0));
             ap = 0;
         }
         UVariant uv{};
@@ -435,7 +447,7 @@ Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vec
             for (int j = 0; j < q; ++j) dup |= (v[j] == v[q]);
             if (!dup && last_r_use[v[q]] == i && reg_of[v[q]] >= 0) { give_back(reg_of[v[q]]); }
         }
-        unsigned st = FM_NO_STORE;
+        unsigned st = no_store;
         const int res = n_in + i;
         if (stored[res]) {
             if (free_regs.empty()) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "register budget of one launch exceeded"); }
@@ -456,6 +468,7 @@ Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vec
     p->n_scal = (int)scal.size();
     p->proto.n_ops = (uint32_t)n_uops; p->proto.n_in = (uint32_t)n_in; p->proto.n_out = (uint32_t)outs.size();
     p->proto.n_red = (uint32_t)reds.size(); p->proto.n_scal = (uint32_t)p->n_scal;
+    p->proto.variant = (uint32_t)variant;
     p->proto.row_words = (uint32_t)(n_in + (int)outs.size() + (int)reds.size() + (p->n_scal + 1) / 2);
     p->scalars = scal;
     if (scalars_out) *scalars_out = scal;
@@ -483,12 +496,15 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         return;
     }
     DevProgramArgs args = p->proto;
-    const int64_t n4 = (n + 3) / 4;
-    const int64_t tiles = (n4 + FM_BLOCK - 1) / FM_BLOCK;
+    const int64_t elems_per_pass = (int64_t)FM_BLOCK * FM_VARIANT_ELEMS[args.variant];
+    const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
     if (tiles > int64_t(0x7fffffff)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "vector too long");
-    // One tile (1024 elements) per workgroup: measured fastest for pure streaming on MI355X (5.8 TB/s vs 5.0 TB/s
-    // with a 2048-workgroup grid-stride loop); the loop in the kernel only runs when the grid is capped.
-    int64_t bpr = std::min<int64_t>(tiles, 65536);
+    // One pass per workgroup: measured fastest for pure streaming on MI355X (5.8 TB/s vs 5.0 TB/s with a 2048-workgroup
+    // grid-stride loop).  With fused reductions a workgroup covers ≈4096 elements so that the wave/LDS combine and
+    // the partial write are amortised.
+    int64_t passes_per_block = (n_red > 0) ? std::max<int64_t>(1, 4096 / elems_per_pass) : 1;
+    int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
+    bpr = std::min<int64_t>(std::max<int64_t>(bpr, 1), 65536);
     args.n = n;
     args.tiles_per_row = (uint32_t)tiles;
     const size_t rw = args.row_words;
