@@ -18,15 +18,19 @@ namespace fm {
 // java.lang.Math.min/max(float,float): NaN-propagating, -0.0f < +0.0f (RandomVariableFromFloatArray.java:759,774).
 // The reference's CUDA kernels use `a < b ? a : b` (RandomVariableCudaKernel.cu:2-21), which differs from
 // its own CPU twin for NaN and signed zeros; the twin (and finmath-lib's double class) is followed here.
-// Written as selects (no early returns) so that they stay branch-free v_cmp/v_cndmask sequences.
+// Built on the hardware v_min_f32 / v_max_f32, which order -0 < +0 exactly like Java and return the other operand
+// when one is NaN; the NaN propagation is added with two selects (branch-free).
+// (inline asm: the builtin min/max would first canonicalise both inputs with an extra v_max_f32 x,x each)
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float jmin(float a, float b) {
-    float r = (a <= b) ? a : b;                                                        // b if b is NaN
-    r = ((a == 0.0f) & (b == 0.0f) & ((__float_as_uint(b) >> 31) != 0u)) ? b : r;      // min(+0,-0) = -0
+    float r = hw_min(a, b);
+    r = (b != b) ? b : r;
     return (a != a) ? a : r;
 }
 __device__ __forceinline__ float jmax(float a, float b) {
-    float r = (a >= b) ? a : b;
-    r = ((a == 0.0f) & (b == 0.0f) & ((__float_as_uint(a) >> 31) != 0u)) ? b : r;      // max(-0,+0) = +0
+    float r = hw_max(a, b);
+    r = (b != b) ? b : r;
     return (a != a) ? a : r;
 }
 // java.lang.Math.pow special cases that differ from C99 pow (see oracle/rv_float.c jpow).

@@ -85,8 +85,9 @@ __device__ __forceinline__ void wave_reduce(double& s1, double& s2, float& mn, f
 
 // E elements per lane (E/4 tiles of 1024 elements per pass), RegVec = register-file vector (NREG floats).
 //   variant 0: E = 4, 16 registers  — programs with many live values
-//   variant 1: E = 8,  8 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
-template <int NRED, bool INLINE_ROW, int E, int NREG, typename RegVec>
+//   variant 1: E = 8, 10 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
+// NIN_T = compile-time bound of the number of preloaded inputs (the preload loop is unrolled NIN_T times).
+template <int NRED, bool INLINE_ROW, int E, int NREG, int NIN_T, typename RegVec>
 __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A,
                                                                const uint64_t* __restrict__ rows,     // [batch][row_words]
                                                                double* __restrict__ partials)         // [batch][NRED][grid.x][4]
@@ -103,9 +104,10 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 
     double acc_sum[NRED > 0 ? NRED : 1], acc_sq[NRED > 0 ? NRED : 1];
     float  acc_min[NRED > 0 ? NRED : 1], acc_max[NRED > 0 ? NRED : 1];
+    unsigned long long nan_mask[NRED > 0 ? NRED : 1];
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
-        acc_sum[r] = 0.0; acc_sq[r] = 0.0;
+        acc_sum[r] = 0.0; acc_sq[r] = 0.0; nan_mask[r] = 0ull;
         acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
     }
 
@@ -133,8 +135,8 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         // unconditional (a conditional insert makes every file register a PHI at each branch and wrecks register
         // allocation: 253 VGPRs + scratch instead of ~110).
 #pragma unroll
-        for (int k = 0; k < FM_MAX_IN; ++k) {
-            if (k < NREG - 1) {                    // the last register is the dummy; inputs never live there
+        for (int k = 0; k < NIN_T; ++k) {
+            {
                 f32x4 v[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) v[t] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
@@ -175,9 +177,10 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
                 FM_U2(U_CHOOSE_T) FM_U2(U_CHOOSE_P) FM_U2(U_CHOOSE_N)
                 default: break;
             }
-            // unconditional on purpose: "no store" is a dummy register (the last one of the file)
+            if (st != (uint32_t)(NREG - 1)) {       // the last register of the file means "no store"
 #pragma unroll
-            for (int j = 0; j < E; ++j) R[j][st] = a[j];
+                for (int j = 0; j < E; ++j) R[j][st] = a[j];
+            }
             w = w1; w1 = w2; s = s_next;
         }
 
@@ -192,20 +195,37 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             }
         }
 
-        // ---- fused reductions (fp64 accumulation of fp32 values, as the twin does: :325-333, :373-381)
+        // ---- fused reductions (fp64 accumulation of fp32 values, as the twin does: :325-333, :373-381).
+        // min/max use the hardware v_min_f32/v_max_f32 (which order -0 < +0 like java.lang.Math.min/max) and track NaN
+        // separately in a wave-level ballot mask (scalar registers): NaN anywhere ⇒ the reduction result is NaN.
+        const bool pass_full = ((int64_t)tile * T + T) * (FM_BLOCK * FM_VEC) <= n;      // wave-uniform: no masking needed
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
             const uint32_t reg = A.red_reg[r];
             const double shift = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
+            float x[E];
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                const float x = R[j][reg];
-                if (i4[j / 4] * FM_VEC + (j & 3) < n) {
-                    const double dv = (double)x - shift;
+            for (int j = 0; j < E; ++j) x[j] = R[j][reg];
+            if (pass_full) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double dv = (double)x[j] - shift;
                     acc_sum[r] += dv;
-                    acc_sq[r]  += dv * dv;
-                    acc_min[r] = jmin(x, acc_min[r]);
-                    acc_max[r] = jmax(x, acc_max[r]);
+                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
+                    acc_min[r] = hw_min(acc_min[r], x[j]);
+                    acc_max[r] = hw_max(acc_max[r], x[j]);
+                    nan_mask[r] |= __ballot(x[j] != x[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const bool ok = i4[j / 4] * FM_VEC + (j & 3) < n;
+                    const double dv = ok ? (double)x[j] - shift : 0.0;
+                    acc_sum[r] += dv;
+                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
+                    acc_min[r] = ok ? hw_min(acc_min[r], x[j]) : acc_min[r];
+                    acc_max[r] = ok ? hw_max(acc_max[r], x[j]) : acc_max[r];
+                    nan_mask[r] |= __ballot(ok && (x[j] != x[j]));
                 }
             }
         }
@@ -220,6 +240,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         for (int r = 0; r < NRED; ++r) {
             double s1 = acc_sum[r], s2 = acc_sq[r];
             float mn = acc_min[r], mx = acc_max[r];
+            if (nan_mask[r] != 0ull) { mn = __builtin_nanf(""); mx = mn; }      // wave-uniform
             wave_reduce(s1, s2, mn, mx);
             if (lane == 63) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
         }
@@ -401,19 +422,22 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_fill_kernel(float4* __restrict__ 
 // Host-side launchers (the only functions the runtime calls)
 // ---------------------------------------------------------------------------------------------
 
-template <int NRED, int E, int NREG, typename RegVec>
+template <int NRED, int E, int NREG, int NIN_T, typename RegVec>
 static hipError_t launch_program_v(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
 {
-    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true, E, NREG, RegVec>),  grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
-    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false, E, NREG, RegVec>), grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
+    if (a.use_inline) hipLaunchKernelGGL((fm_program_kernel<NRED, true, E, NREG, NIN_T, RegVec>),  grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
+    else              hipLaunchKernelGGL((fm_program_kernel<NRED, false, E, NREG, NIN_T, RegVec>), grid, dim3(FM_BLOCK), 0, st, a, rows, partials);
     return hipGetLastError();
 }
 
 template <int NRED>
 static hipError_t launch_program_nred(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
 {
-    if (a.variant == 1) return launch_program_v<NRED, 8, 10, f32x10>(a, rows, partials, grid, st);
-    return launch_program_v<NRED, 4, 16, f32x16>(a, rows, partials, grid, st);
+    if (a.variant == 1) {
+        if (a.n_in <= 3) return launch_program_v<NRED, 8, 10, 3, f32x10>(a, rows, partials, grid, st);
+        return launch_program_v<NRED, 8, 10, 9, f32x10>(a, rows, partials, grid, st);
+    }
+    return launch_program_v<NRED, 4, 16, FM_MAX_IN, f32x16>(a, rows, partials, grid, st);
 }
 
 hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double* partials,

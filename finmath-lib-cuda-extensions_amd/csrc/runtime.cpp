@@ -362,17 +362,18 @@ static int acc_position(const SsaOp& op, int n_vec, int v) {
 }
 
 Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
-                         std::vector<float>* scalars_out)
+                         std::vector<float>* scalars_out, bool fixed_scalars)
 {
     // Prefer the 8-elements-per-lane kernel (8 registers); fall back to 4 elements / 16 registers when the program
     // keeps more values alive.
-    try { return compile_variant(ops, n_in, outs, reds, scalars_out, 1); }
+    // fixed_scalars == false: the lazy front-end patches scalars per row, so no value-dependent rewrites are allowed
+    try { return compile_variant(ops, n_in, outs, reds, scalars_out, 1, fixed_scalars); }
     catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; }
-    return compile_variant(ops, n_in, outs, reds, scalars_out, 0);
+    return compile_variant(ops, n_in, outs, reds, scalars_out, 0, fixed_scalars);
 }
 
 Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
-                                 std::vector<float>* scalars_out, int variant)
+                                 std::vector<float>* scalars_out, int variant, bool fixed_scalars)
 {
     const int nreg_alloc = FM_VARIANT_NREG[variant] - 1;        // the last register is the "no store" dummy
     const unsigned no_store = (unsigned)nreg_alloc;
@@ -455,12 +456,22 @@ Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const 
             reg_of[res] = (int)st;
         }
         unsigned slot = 0;
+        uint32_t uop = uv.uop;
         if (op_info(ops[i].opcode).scalar) {
             if ((int)scal.size() >= FM_MAX_SCAL) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many scalar operands for one launch"); }
             slot = (unsigned)scal.size();
-            scal.push_back((float)ops[i].scalar);   // "(float)value", RandomVariableCuda.java:521
+            float sv = (float)ops[i].scalar;        // "(float)value", RandomVariableCuda.java:521
+            if (uop == U_DIV_S && fixed_scalars) {
+                // a / (±2^k) == a * (±2^-k) bit for bit (both are the correctly rounded value of the same real number,
+                // also for denormal results) as long as the reciprocal is itself a normal float: 1 multiply instead of
+                // the 11-instruction IEEE division.  Only when the scalar is fixed at compile time (explicit programs).
+                int ex = 0;
+                const float mant = std::frexp(sv, &ex);
+                if ((mant == 0.5f || mant == -0.5f) && ex > -124 && ex < 126) { uop = U_MULT_S; sv = 1.0f / sv; }
+            }
+            scal.push_back(sv);
         }
-        emit(fm_pack_op(uv.uop, r1, r2, st, slot));
+        emit(fm_pack_op(uop, r1, r2, st, slot));
     }
     for (size_t k = 0; k < outs.size(); ++k) p->proto.out_reg[k] = (uint32_t)reg_of[outs[k]];
     for (size_t k = 0; k < reds.size(); ++k) p->proto.red_reg[k] = (uint32_t)reg_of[reds[k]];
@@ -674,7 +685,7 @@ bool Engine::try_fused(const std::vector<Node*>& targets) {
     auto it = program_cache_.find(d0.sig);
     if (it != program_cache_.end()) prog = it->second;
     else {
-        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, {}, nullptr); }
+        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, {}, nullptr, false); }
         catch (const Error& e) { if (e.code == FMHIP_ERR_PROGRAM_LIMIT) return false; throw; }
         program_cache_[d0.sig] = prog;
     }
@@ -777,7 +788,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     Program* prog;
     auto it = program_cache_.find(key);
     if (it != program_cache_.end()) prog = it->second;
-    else { prog = compile({}, 1, {}, { 0 }, nullptr); program_cache_[key] = prog; }
+    else { prog = compile({}, 1, {}, { 0 }, nullptr, true); program_cache_[key] = prog; }
     std::vector<RowSpec> rows(1);
     rows[0].in.push_back(nd->buf->ptr);
     rows[0].scalars = nullptr;
@@ -795,7 +806,7 @@ fmhip_program Engine::program_create(const fmhip_prog_op* ops, int n_ops, int n_
     if (n_out == 0 && n_red == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a program needs an output or a reduction");
     std::vector<SsaOp> s(n_ops);
     for (int i = 0; i < n_ops; ++i) s[i] = { ops[i].opcode, ops[i].a, ops[i].b, ops[i].c, ops[i].scalar };
-    Program* p = compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr);
+    Program* p = compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr, true);
     const int64_t id = next_id_++;
     programs_[id] = p;
     return id;

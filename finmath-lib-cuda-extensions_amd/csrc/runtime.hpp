@@ -157,9 +157,9 @@ private:
     void drop_expression(Node* nd);
 
     Program* compile(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
-                     std::vector<float>* scalars_out);
+                     std::vector<float>* scalars_out, bool fixed_scalars);
     Program* compile_variant(const std::vector<SsaOp>& ops, int n_in, const std::vector<int>& outs, const std::vector<int>& reds,
-                             std::vector<float>* scalars_out, int variant);
+                             std::vector<float>* scalars_out, int variant, bool fixed_scalars);
     // rows: per batch row, n_in input buffers + n_out output buffers (+ per-row scalars, shifts)
     struct RowSpec { std::vector<const float*> in; std::vector<float*> out; const float* scalars; const double* shifts; };
     void launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments);
