@@ -173,6 +173,17 @@ def main():
     alg_bytes = 4.0 * (3 + 1) * n * B
     achieved = alg_bytes / avg_kernel_s / 1e9
 
+    # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
+    # correction applied) — measured offline on this exact workload and committed under profiles/; null for other shapes.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "round01_hbm_traffic.json")) as fh:
+            prof = json.load(fh)
+        if prof["workload"]["paths"] == n and prof["workload"]["batch"] == B:
+            traffic = prof["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = N_OPS * n * B * world / (elapsed / args.steps)
@@ -189,8 +200,8 @@ def main():
                        "parallelism": f"path-shard x{world}" if world > 1 else "single GPU",
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fm_program_kernel<1,false>", "avg_kernel_us": avg_kernel_s * 1e6,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "fm::fm_program_kernel<1, false, 8, 10, 3, float __vector(10)>", "avg_kernel_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "mean_w": mean_w,
         }
