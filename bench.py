@@ -156,11 +156,12 @@ def main():
         elapsed = float(tmax.item())
 
     # combined expectations (sanity: finite, and identical on every rank by construction)
+    par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
     if world > 1:
-        g = gathered.view(world, B, 4)
-        mean_w = float((g[:, :, 0].sum(0) / (world * n)).mean().item())
+        comb = par.combine_moments(gathered.view(world, B, 4))
     else:
-        mean_w = float((partial.view(B, 4)[:, 0] / n).mean().item())
+        comb = partial.view(B, 4)
+    mean_w = float((comb[:, 0] / (world * n)).mean().item())
     assert np.isfinite(mean_w)
 
     # live kernel duration of the dominant kernel (HIP events on the runtime stream), separate short pass

@@ -1,0 +1,113 @@
+"""Callers on the other side of the hot path: the reference's MonteCarloBlackScholesModelTest
+(MonteCarloBlackScholesModelTest.java:62-85,125-157 — MC call price within 0.005 of the analytic value 0.1899,
+README.md:212) and BASELINE.json configs[2] (BrownianMotionHip 1M paths × 200 steps × 5 factors driving a Heston MC),
+plus parity of the whole simulation against the CPU twin fed with the same increments."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+S0, R, SIGMA, T, K = 1.0, 0.05, 0.30, 2.0, 1.05        # MonteCarloBlackScholesModelTest.java:62-64,75-76
+
+
+class ArrayBrownianMotion:
+    """BrownianMotion over given increment vectors and a given factory (test helper: feeds the CPU twin with the
+    very same increments the device generated)."""
+    def __init__(self, td, factory, increments):
+        self.td, self.factory = td, factory
+        self.inc = [[factory.createRandomVariable(td.getTime(t + 1), a) for a in row] for t, row in enumerate(increments)]
+    def getTimeDiscretization(self): return self.td
+    def getBrownianIncrement(self, t, f): return self.inc[t][f]
+    def getRandomVariableForConstant(self, v): return self.factory.createRandomVariable(v)
+
+
+def test_black_scholes_reference_configuration(gpu):
+    """1 000 000 paths, 100 steps of Δt = 1.0, seed 31415, call T=2, K=1.05: |MC - analytic| < 0.005."""
+    from importlib import import_module
+    mc = import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    bm = gpu.BrownianMotionHip(gpu.TimeDiscretization(0.0, 100, 1.0), 1, 1_000_000, 31415)
+    analytic = mc.black_scholes_call_analytic(S0, R, SIGMA, T, K)
+    assert abs(analytic - 0.1899) < 5e-4                                   # README.md:212
+    for fusion in (False, True):
+        prev = gpu.set_fusion(fusion)
+        try:
+            value, _ = mc.black_scholes_call_mc(bm, S0, R, SIGMA, T, K)
+        finally:
+            gpu.set_fusion(prev)
+        assert abs(value - analytic) < 0.005, (fusion, value, analytic)    # MonteCarloBlackScholesModelTest.java:156
+
+
+def test_black_scholes_whole_simulation_parity_vs_twin(gpu, oracle):
+    from importlib import import_module
+    mc = import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    n, steps, dt = 20000, 8, 0.25
+    td = gpu.TimeDiscretization(0.0, steps, dt)
+    bm = gpu.BrownianMotionHip(td, 1, n, 31415)
+    inc = oracle.bm_generate(31415, [td.getTimeStep(i) for i in range(steps)], 1, n)
+    bmo = ArrayBrownianMotion(td, oracle.RandomVariableFloatFactory(), inc)
+    vo, rvo = mc.black_scholes_call_mc(bmo, S0, R, SIGMA, T, K)
+    for fusion in (False, True):
+        prev = gpu.set_fusion(fusion)
+        try:
+            vg, rvg = mc.black_scholes_call_mc(bm, S0, R, SIGMA, T, K)
+            got = rvg.getRealizations()
+        finally:
+            gpu.set_fusion(prev)
+        want = rvo.getRealizations()
+        assert (np.abs(got - want) <= 1e-7 * (1 + np.abs(want))).all()     # one fp64-evaluated exp in the chain
+        assert (got != want).mean() <= 1e-4
+        assert abs(vg - vo) <= 1e-9
+
+
+@pytest.mark.parametrize("xi", [0.0, 0.3])
+def test_heston_whole_simulation_parity_vs_twin(gpu, oracle, xi):
+    from importlib import import_module
+    mc = import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    n, steps, dt = 4099, 20, 0.1
+    td = gpu.TimeDiscretization(0.0, steps, dt)
+    bm = gpu.BrownianMotionHip(td, 2, n, 777)
+    inc = oracle.bm_generate(777, [td.getTimeStep(i) for i in range(steps)], 2, n)
+    bmo = ArrayBrownianMotion(td, oracle.RandomVariableFloatFactory(), inc)
+    args = (S0, R, 0.09, 1.0, 0.09, xi, -0.5, T, K)
+    vo, rvo = mc.heston_call_mc(bmo, *args)
+    for fusion in (False, True):
+        prev = gpu.set_fusion(fusion)
+        try:
+            vg, rvg = mc.heston_call_mc(bm, *args)
+            got = rvg.getRealizations()
+        finally:
+            gpu.set_fusion(prev)
+        want = rvo.getRealizations()
+        # everything before the final exp is bit-exact arithmetic (+ - * sqrt max); the exp is fp64-evaluated
+        assert (np.abs(got - want) <= 1e-7 * (1 + np.abs(want))).all()
+        assert (got != want).mean() <= 1e-4
+        assert abs(vg - vo) <= 1e-9
+
+
+def test_heston_config3_full_size(gpu):
+    """BASELINE.json configs[2]: 1 000 000 paths × 200 steps (dt = 0.01) × 5 factors, seed 31415 (4.0 GB of increments).
+    ξ = 0 ⇒ Black–Scholes limit within 0.005 (MonteCarloBlackScholesModelTest.java:156); ξ = 0.3 ⇒ a price in the
+    no-arbitrage band and below the ξ = 0 price by a small skew effect."""
+    from importlib import import_module
+    mc = import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    n = 1_000_000
+    td = gpu.TimeDiscretization(0.0, 200, 0.01)
+    bm = gpu.BrownianMotionHip(td, 5, n, 31415)
+    analytic = mc.black_scholes_call_analytic(S0, R, SIGMA, T, K)
+    prev = gpu.set_fusion(True)
+    try:
+        before = gpu.pool_stats().n_kernel_launches
+        v0, _ = mc.heston_call_mc(bm, S0, R, 0.09, 1.0, 0.09, 0.0, -0.5, T, K)
+        launches = gpu.pool_stats().n_kernel_launches - before
+        v3, rv3 = mc.heston_call_mc(bm, S0, R, 0.09, 1.0, 0.09, 0.3, -0.5, T, K)
+    finally:
+        gpu.set_fusion(prev)
+    assert abs(v0 - analytic) < 0.005
+    assert max(S0 - K * math.exp(-R * T), 0.0) < v3 < S0 and abs(v3 - analytic) < 0.02
+    assert rv3.getMin() >= 0.0
+    # 200 steps × ~6 method calls per step would be ≥ 1200 launches unfused
+    assert launches < 200, launches
+    del bm
+    gpu.purge()
