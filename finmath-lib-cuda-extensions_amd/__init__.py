@@ -54,6 +54,16 @@ def set_fusion(enabled: bool) -> bool:
     return bool(prev.value)
 
 
+MATH_EXACT, MATH_FAST = 0, 1
+
+
+def set_math_mode(mode: int) -> int:
+    """MATH_EXACT (default): exp/log in fp64, narrowed once; MATH_FAST: hardware exp/log, within 2 fp32 ulp."""
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_set_math_mode(int(mode), _C.byref(prev)))
+    return prev.value
+
+
 def flush() -> None:
     _native.check(lib().fmhip_flush())
 

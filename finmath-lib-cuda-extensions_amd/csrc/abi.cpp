@@ -100,6 +100,16 @@ int fmhip_set_fusion(int enabled, int* previous) {
         e.fusion = enabled != 0;
     });
 }
+int fmhip_set_math_mode(int mode, int* previous) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        e.require_init();
+        if (mode != FMHIP_MATH_EXACT && mode != FMHIP_MATH_FAST) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown math mode");
+        if (previous) *previous = e.math_mode;
+        if (e.math_mode != mode) e.flush_all();         // pending nodes were recorded under the old mode
+        e.math_mode = mode;
+    });
+}
 int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); }); }
 
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {

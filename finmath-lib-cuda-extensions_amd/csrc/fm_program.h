@@ -42,15 +42,17 @@ enum UOp : uint32_t {
     // A = f(A, R[r1], R[r2])
     U_ADDPRODUCT_A /*A+R1*R2*/, U_ADDPRODUCT_B /*R1+A*R2*/, U_ADDRATIO_A /*A+R1/R2*/, U_SUBRATIO_A /*A-R1/R2*/,
     U_CHOOSE_T /*A>=0?R1:R2*/, U_CHOOSE_P /*R1>=0?A:R2*/, U_CHOOSE_N /*R1>=0?R2:A*/,
+    // fast-math variants (hardware transcendentals, ≤ 2 ulp)
+    U_EXP_FAST, U_LOG_FAST,
     U__COUNT
 };
 
 // Instruction word: code[0:7] r1[8:11] r2[12:15] store[16:19] scalar_slot[24:31].
 // Every micro-op writes A to R[store]; the LAST register of the file is a dummy that is never allocated ("no
 // store") — an unconditional write is cheaper for the compiler than a conditional one (see the kernel).
-// Two kernel variants: variant 0 = 4 elements per lane, 16 registers; variant 1 = 8 elements per lane, 10 registers.
+// Two kernel variants: variant 0 = 4 elements per lane, 16 registers; variant 1 = 8 elements per lane, 9 registers.
 struct DevOp { uint32_t w; };
-constexpr int FM_VARIANT_NREG[2] = { 16, 10 };
+constexpr int FM_VARIANT_NREG[2] = { 16, 9 };
 constexpr int FM_VARIANT_ELEMS[2] = { 4, 8 };
 static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsigned st, unsigned sslot) {
     return (code & 0xffu) | ((r1 & 15u) << 8) | ((r2 & 15u) << 12) | ((st & 15u) << 16) | ((sslot & 0xffu) << 24);

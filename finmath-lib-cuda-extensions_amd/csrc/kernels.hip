@@ -23,7 +23,7 @@
 namespace fm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x10 __attribute__((ext_vector_type(10)));   // > 8 elements: dynamic indexing stays on s_set_gpr_idx (<= 8 would be expanded into v_cndmask chains)
+typedef float f32x9 __attribute__((ext_vector_type(9)));   // > 8 elements: dynamic indexing stays on s_set_gpr_idx (<= 8 would be expanded into v_cndmask chains)
 // Vector pointers arrive as 64-bit integers in the row block; casting them to the GLOBAL address space keeps the
 // data path on global_load/global_store_dwordx4 (a plain C++ pointer would be "generic" → flat_load, which also
 // ties up lgkmcnt).
@@ -37,6 +37,14 @@ typedef f32x4 __attribute__((address_space(1))) gfloat4;
 // One case of the dispatch switch: number of register operands fetched from R = 0, 1 or 2.  E elements per lane.
 #define FM_U0(CODE) case CODE:                                                                          \
         _Pragma("unroll") for (int j = 0; j < E; ++j) a[j] = ueval<CODE>(a[j], 0.f, 0.f, s);           \
+        break;
+// Register-hungry fp64 bodies (exact exp/log): evaluate four elements at a time so that the live fp64 temporaries of
+// eight interleaved evaluations do not push the kernel past 128 VGPRs (= below 4 waves per SIMD).
+#define FM_U0H(CODE) case CODE:                                                                         \
+        _Pragma("unroll") for (int g = 0; g < E; g += 4) {                                              \
+            _Pragma("unroll") for (int j = g; j < g + 4; ++j) a[j] = ueval<CODE>(a[j], 0.f, 0.f, s);    \
+            __builtin_amdgcn_sched_barrier(0);                                                          \
+        }                                                                                               \
         break;
 #define FM_U1(CODE) case CODE: {                                                                        \
         float p[E];                                                                                     \
@@ -85,7 +93,7 @@ __device__ __forceinline__ void wave_reduce(double& s1, double& s2, float& mn, f
 
 // E elements per lane (E/4 tiles of 1024 elements per pass), RegVec = register-file vector (NREG floats).
 //   variant 0: E = 4, 16 registers  — programs with many live values
-//   variant 1: E = 8, 10 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
+//   variant 1: E = 8,  9 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
 // NIN_T = compile-time bound of the number of preloaded inputs (the preload loop is unrolled NIN_T times).
 template <int NRED, bool INLINE_ROW, int E, int NREG, int NIN_T, typename RegVec>
 __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A,
@@ -111,9 +119,12 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
     }
 
-    RegVec R[E];                                    // virtual register file, one vector per element lane (static indices only)
+    // Virtual register file, one vector per element lane (static indices only).  Deliberately NOT zero-initialised:
+    // a register is always written (preload / store) before the program reads it, and clearing 80 VGPRs per workgroup
+    // cost 10 VALU instructions per element.  The empty asm gives the vectors a defined (arbitrary) value.
+    RegVec R[E];
 #pragma unroll
-    for (int j = 0; j < E; ++j) R[j] = 0.0f;
+    for (int j = 0; j < E; ++j) asm volatile("" : "=v"(R[j]));
 
     // A.tiles_per_row counts passes of FM_BLOCK*E elements.
     for (uint32_t tile = blockIdx.x; tile < A.tiles_per_row; tile += gridDim.x) {
@@ -121,13 +132,14 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         // operands with VECTOR loads — measured: one global_load + 500 cycles per micro-op).  Lanes past the end read
         // element 0 and are masked at the stores / reductions.  Vectors are padded to 256 B, so a partially valid
         // float4 is in bounds.
-        int64_t i4[T], i4c[T];
+        // 32-bit float4 indices (the host limits a vector to 2^31 elements): half the address registers of int64.
+        uint32_t i4[T], i4c[T];
         bool lane_valid[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            i4[t] = ((int64_t)tile * T + t) * FM_BLOCK + threadIdx.x;   // float4 index inside the vector, unit stride across lanes
-            lane_valid[t] = i4[t] * FM_VEC < n;
-            i4c[t] = lane_valid[t] ? i4[t] : 0;
+            i4[t] = (tile * T + t) * FM_BLOCK + threadIdx.x;            // float4 index inside the vector, unit stride across lanes
+            lane_valid[t] = (int64_t)i4[t] * FM_VEC < n;
+            i4c[t] = lane_valid[t] ? i4[t] : 0u;
         }
 
         // ---- preload: every input vector, 16 B per lane and tile, all loads in flight before the first use.
@@ -153,7 +165,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
         // ---- interpret: one wave-uniform decode per micro-op, E elements per lane, accumulator in a[].
         float a[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) a[j] = 0.0f;
+        for (int j = 0; j < E; ++j) asm volatile("" : "=v"(a[j]));     // the first micro-op of every program is U_LDA
         // Two-deep software pipeline of the scalar fetches: while micro-op pc executes, the scalar operand of pc+1 and
         // the instruction word of pc+2 are in flight (ops[] carries two slack entries).
         uint32_t w = A.ops[0].w;
@@ -166,16 +178,26 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             const uint32_t r1 = (w >> 8) & 15u, r2 = (w >> 12) & 15u, st = (w >> 16) & 15u;
             switch (code) {
                 FM_U1(U_LDA)
-                FM_U0(U_SQUARED) FM_U0(U_SQRT) FM_U0(U_EXP) FM_U0(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
-                FM_U0(U_SIN) FM_U0(U_COS) FM_U0(U_ISNAN)
+                FM_U0(U_SQUARED) FM_U0(U_SQRT) FM_U0H(U_EXP) FM_U0H(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
+                FM_U0(U_ISNAN) FM_U0(U_EXP_FAST) FM_U0(U_LOG_FAST)
                 FM_U0(U_CAP_S) FM_U0(U_FLOOR_S) FM_U0(U_ADD_S) FM_U0(U_SUB_S) FM_U0(U_BUS_S) FM_U0(U_MULT_S)
-                FM_U0(U_DIV_S) FM_U0(U_VID_S) FM_U0(U_POW_S)
+                FM_U0(U_DIV_S) FM_U0(U_VID_S)
                 FM_U1(U_CAP) FM_U1(U_FLOOR) FM_U1(U_ADD) FM_U1(U_MULT) FM_U1(U_SUB) FM_U1(U_BUS) FM_U1(U_DIV) FM_U1(U_VID)
                 FM_U1(U_ACCRUE_A) FM_U1(U_ACCRUE_B) FM_U1(U_DISCOUNT_A) FM_U1(U_DISCOUNT_B)
                 FM_U1(U_ADDPRODUCT_VS_A) FM_U1(U_ADDPRODUCT_VS_B)
                 FM_U2(U_ADDPRODUCT_A) FM_U2(U_ADDPRODUCT_B) FM_U2(U_ADDRATIO_A) FM_U2(U_SUBRATIO_A)
                 FM_U2(U_CHOOSE_T) FM_U2(U_CHOOSE_P) FM_U2(U_CHOOSE_N)
-                default: break;
+                default:
+                    // pow / sin / cos call out-of-line fp64 library code; a call site inside the 8-element kernel would
+                    // add the callee's ~40 VGPRs to 96 live ones (→ 3 waves/SIMD for everybody).  Programs that use
+                    // them are compiled for the 4-element / 16-register variant (runtime.cpp: compile()).
+                    if constexpr (E == 4) {
+                        switch (code) {
+                            FM_U0(U_SIN) FM_U0(U_COS) FM_U0(U_POW_S)
+                            default: break;
+                        }
+                    }
+                    break;
             }
             if (st != (uint32_t)(NREG - 1)) {       // the last register of the file means "no store"
 #pragma unroll
@@ -206,7 +228,17 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             float x[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = R[j][reg];
-            if (pass_full) {
+            if (pass_full && shift == 0.0) {        // getAverage / first pass of getVariance: no subtraction
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double dv = (double)x[j];
+                    acc_sum[r] += dv;
+                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
+                    acc_min[r] = hw_min(acc_min[r], x[j]);
+                    acc_max[r] = hw_max(acc_max[r], x[j]);
+                    nan_mask[r] |= __ballot(x[j] != x[j]);
+                }
+            } else if (pass_full) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     const double dv = (double)x[j] - shift;
@@ -219,7 +251,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             } else {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
-                    const bool ok = i4[j / 4] * FM_VEC + (j & 3) < n;
+                    const bool ok = (int64_t)i4[j / 4] * FM_VEC + (j & 3) < n;
                     const double dv = ok ? (double)x[j] - shift : 0.0;
                     acc_sum[r] += dv;
                     acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
@@ -434,8 +466,8 @@ template <int NRED>
 static hipError_t launch_program_nred(const DevProgramArgs& a, const uint64_t* rows, double* partials, dim3 grid, hipStream_t st)
 {
     if (a.variant == 1) {
-        if (a.n_in <= 3) return launch_program_v<NRED, 8, 10, 3, f32x10>(a, rows, partials, grid, st);
-        return launch_program_v<NRED, 8, 10, 9, f32x10>(a, rows, partials, grid, st);
+        if (a.n_in <= 3) return launch_program_v<NRED, 8, 9, 3, f32x9>(a, rows, partials, grid, st);
+        return launch_program_v<NRED, 8, 9, 8, f32x9>(a, rows, partials, grid, st);
     }
     return launch_program_v<NRED, 4, 16, FM_MAX_IN, f32x16>(a, rows, partials, grid, st);
 }

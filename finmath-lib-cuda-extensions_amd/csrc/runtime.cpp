@@ -231,7 +231,7 @@ void Engine::release(fmhip_vec h) {
 }
 
 static void check_n(int64_t n) {
-    if (n < 0 || n > (int64_t(1) << 40)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "invalid vector size " + std::to_string(n));
+    if (n < 0 || n > (int64_t(1) << 31)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "invalid vector size " + std::to_string(n));
 }
 
 fmhip_vec Engine::create_uninitialized(int64_t n) {
@@ -367,8 +367,12 @@ Program* Engine::compile(const std::vector<SsaOp>& ops, int n_in, const std::vec
     // Prefer the 8-elements-per-lane kernel (8 registers); fall back to 4 elements / 16 registers when the program
     // keeps more values alive.
     // fixed_scalars == false: the lazy front-end patches scalars per row, so no value-dependent rewrites are allowed
-    try { return compile_variant(ops, n_in, outs, reds, scalars_out, 1, fixed_scalars); }
-    catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; }
+    bool library_math = false;          // pow / sin / cos live only in the 4-element kernel (see kernels.hip)
+    for (const SsaOp& o : ops) library_math |= (o.opcode == FMHIP_OP_POW_S || o.opcode == FMHIP_OP_SIN || o.opcode == FMHIP_OP_COS);
+    if (!library_math) {
+        try { return compile_variant(ops, n_in, outs, reds, scalars_out, 1, fixed_scalars); }
+        catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; }
+    }
     return compile_variant(ops, n_in, outs, reds, scalars_out, 0, fixed_scalars);
 }
 
@@ -457,6 +461,7 @@ Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const 
         }
         unsigned slot = 0;
         uint32_t uop = uv.uop;
+        if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
         if (op_info(ops[i].opcode).scalar) {
             if ((int)scal.size() >= FM_MAX_SCAL) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many scalar operands for one launch"); }
             slot = (unsigned)scal.size();
@@ -511,9 +516,9 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
     if (tiles > int64_t(0x7fffffff)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "vector too long");
     // One pass per workgroup: measured fastest for pure streaming on MI355X (5.8 TB/s vs 5.0 TB/s with a 2048-workgroup
-    // grid-stride loop).  With fused reductions a workgroup covers ≈4096 elements so that the wave/LDS combine and
-    // the partial write are amortised.
-    int64_t passes_per_block = (n_red > 0) ? std::max<int64_t>(1, 4096 / elems_per_pass) : 1;
+    // grid-stride loop).  With fused reductions a workgroup covers several passes so that the wave/LDS combine and
+    // the partial write are amortised (≈8192 elements per workgroup).
+    int64_t passes_per_block = (n_red > 0) ? std::max<int64_t>(1, 8192 / elems_per_pass) : 1;
     int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
     bpr = std::min<int64_t>(std::max<int64_t>(bpr, 1), 65536);
     args.n = n;
@@ -647,7 +652,7 @@ bool Engine::build_dag(Node* target, Dag& dag) {
     const int n_in = (int)dag.leaves.size();
     for (int k = 0; k < n_in; ++k) id_of[dag.leaves[k]] = k;
     dag.sig.reserve(dag.order.size() * 12 + 16);
-    dag.sig += "i" + std::to_string(n_in) + ";";
+    dag.sig += "m" + std::to_string(math_mode) + "i" + std::to_string(n_in) + ";";
     for (size_t i = 0; i < dag.order.size(); ++i) {
         Node* nd = dag.order[i];
         id_of[nd] = n_in + (int)i;

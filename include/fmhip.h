@@ -185,6 +185,16 @@ int fmhip_set_fusion(int enabled, int* previous);
  * different vectors are batched into one launch). */
 int fmhip_flush(void);
 
+/* Arithmetic mode of exp and log (everything else is identical in both modes):
+ *   FMHIP_MATH_EXACT (default): evaluated in fp64 and narrowed once — bit-identical to the reference's CPU twin
+ *                               `(float)Math.exp(x)` except where two fp64 libms differ in the last fp64 ulp;
+ *   FMHIP_MATH_FAST:            hardware v_exp_f32 / v_log_f32 with fp32 range reduction, within 2 fp32 ulp — the accuracy
+ *                               class of the CUDA expf/logf used by the reference's kernels; ~4x fewer instructions.
+ * Applies to programs compiled after the call (eager ops, fused chains, fmhip_program_create). */
+#define FMHIP_MATH_EXACT 0
+#define FMHIP_MATH_FAST  1
+int fmhip_set_math_mode(int mode, int* previous);
+
 /* ---------------------------------------------------------------- reductions */
 
 /* One pass over v on the device: Σ(x-shift), Σ(x-shift)², min, max with fp64 accumulation; 32 bytes

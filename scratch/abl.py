@@ -36,7 +36,13 @@ def prog(kind, red=True):
     p.output(w)
     if red: p.reduce(w)
     return p.compile()
-for kind, red in [("copy1", False), ("copy1", True), ("simple12", False), ("simple24", False), ("div1", False), ("sqrt1", False), ("exp1", False), ("log1", False), ("S_noexplog", True), ("S", True), ("S", False)]:
+import sys as _s
+MODES = [("exact", fm.MATH_EXACT), ("fast", fm.MATH_FAST)]
+for mname, mode in MODES:
+  fm.set_math_mode(mode)
+  print("math mode", mname)
+  for kind, red in [("copy1", False), ("copy1", True), ("simple12", False), ("simple24", False), ("div1", False), ("sqrt1", False), ("exp1", False), ("log1", False), ("S_noexplog", True), ("S", True), ("S", False)]:
+    if mname == "fast" and kind not in ("exp1", "log1", "S"): continue
     p = prog(kind, red)
     for _ in range(3): p.run_into(rows, outs, want_moments=False)
     fm.profile_enable(True)

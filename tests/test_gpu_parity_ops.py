@@ -151,3 +151,28 @@ def test_errors(gpu):
     with pytest.raises(gpu.FmhipError) as e:
         a.v1s0("ADD")                   # wrong call shape for the opcode
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("op", ["EXP", "LOG"])
+def test_fast_math_mode_within_2_ulp(gpu, oracle, xyz, op):
+    """FMHIP_MATH_FAST: hardware v_exp_f32 / v_log_f32 with fp32 range reduction.  Stated tolerance: 2 fp32 ulp of the
+    twin's `(float)Math.exp/log((double)x)` (the accuracy class of the CUDA expf/logf the reference kernels call);
+    special values (0, negatives, ±inf, NaN, denormals, overflow/underflow) exactly as in exact mode."""
+    x, y, z = xyz
+    prev = gpu.set_math_mode(gpu.MATH_FAST)
+    try:
+        with np.errstate(all="ignore"):
+            worst = 0
+            wide = np.concatenate([x * 170.0 - 85.0, np.logspace(-44, 38, 20001).astype(np.float32), 1.0 + (x - 0.5) * 1e-3])
+            for v in (x, y, z * 20.0, wide, edge_values()[0]):
+                got = dv(gpu, v).v1s0(op).to_float32()
+                want = oracle.f_v1s0(op, v)
+                d = ulp_diff(got, want)
+                assert (np.isnan(got) == np.isnan(want)).all(), op
+                assert (np.isinf(got) == np.isinf(want)).all() or op == "EXP", op
+                worst = max(worst, int(d[np.isfinite(want) & np.isfinite(got)].max(initial=0)))
+            assert worst <= 2, f"{op}: max ulp error {worst}"
+    finally:
+        gpu.set_math_mode(prev)
+    # exact mode is restored: bit-level agreement again
+    assert_libm_close(dv(gpu, x).v1s0(op).to_float32(), oracle.f_v1s0(op, x), op)
