@@ -612,40 +612,43 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
 }
 
 struct Engine::Dag {
-    Node* target = nullptr;
-    std::vector<Node*> order;       // pending nodes, operands before users, target last
+    std::vector<Node*> roots;       // the values asked for
+    std::vector<Node*> order;       // pending nodes, operands before users
     std::vector<Node*> leaves;      // distinct materialised inputs
-    std::vector<Node*> outs;        // target first, then escaping intermediates
+    std::vector<Node*> outs;        // roots first, then escaping intermediates
     std::vector<SsaOp> ops;
     std::vector<int> out_ids;
     std::vector<float> scalars;
     std::string sig;
 };
 
-// Linearise the pending expression below `target`.  Returns false when it cannot run as one launch.
-bool Engine::build_dag(Node* target, Dag& dag) {
-    dag.target = target;
-    std::unordered_map<Node*, int> id_of;           // value id per node (leaves first — assigned in a second pass)
+// Linearise the pending expressions below `roots` into ONE program (roots may share intermediates: they become
+// several outputs of the same launch).  Returns false when it cannot run as one launch.
+bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
+    dag.roots = roots;
+    std::unordered_map<Node*, int> id_of;
     std::unordered_map<Node*, int> in_dag_uses;
     std::unordered_set<Node*> seen;
-    // iterative post-order
     std::vector<std::pair<Node*, int>> stack;
-    stack.push_back({ target, 0 });
-    seen.insert(target);
-    while (!stack.empty()) {
-        auto& top = stack.back();
-        Node* nd = top.first;
-        if (top.second < nd->n_in) {
-            Node* c = nd->in[top.second++];
-            if (c->buf) {
-                if (!seen.count(c)) { seen.insert(c); dag.leaves.push_back(c); }
+    for (Node* root : roots) {
+        if (seen.count(root)) continue;             // a root that is also an operand of an earlier root
+        stack.push_back({ root, 0 });
+        seen.insert(root);
+        while (!stack.empty()) {                    // iterative post-order
+            auto& top = stack.back();
+            Node* nd = top.first;
+            if (top.second < nd->n_in) {
+                Node* c = nd->in[top.second++];
+                if (c->buf) {
+                    if (!seen.count(c)) { seen.insert(c); dag.leaves.push_back(c); }
+                } else {
+                    in_dag_uses[c]++;
+                    if (!seen.count(c)) { seen.insert(c); stack.push_back({ c, 0 }); }
+                }
             } else {
-                in_dag_uses[c]++;
-                if (!seen.count(c)) { seen.insert(c); stack.push_back({ c, 0 }); }
+                dag.order.push_back(nd);
+                stack.pop_back();
             }
-        } else {
-            dag.order.push_back(nd);
-            stack.pop_back();
         }
     }
     if ((int)dag.leaves.size() > FM_MAX_IN || (int)dag.order.size() > FM_MAX_OPS) return false;
@@ -664,13 +667,13 @@ bool Engine::build_dag(Node* target, Dag& dag) {
         dag.sig += std::to_string(nd->opcode) + "," + std::to_string(op.a) + "," + std::to_string(op.b) + "," + std::to_string(op.c) + ";";
     }
     if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
-    // outputs: the target, plus every intermediate somebody else still needs
-    dag.outs.push_back(target);
-    dag.out_ids.push_back(id_of[target]);
+    // outputs: every root, plus every intermediate somebody else still needs
+    std::unordered_set<Node*> is_out;
+    for (Node* r : roots) if (is_out.insert(r).second) { dag.outs.push_back(r); dag.out_ids.push_back(id_of[r]); }
     for (Node* nd : dag.order) {
-        if (nd == target) continue;
+        if (is_out.count(nd)) continue;
         const int inside = in_dag_uses.count(nd) ? in_dag_uses[nd] : 0;
-        if (nd->refs_ext > 0 || nd->refs_int > inside) { dag.outs.push_back(nd); dag.out_ids.push_back(id_of[nd]); }
+        if (nd->refs_ext > 0 || nd->refs_int > inside) { is_out.insert(nd); dag.outs.push_back(nd); dag.out_ids.push_back(id_of[nd]); }
     }
     if ((int)dag.outs.size() > FM_MAX_OUT) return false;
     dag.sig += "o";
@@ -678,14 +681,10 @@ bool Engine::build_dag(Node* target, Dag& dag) {
     return true;
 }
 
-// Execute a set of mutually independent expression DAGs with the same structure as ONE launch.
-bool Engine::try_fused(const std::vector<Node*>& targets) {
-    std::vector<Dag> dags(targets.size());
-    for (size_t i = 0; i < targets.size(); ++i) {
-        if (!build_dag(targets[i], dags[i])) return false;
-        if (dags[i].sig != dags[0].sig || targets[i]->n != targets[0]->n) return false;
-    }
+// Execute structurally identical, mutually independent DAGs as ONE launch (one batch row per DAG).
+bool Engine::run_dags(std::vector<Dag>& dags) {
     Dag& d0 = dags[0];
+    const int64_t n = d0.roots[0]->n;
     Program* prog = nullptr;
     auto it = program_cache_.find(d0.sig);
     if (it != program_cache_.end()) prog = it->second;
@@ -694,21 +693,20 @@ bool Engine::try_fused(const std::vector<Node*>& targets) {
         catch (const Error& e) { if (e.code == FMHIP_ERR_PROGRAM_LIMIT) return false; throw; }
         program_cache_[d0.sig] = prog;
     }
-    // allocate outputs
     std::vector<std::vector<Buffer*>> out_bufs(dags.size());
     std::vector<RowSpec> rows(dags.size());
     try {
         for (size_t i = 0; i < dags.size(); ++i) {
             for (Node* l : dags[i].leaves) rows[i].in.push_back(l->buf->ptr);
             for (size_t k = 0; k < dags[i].outs.size(); ++k) {
-                Buffer* b = new_buffer(targets[0]->n);
+                Buffer* b = new_buffer(n);
                 out_bufs[i].push_back(b);
                 rows[i].out.push_back(b->ptr);
             }
             rows[i].scalars = dags[i].scalars.data();
             rows[i].shifts = nullptr;
         }
-        launch(prog, targets[0]->n, rows, nullptr, nullptr);
+        launch(prog, n, rows, nullptr, nullptr);
     } catch (...) {
         for (auto& v : out_bufs) for (Buffer* b : v) buffer_unref(b);
         throw;
@@ -726,6 +724,12 @@ bool Engine::try_fused(const std::vector<Node*>& targets) {
     return true;
 }
 
+bool Engine::try_fused(const std::vector<Node*>& roots) {
+    std::vector<Dag> dags(1);
+    if (!build_dag(roots, dags[0])) return false;
+    return run_dags(dags);
+}
+
 void Engine::materialize(const std::vector<Node*>& targets) {
     for (Node* t : targets) {
         if (t->buf) continue;
@@ -741,45 +745,69 @@ void Engine::materialize(const std::vector<Node*>& targets) {
     }
 }
 
+// Execute everything that is pending and still referenced.  Pending results that share intermediates form one
+// connected component and run as ONE multi-output launch; components with identical structure (same ops, different
+// vectors and scalars — e.g. all LIBOR components of an Euler step) are batched as rows of one launch.
 void Engine::flush_all() {
     require_init();
-    for (;;) {
-        // roots: live pending vectors nobody pending depends on
-        std::vector<Node*> roots;
+    for (int round = 0; round < 1000000; ++round) {
+        std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
         for (auto& kv : nodes_) if (!kv.second->buf && kv.second->refs_int == 0) roots.push_back(kv.second);
         if (roots.empty()) {
-            // only pending nodes with pending consumers but no live root can remain if handles were released; done
             bool any = false;
             for (auto& kv : nodes_) if (!kv.second->buf) { any = true; materialize({ kv.second }); break; }
             if (!any) return;
             continue;
         }
         std::sort(roots.begin(), roots.end(), [](Node* a, Node* b) { return a->id < b->id; });
-        // group structurally identical, mutually disjoint DAGs
-        std::unordered_set<Node*> claimed;
-        std::unordered_map<std::string, std::vector<Node*>> groups;
-        std::vector<std::string> group_order;
-        std::vector<Node*> singles;
-        for (Node* r : roots) {
-            Dag d;
-            if (!build_dag(r, d)) { singles.push_back(r); continue; }
-            bool overlap = false;
-            for (Node* nd : d.order) if (claimed.count(nd)) { overlap = true; break; }
-            if (overlap) continue;                  // next round, after the shared part has been materialised
-            for (Node* nd : d.order) claimed.insert(nd);
-            const std::string key = d.sig + "#" + std::to_string(r->n);
-            if (!groups.count(key)) group_order.push_back(key);
-            groups[key].push_back(r);
-        }
-        for (const std::string& key : group_order) {
-            std::vector<Node*>& g = groups[key];
-            const size_t max_batch = 1024;
-            for (size_t off = 0; off < g.size(); off += max_batch) {
-                std::vector<Node*> part(g.begin() + off, g.begin() + std::min(g.size(), off + max_batch));
-                if (!try_fused(part)) materialize(part);
+        // connected components of the pending graph (union-find over root indices)
+        std::vector<int> parent(roots.size());
+        for (size_t i = 0; i < roots.size(); ++i) parent[i] = (int)i;
+        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        std::unordered_map<Node*, int> owner;
+        std::vector<Node*> stack;
+        for (size_t i = 0; i < roots.size(); ++i) {
+            stack.push_back(roots[i]);
+            owner[roots[i]] = (int)i;
+            while (!stack.empty()) {
+                Node* nd = stack.back(); stack.pop_back();
+                for (int k = 0; k < nd->n_in; ++k) {
+                    Node* c = nd->in[k];
+                    if (c->buf) continue;
+                    auto f = owner.find(c);
+                    if (f != owner.end()) { const int a = find((int)i), b = find(f->second); if (a != b) parent[b] = a; }
+                    else { owner[c] = (int)i; stack.push_back(c); }
+                }
             }
         }
-        if (!singles.empty()) materialize(singles);
+        std::unordered_map<int, std::vector<Node*>> comps;
+        std::vector<int> comp_order;
+        for (size_t i = 0; i < roots.size(); ++i) {
+            const int c = find((int)i);
+            if (!comps.count(c)) comp_order.push_back(c);
+            comps[c].push_back(roots[i]);
+        }
+        // one DAG per component; group identical structures
+        std::unordered_map<std::string, std::vector<Dag>> groups;
+        std::vector<std::string> group_order;
+        std::vector<Node*> leftovers;
+        for (int c : comp_order) {
+            Dag d;
+            if (!build_dag(comps[c], d)) { for (Node* r : comps[c]) leftovers.push_back(r); continue; }
+            const std::string key = d.sig + "#" + std::to_string(d.roots[0]->n);
+            if (!groups.count(key)) group_order.push_back(key);
+            groups[key].push_back(std::move(d));
+        }
+        for (const std::string& key : group_order) {
+            std::vector<Dag>& g = groups[key];
+            const size_t max_batch = 1024;
+            for (size_t off = 0; off < g.size(); off += max_batch) {
+                std::vector<Dag> part(std::make_move_iterator(g.begin() + off), std::make_move_iterator(g.begin() + std::min(g.size(), off + max_batch)));
+                if (!run_dags(part)) for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r);
+            }
+        }
+        // components that do not fit one launch: root by root (shared parts escape and are reused)
+        for (Node* r : leftovers) if (!r->buf) materialize({ r });
     }
 }
 

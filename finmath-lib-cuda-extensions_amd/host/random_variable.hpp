@@ -1,0 +1,405 @@
+// random_variable.hpp — C++ host-side mirror of the reference's plug-in interfaces, above the C-ABI.
+//
+//   reference (Java)                                              here (namespace fmhost)
+//   ------------------------------------------------------------------------------------------------------
+//   net.finmath.stochastic.RandomVariable (finmath-lib, external) RandomVariable   (abstract interface)
+//   net.finmath.montecarlo.RandomVariableFactory                  RandomVariableFactory
+//   net.finmath.montecarlo.BrownianMotion                         BrownianMotion
+//   RandomVariableCuda        (RandomVariableCuda.java)           RandomVariableHip
+//   RandomVariableCudaFactory (RandomVariableCudaFactory.java)    RandomVariableHipFactory
+//   BrownianMotionCudaWithRandomVariableCuda                      BrownianMotionHip
+//
+// Same method names, argument meaning, dispatch order (type priority → newTime → deterministic fast paths) and
+// error behaviour as RandomVariableCuda (`:line` cites RandomVariableCuda.java; the deviations that follow the
+// reference's own CPU twin are the ones listed in ../random_variable.py).  Random variables are immutable and
+// shared: `RV` = std::shared_ptr<const RandomVariable>.  Models (lmm.hpp) are written against the interfaces
+// only, so the same model code runs on any implementation — exactly how finmath-lib injects a factory
+// (LIBORMarketModelCalibrationATMTest.java:351-358).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fmhip.h"
+
+namespace fmhost {
+
+class RandomVariable;
+using RV = std::shared_ptr<const RandomVariable>;
+
+// ------------------------------------------------------------------ interfaces
+
+class RandomVariable : public std::enable_shared_from_this<RandomVariable> {
+public:
+    virtual ~RandomVariable() = default;
+    // accessors
+    virtual double getFiltrationTime() const = 0;
+    virtual int    getTypePriority() const = 0;
+    virtual bool   isDeterministic() const = 0;
+    virtual int64_t size() const = 0;
+    virtual double doubleValue() const = 0;                      // throws if stochastic (:1125-1131)
+    virtual std::vector<double> getRealizations() const = 0;     // :1116-1123
+    // reductions
+    virtual double getAverage() const = 0;
+    virtual double getVariance() const = 0;
+    virtual double getMin() const = 0;
+    virtual double getMax() const = 0;
+    double getSampleVariance() const { const int64_t n = size(); return (isDeterministic() || n == 1) ? 0.0 : getVariance() * n / (n - 1); }
+    double getStandardDeviation() const { return isDeterministic() ? 0.0 : std::sqrt(getVariance()); }
+    double getStandardError() const { return isDeterministic() ? 0.0 : getStandardDeviation() / std::sqrt((double)size()); }
+    virtual double getAverage(const RV& probabilities) const { return mult(probabilities)->getAverage(); }   // :886-888
+    // scalar operand / unary
+    virtual RV cap(double v) const = 0;
+    virtual RV floor(double v) const = 0;
+    virtual RV add(double v) const = 0;
+    virtual RV sub(double v) const = 0;
+    virtual RV bus(double v) const = 0;
+    virtual RV mult(double v) const = 0;
+    virtual RV div(double v) const = 0;
+    virtual RV vid(double v) const = 0;
+    virtual RV pow(double e) const = 0;
+    virtual RV squared() const = 0;
+    virtual RV sqrt() const = 0;
+    virtual RV exp() const = 0;
+    virtual RV log() const = 0;
+    virtual RV invert() const = 0;
+    virtual RV abs() const = 0;
+    virtual RV isNaN() const = 0;
+    // vector operand
+    virtual RV cap(const RV& rv) const = 0;
+    virtual RV floor(const RV& rv) const = 0;
+    virtual RV add(const RV& rv) const = 0;
+    virtual RV sub(const RV& rv) const = 0;
+    virtual RV bus(const RV& rv) const = 0;
+    virtual RV mult(const RV& rv) const = 0;
+    virtual RV div(const RV& rv) const = 0;
+    virtual RV vid(const RV& rv) const = 0;
+    virtual RV accrue(const RV& rate, double periodLength) const = 0;
+    virtual RV discount(const RV& rate, double periodLength) const = 0;
+    virtual RV choose(const RV& valueIfTriggerNonNegative, const RV& valueIfTriggerNegative) const = 0;
+    virtual RV addProduct(const RV& factor1, double factor2) const = 0;
+    virtual RV addProduct(const RV& factor1, const RV& factor2) const = 0;
+    virtual RV addRatio(const RV& numerator, const RV& denominator) const { return add(numerator->div(denominator)); }   // :1686-1689
+    virtual RV subRatio(const RV& numerator, const RV& denominator) const { return sub(numerator->div(denominator)); }   // :1692-1695
+    RV average() const;                                           // :1280
+    RV self() const { return shared_from_this(); }
+};
+
+class RandomVariableFactory {
+public:
+    virtual ~RandomVariableFactory() = default;
+    virtual RV createRandomVariable(double value) const = 0;                                // time = -infinity
+    virtual RV createRandomVariable(double time, double value) const = 0;                   // RandomVariableCudaFactory.java:27
+    virtual RV createRandomVariable(double time, const std::vector<double>& values) const = 0;   // :32
+};
+
+class TimeDiscretization {      // stand-in for net.finmath.time.TimeDiscretizationFromArray (finmath-lib, not vendored)
+public:
+    TimeDiscretization() = default;
+    TimeDiscretization(double initial, int numberOfTimeSteps, double deltaT) {
+        for (int i = 0; i <= numberOfTimeSteps; ++i) times_.push_back(initial + i * deltaT);
+    }
+    explicit TimeDiscretization(std::vector<double> times) : times_(std::move(times)) {}
+    int getNumberOfTimeSteps() const { return (int)times_.size() - 1; }
+    int getNumberOfTimes() const { return (int)times_.size(); }
+    double getTime(int i) const { return times_.at((size_t)i); }
+    double getTimeStep(int i) const { return times_.at((size_t)i + 1) - times_.at((size_t)i); }
+    // getTimeIndex: index of `time`, or -(insertion point)-1 (java.util.Arrays.binarySearch contract)
+    int getTimeIndex(double time) const {
+        int lo = 0, hi = (int)times_.size() - 1;
+        while (lo <= hi) { const int mid = (lo + hi) / 2; if (std::fabs(times_[mid] - time) < 1e-12) return mid; if (times_[mid] < time) lo = mid + 1; else hi = mid - 1; }
+        return -(lo) - 1;
+    }
+    int getTimeIndexNearestLessOrEqual(double time) const { int i = getTimeIndex(time); if (i < 0) i = -i - 2; return i; }
+    const std::vector<double>& asVector() const { return times_; }
+private:
+    std::vector<double> times_;
+};
+
+class BrownianMotion {
+public:
+    virtual ~BrownianMotion() = default;
+    virtual RV getBrownianIncrement(int timeIndex, int factor) const = 0;
+    virtual const TimeDiscretization& getTimeDiscretization() const = 0;
+    virtual int getNumberOfFactors() const = 0;
+    virtual int64_t getNumberOfPaths() const = 0;
+    virtual RV getRandomVariableForConstant(double value) const = 0;
+};
+
+// ------------------------------------------------------------------ helpers shared by implementations
+
+inline double jmin(double a, double b) { if (a != a) return a; if (a == 0.0 && b == 0.0 && std::signbit(b)) return b; return (a <= b) ? a : b; }
+inline double jmax(double a, double b) { if (a != a) return a; if (a == 0.0 && b == 0.0 && std::signbit(a)) return b; return (a >= b) ? a : b; }
+inline double jpow(double x, double y) { if (y == 0.0) return 1.0; if (y != y) return y; if (std::isinf(y) && std::fabs(x) == 1.0) return std::nan(""); return std::pow(x, y); }
+
+struct UnsupportedOperation : std::logic_error { using std::logic_error::logic_error; };
+
+// ------------------------------------------------------------------ device vector (RAII over one fmhip_vec handle)
+
+struct FmhipError : std::runtime_error {
+    int code;
+    FmhipError(int c, const std::string& m) : std::runtime_error("fmhip error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int status) { if (status != FMHIP_OK) throw FmhipError(status, fmhip_last_error()); }
+
+class DeviceVector {
+public:
+    explicit DeviceVector(fmhip_vec h) : h_(h) {}
+    ~DeviceVector() { if (h_) fmhip_vec_release(h_); }
+    DeviceVector(const DeviceVector&) = delete;
+    DeviceVector& operator=(const DeviceVector&) = delete;
+    fmhip_vec handle() const { return h_; }
+    using Ptr = std::shared_ptr<const DeviceVector>;
+    static Ptr fromHost(const std::vector<double>& v) { fmhip_vec h = 0; check(fmhip_vec_create_from_double(v.data(), (int64_t)v.size(), &h)); return std::make_shared<DeviceVector>(h); }
+    static Ptr filled(int64_t n, double value) { fmhip_vec h = 0; check(fmhip_vec_create_filled(n, value, &h)); return std::make_shared<DeviceVector>(h); }
+    // the five launch helpers of the reference (callFunctionv1s0 … v3s0, :483-537)
+    Ptr v1s0(int op) const { fmhip_vec o = 0; check(fmhip_call_v1s0(op, h_, &o)); return std::make_shared<DeviceVector>(o); }
+    Ptr v1s1(int op, double s) const { fmhip_vec o = 0; check(fmhip_call_v1s1(op, h_, s, &o)); return std::make_shared<DeviceVector>(o); }
+    Ptr v2s0(int op, const DeviceVector& b) const { fmhip_vec o = 0; check(fmhip_call_v2s0(op, h_, b.h_, &o)); return std::make_shared<DeviceVector>(o); }
+    Ptr v2s1(int op, const DeviceVector& b, double s) const { fmhip_vec o = 0; check(fmhip_call_v2s1(op, h_, b.h_, s, &o)); return std::make_shared<DeviceVector>(o); }
+    Ptr v3s0(int op, const DeviceVector& b, const DeviceVector& c) const { fmhip_vec o = 0; check(fmhip_call_v3s0(op, h_, b.h_, c.h_, &o)); return std::make_shared<DeviceVector>(o); }
+    fmhip_moments moments(double shift = 0.0) const { fmhip_moments m; check(fmhip_reduce_moments(h_, shift, &m)); return m; }
+private:
+    fmhip_vec h_;
+};
+
+// ------------------------------------------------------------------ RandomVariableHip
+
+class RandomVariableHip final : public RandomVariable {
+public:
+    static constexpr int typePriorityDefault = 20;                // :568
+    // constant (:683-689)
+    RandomVariableHip(double time, double value, int typePriority = typePriorityDefault)
+        : time_(time), value_(value), n_(1), priority_(typePriority) {}
+    // device vector (RandomVariableCuda.of, :618-646)
+    RandomVariableHip(double time, DeviceVector::Ptr realizations, int64_t n, int typePriority = typePriorityDefault)
+        : time_(time), value_(std::numeric_limits<double>::quiet_NaN()), vec_(std::move(realizations)), n_(n), priority_(typePriority) {}
+    // host values, narrowed to fp32 and uploaded (:696-723)
+    RandomVariableHip(double time, const std::vector<double>& values)
+        : time_(time), value_(std::numeric_limits<double>::quiet_NaN()), vec_(DeviceVector::fromHost(values)), n_((int64_t)values.size()), priority_(typePriorityDefault) {}
+
+    static RV of(double time, double value) { return std::make_shared<RandomVariableHip>(time, value); }
+    static RV of(double time, DeviceVector::Ptr v, int64_t n) { return std::make_shared<RandomVariableHip>(time, std::move(v), n); }
+
+    double getFiltrationTime() const override { return time_; }
+    int getTypePriority() const override { return priority_; }
+    bool isDeterministic() const override { return !vec_; }
+    int64_t size() const override { return isDeterministic() ? 1 : n_; }
+    double doubleValue() const override {
+        if (isDeterministic()) return value_;
+        throw UnsupportedOperation("The random variable is non-deterministic");
+    }
+    std::vector<double> getRealizations() const override {
+        if (isDeterministic()) return { value_ };
+        std::vector<double> out((size_t)n_);
+        check(fmhip_vec_read_double(vec_->handle(), out.data(), n_));
+        return out;
+    }
+    const DeviceVector::Ptr& deviceVector() const { return vec_; }
+
+    // ---- reductions on the device (replaces :830-901)
+    double getAverage() const override {
+        if (isDeterministic()) return value_;
+        if (n_ == 0) return std::nan("");
+        return vec_->moments().sum / (double)n_;
+    }
+    double getVariance() const override {                          // twin two-pass Σ(x-mean)²/n (twin:360-382)
+        if (isDeterministic() || n_ == 1) return 0.0;
+        if (n_ == 0) return std::nan("");
+        const double mean = getAverage();
+        return vec_->moments(mean).sumsq / (double)n_;
+    }
+    double getMin() const override { return isDeterministic() ? value_ : vec_->moments().min; }
+    double getMax() const override { return isDeterministic() ? value_ : vec_->moments().max; }
+
+    // ---- scalar operand / unary (:1172-1352)
+    RV cap(double v) const override   { return scalar(FMHIP_OP_CAP_S, v, jmin(value_, v)); }
+    RV floor(double v) const override { return scalar(FMHIP_OP_FLOOR_S, v, jmax(value_, v)); }
+    RV add(double v) const override   { return scalar(FMHIP_OP_ADD_S, v, value_ + v); }
+    RV sub(double v) const override   { return scalar(FMHIP_OP_SUB_S, v, value_ - v); }
+    RV bus(double v) const override   { return scalar(FMHIP_OP_BUS_S, v, -value_ + v); }
+    RV mult(double v) const override  { return scalar(FMHIP_OP_MULT_S, v, value_ * v); }
+    RV div(double v) const override   { return scalar(FMHIP_OP_DIV_S, v, value_ / v); }
+    RV vid(double v) const override   { return scalar(FMHIP_OP_VID_S, v, v / value_); }
+    RV pow(double e) const override   { return scalar(FMHIP_OP_POW_S, e, jpow(value_, e)); }
+    RV squared() const override { return unary(FMHIP_OP_SQUARED, value_ * value_); }
+    RV sqrt() const override    { return unary(FMHIP_OP_SQRT, std::sqrt(value_)); }
+    RV exp() const override     { return unary(FMHIP_OP_EXP, std::exp(value_)); }
+    RV log() const override     { return unary(FMHIP_OP_LOG, std::log(value_)); }
+    RV invert() const override  { return unary(FMHIP_OP_INVERT, 1.0 / value_); }
+    RV abs() const override     { return unary(FMHIP_OP_ABS, std::fabs(value_)); }
+    RV isNaN() const override   { return unary(FMHIP_OP_ISNAN, value_ != value_ ? 1.0 : 0.0); }
+
+    // ---- vector operand (:1391-1580)
+    RV add(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->add(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, value_ + rv->doubleValue());
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_ADD_S, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_ADD_S, rv->doubleValue()), n_);
+        return of(t, vec_->v2s0(FMHIP_OP_ADD, *vecOf(rv)), n_);
+    }
+    RV sub(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->bus(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, value_ - rv->doubleValue());
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_BUS_S, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_SUB_S, rv->doubleValue()), n_);
+        return of(t, vec_->v2s0(FMHIP_OP_SUB, *vecOf(rv)), n_);
+    }
+    RV bus(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->sub(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, -value_ + rv->doubleValue());
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_SUB_S, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_BUS_S, rv->doubleValue()), n_);
+        return of(t, vecOf(rv)->v2s0(FMHIP_OP_SUB, *vec_), n_);                   // flipped arguments, :1458
+    }
+    RV mult(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->mult(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, value_ * rv->doubleValue());
+        if (rv->isDeterministic()) return mult(rv->doubleValue());
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_MULT_S, value_), rv->size());
+        return of(t, vec_->v2s0(FMHIP_OP_MULT, *vecOf(rv)), n_);
+    }
+    RV div(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->vid(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, value_ / rv->doubleValue());
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_VID_S, value_), rv->size());
+        if (rv->isDeterministic()) return div(rv->doubleValue());
+        return of(t, vec_->v2s0(FMHIP_OP_DIV, *vecOf(rv)), n_);
+    }
+    RV vid(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->div(self());             // twin:1116-1119
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, rv->doubleValue() / value_);
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_DIV_S, value_), rv->size());
+        if (rv->isDeterministic()) return vid(rv->doubleValue());
+        return of(t, vecOf(rv)->v2s0(FMHIP_OP_DIV, *vec_), n_);                   // flipped arguments, :1531
+    }
+    RV cap(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->cap(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, jmin(value_, rv->doubleValue()));
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_CAP_S, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_CAP_S, rv->doubleValue()), n_);
+        return of(t, vec_->v2s0(FMHIP_OP_CAP, *vecOf(rv)), n_);
+    }
+    RV floor(const RV& rv) const override {
+        if (rv->getTypePriority() > priority_) return rv->floor(self());
+        const double t = std::max(time_, rv->getFiltrationTime());
+        if (isDeterministic() && rv->isDeterministic()) return of(t, jmax(value_, rv->doubleValue()));
+        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_FLOOR_S, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_FLOOR_S, rv->doubleValue()), n_);
+        return of(t, vec_->v2s0(FMHIP_OP_FLOOR, *vecOf(rv)), n_);
+    }
+    RV accrue(const RV& rate, double p) const override {                            // :1583-1601
+        if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->mult(self());
+        const double t = std::max(time_, rate->getFiltrationTime());
+        if (rate->isDeterministic()) return mult(1.0 + rate->doubleValue() * p);
+        if (isDeterministic()) return rate->mult(p)->add(1.0)->mult(value_);
+        return of(t, vec_->v2s1(FMHIP_OP_ACCRUE, *vecOf(rate), p), n_);
+    }
+    RV discount(const RV& rate, double p) const override {                          // :1604-1624
+        if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->invert()->mult(self());
+        const double t = std::max(time_, rate->getFiltrationTime());
+        if (rate->isDeterministic()) return div(1.0 + rate->doubleValue() * p);
+        if (isDeterministic()) { if (value_ == 0) return self(); return rate->mult(p)->add(1.0)->vid(value_); }
+        return of(t, vec_->v2s1(FMHIP_OP_DISCOUNT, *vecOf(rate), p), n_);
+    }
+    RV choose(const RV& a, const RV& b) const override {                            // twin:1264-1285
+        const double t = std::max(std::max(time_, a->getFiltrationTime()), b->getFiltrationTime());
+        if (isDeterministic()) return value_ >= 0 ? a : b;
+        const DeviceVector::Ptr va = a->isDeterministic() ? DeviceVector::filled(n_, a->doubleValue()) : vecOf(a);
+        const DeviceVector::Ptr vb = b->isDeterministic() ? DeviceVector::filled(n_, b->doubleValue()) : vecOf(b);
+        return of(t, vec_->v3s0(FMHIP_OP_CHOOSE, *va, *vb), n_);
+    }
+    RV addProduct(const RV& f1, double f2) const override {                         // :1638-1656
+        if (f1->getTypePriority() > priority_) return f1->mult(f2)->add(self());
+        const double t = std::max(time_, f1->getFiltrationTime());
+        if (f1->isDeterministic()) return add(f1->doubleValue() * f2);
+        if (!isDeterministic()) return of(t, vec_->v2s1(FMHIP_OP_ADDPRODUCT_VS, *vecOf(f1), f2), n_);
+        return add(f1->mult(f2));
+    }
+    RV addProduct(const RV& f1, const RV& f2) const override {                      // :1658-1683
+        if (f1->getTypePriority() > priority_ || f2->getTypePriority() > priority_) return f1->mult(f2)->add(self());
+        const double t = std::max(std::max(time_, f1->getFiltrationTime()), f2->getFiltrationTime());
+        if (isDeterministic() && f1->isDeterministic() && f2->isDeterministic()) return of(t, value_ + f1->doubleValue() * f2->doubleValue());
+        if (f1->isDeterministic() && f2->isDeterministic()) return add(f1->doubleValue() * f2->doubleValue());
+        if (f2->isDeterministic()) return addProduct(f1, f2->doubleValue());
+        if (f1->isDeterministic()) return addProduct(f2, f1->doubleValue());
+        if (!isDeterministic()) return of(t, vec_->v3s0(FMHIP_OP_ADDPRODUCT, *vecOf(f1), *vecOf(f2)), n_);
+        return add(f1->mult(f2));
+    }
+
+private:
+    // getRandomVariableCuda(rv).realizations (:759-766): foreign types are uploaded through getRealizations()
+    static DeviceVector::Ptr vecOf(const RV& rv) {
+        if (auto h = dynamic_cast<const RandomVariableHip*>(rv.get())) return h->vec_;
+        return DeviceVector::fromHost(rv->getRealizations());
+    }
+    RV scalar(int op, double s, double detResult) const {
+        if (isDeterministic()) return of(time_, detResult);
+        return of(time_, vec_->v1s1(op, s), n_);
+    }
+    RV unary(int op, double detResult) const {
+        if (isDeterministic()) return of(time_, detResult);
+        return of(time_, vec_->v1s0(op), n_);
+    }
+    double time_;
+    double value_;
+    DeviceVector::Ptr vec_;
+    int64_t n_;
+    int priority_;
+};
+
+inline RV RandomVariable::average() const { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), getAverage()); }
+
+class RandomVariableHipFactory final : public RandomVariableFactory {      // RandomVariableCudaFactory.java:27-34
+public:
+    RV createRandomVariable(double value) const override { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), value); }
+    RV createRandomVariable(double time, double value) const override { return RandomVariableHip::of(time, value); }
+    RV createRandomVariable(double time, const std::vector<double>& values) const override { return std::make_shared<RandomVariableHip>(time, values); }
+};
+
+// ------------------------------------------------------------------ BrownianMotionHip
+// BrownianMotionCudaWithRandomVariableCuda.java:78-259: increments N(0, dt) with filtration time t_{i+1}, generated
+// eagerly on first access (:123-130) — here by ONE launch for all (step, factor) vectors (fmhip_bm_generate).
+class BrownianMotionHip final : public BrownianMotion {
+public:
+    BrownianMotionHip(TimeDiscretization td, int numberOfFactors, int64_t numberOfPaths, int64_t seed, int64_t pathOffset = 0)
+        : td_(std::move(td)), factors_(numberOfFactors), paths_(numberOfPaths), seed_(seed), offset_(pathOffset) {}
+    RV getBrownianIncrement(int timeIndex, int factor) const override {
+        if (inc_.empty()) generate();
+        return inc_.at((size_t)timeIndex * factors_ + factor);
+    }
+    const TimeDiscretization& getTimeDiscretization() const override { return td_; }
+    int getNumberOfFactors() const override { return factors_; }
+    int64_t getNumberOfPaths() const override { return paths_; }
+    int64_t getSeed() const { return seed_; }
+    RV getRandomVariableForConstant(double value) const override { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), value); }
+private:
+    void generate() const {
+        const int steps = td_.getNumberOfTimeSteps();
+        std::vector<double> dt((size_t)steps);
+        for (int i = 0; i < steps; ++i) dt[(size_t)i] = td_.getTimeStep(i);
+        std::vector<fmhip_vec> h((size_t)steps * factors_);
+        check(fmhip_bm_generate(seed_, steps, factors_, paths_, offset_, dt.data(), h.data()));
+        inc_.reserve(h.size());
+        for (int i = 0; i < steps; ++i)
+            for (int f = 0; f < factors_; ++f)
+                inc_.push_back(RandomVariableHip::of(td_.getTime(i + 1), std::make_shared<DeviceVector>(h[(size_t)i * factors_ + f]), paths_));
+    }
+    TimeDiscretization td_;
+    int factors_;
+    int64_t paths_, seed_, offset_;
+    mutable std::vector<RV> inc_;
+};
+
+} // namespace fmhost

@@ -204,3 +204,40 @@ def test_device_moments_output(gpu, oracle):
     raw = buf.to_float32().view(np.float64)
     m = v.moments()
     assert raw[0] == m.sum and raw[1] == m.sumsq and raw[2] == m.min and raw[3] == m.max
+
+
+def test_flush_fuses_overlapping_results_into_one_multi_output_launch(gpu, oracle):
+    """Several results that share intermediates (a running sum feeding many updates — the LMM drift pattern) run as
+    ONE launch with several outputs; identical components over different vectors are batched as rows."""
+    n, K, G = 6007, 6, 5                       # K updates sharing a prefix sum, G independent groups
+    f = gpu.RandomVariableHipFactory()
+    of = oracle.RandomVariableFloatFactory()
+    data = [[oracle.java_random_doubles(900 + 10 * g + k, n) for k in range(K)] for g in range(G)]
+    dw = oracle.java_random_doubles(77, n) - 0.5
+
+    def step(fac, Ls, dW, lam):
+        s = None
+        out = []
+        for k, L in enumerate(Ls):
+            y = L.mult(0.5).add(1.0).vid(0.5 * lam[k])             # λδ / (1 + δ L)
+            s = y if s is None else s.add(y)                       # running sum (shared by all later components)
+            out.append(L.addProduct(s, lam[k] * 0.5).addProduct(dW, lam[k]))
+        return out, s
+
+    gpu.set_fusion(True)
+    try:
+        groups = [[f.createRandomVariable(0.0, d) for d in row] for row in data]
+        dWg = f.createRandomVariable(0.0, dw)
+        before = gpu.pool_stats().n_kernel_launches
+        res = [step(f, Ls, dWg, [0.01 * (k + 1) + 0.001 * g for k in range(K)]) for g, Ls in enumerate(groups)]
+        gpu.flush()
+        assert gpu.pool_stats().n_kernel_launches - before == 1          # 5 rows × (6 updates + carry) in one launch
+        got = [([r.getRealizations() for r in outs], s.getRealizations()) for outs, s in res]
+    finally:
+        gpu.set_fusion(False)
+    dWo = of.createRandomVariable(0.0, dw)
+    for g in range(G):
+        outs, s = step(of, [of.createRandomVariable(0.0, d) for d in data[g]], dWo, [0.01 * (k + 1) + 0.001 * g for k in range(K)])
+        for k in range(K):
+            assert (got[g][0][k] == outs[k].getRealizations()).all(), (g, k)
+        assert (got[g][1] == s.getRealizations()).all()
