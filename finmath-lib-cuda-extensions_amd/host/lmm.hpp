@@ -1,0 +1,319 @@
+// lmm.hpp — native LIBOR-Market-Model Monte-Carlo calibration driver (BASELINE.json configs[3..4]).
+//
+// The reference runs this workload through finmath-lib (external jar, NOT vendored): LIBORMarketModelCalibrationATMTest
+// builds a 1-factor LMM on a 0…40y / 0.5y grid (80 forward rates), piecewise-constant volatility on an 8×8
+// (simulation time × time to maturity) grid, exponential-decay correlation reduced to ONE factor, spot measure, normal
+// state space, Euler scheme; calibrates the volatility parameters to ATM normal swaption volatilities with
+// Levenberg–Marquardt and finite differences, every objective evaluation re-simulating the model and valuing each
+// SwaptionSimple by Monte-Carlo → getAverage() (LIBORMarketModelCalibrationATMTest.java:151-470).
+//
+// What is restated here and what pins it:
+//   - inputs: swaption grid and normal vols (:188-236), swap curve (:527-532), grids (:272-278), vol/corr model
+//     (:287-288), measure/state space (:307-311), LM settings (:314-340), acceptance |mean deviation| < 2e-4 (:466);
+//   - model algebra: textbook LMM (spot-measure drift via running factor sums, Euler step in the normal state space,
+//     rolled-over numeraire, SwaptionSimple backward induction, Bachelier ATM inversion).  finmath-lib's exact op order,
+//     day-count/schedule conventions and its optimizer's step rules are [unverified: not under /root/reference];
+//     idealised year fractions are used.  The op STREAM (which RandomVariable methods run on which vectors) has the
+//     same shape, which is what the engine is measured on.
+// The driver only uses the fmhost interfaces, so the same code runs on RandomVariableHip and on the CPU twin.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "random_variable.hpp"
+
+namespace fmhost { namespace lmm {
+
+// ------------------------------------------------------------------ market data (LIBORMarketModelCalibrationATMTest.java)
+
+inline const std::vector<double>& atmNormalVolatilities() {           // :217-236, 14 expiries × 14 tenors
+    static const std::vector<double> v = {
+        0.00151, 0.00169, 0.0021, 0.00248, 0.00291, 0.00329, 0.00365, 0.004, 0.00437, 0.00466, 0.00527, 0.00571,
+        0.00604, 0.00625, 0.0016, 0.00174, 0.00217, 0.00264, 0.00314, 0.00355, 0.00398, 0.00433, 0.00469,
+        0.00493, 0.00569, 0.00607, 0.00627, 0.00645, 0.00182, 0.00204, 0.00238, 0.00286, 0.00339, 0.00384,
+        0.00424, 0.00456, 0.00488, 0.0052, 0.0059, 0.00623, 0.0064, 0.00654, 0.00205, 0.00235, 0.00272, 0.0032,
+        0.00368, 0.00406, 0.00447, 0.00484, 0.00515, 0.00544, 0.00602, 0.00629, 0.0064, 0.00646, 0.00279,
+        0.00319, 0.0036, 0.00396, 0.00436, 0.00469, 0.00503, 0.0053, 0.00557, 0.00582, 0.00616, 0.00628,
+        0.00638, 0.00641, 0.00379, 0.00406, 0.00439, 0.00472, 0.00504, 0.00532, 0.0056, 0.00582, 0.00602,
+        0.00617, 0.0063, 0.00636, 0.00638, 0.00639, 0.00471, 0.00489, 0.00511, 0.00539, 0.00563, 0.00583, 0.006,
+        0.00618, 0.0063, 0.00644, 0.00641, 0.00638, 0.00635, 0.00634, 0.00544, 0.00557, 0.00572, 0.00591,
+        0.00604, 0.00617, 0.0063, 0.00641, 0.00651, 0.00661, 0.00645, 0.00634, 0.00627, 0.00624, 0.00625,
+        0.00632, 0.00638, 0.00644, 0.0065, 0.00655, 0.00661, 0.00667, 0.00672, 0.00673, 0.00634, 0.00614,
+        0.00599, 0.00593, 0.00664, 0.00671, 0.00675, 0.00676, 0.00676, 0.00675, 0.00676, 0.00674, 0.00672,
+        0.00669, 0.00616, 0.00586, 0.00569, 0.00558, 0.00647, 0.00651, 0.00651, 0.00651, 0.00652, 0.00649,
+        0.00645, 0.0064, 0.00637, 0.00631, 0.00576, 0.00534, 0.00512, 0.00495, 0.00615, 0.0062, 0.00618,
+        0.00613, 0.0061, 0.00607, 0.00602, 0.00596, 0.00591, 0.00586, 0.00536, 0.00491, 0.00469, 0.0045,
+        0.00578, 0.00583, 0.00579, 0.00574, 0.00567, 0.00562, 0.00556, 0.00549, 0.00545, 0.00538, 0.00493,
+        0.00453, 0.00435, 0.0042, 0.00542, 0.00547, 0.00539, 0.00532, 0.00522, 0.00516, 0.0051, 0.00504, 0.005,
+        0.00495, 0.00454, 0.00418, 0.00404, 0.00394 };
+    return v;
+}
+inline const std::vector<double>& atmExpiryYears() { static const std::vector<double> v = { 1.0 / 12, 0.25, 0.5, 1, 2, 3, 4, 5, 7, 10, 15, 20, 25, 30 }; return v; }
+inline const std::vector<double>& atmTenorYears()  { static const std::vector<double> v = { 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20, 25, 30 }; return v; }
+
+// Discount curve: log-linear interpolation of discount factors, constant extrapolation (:609-618), bootstrapped from the
+// par swap rates of :527-532 (annual fixed leg against the single curve; idealised year fractions).
+struct DiscountCurve {
+    std::vector<double> t{ 0.0 }, logdf{ 0.0 };
+    double df(double time) const {
+        if (time <= 0.0) return 1.0;
+        if (time >= t.back()) return std::exp(logdf.back());
+        const size_t k = (size_t)(std::upper_bound(t.begin(), t.end(), time) - t.begin());
+        const double w = (time - t[k - 1]) / (t[k] - t[k - 1]);
+        return std::exp(logdf[k - 1] + w * (logdf[k] - logdf[k - 1]));
+    }
+    double forward(double fixing, double period) const { return (df(fixing) / df(fixing + period) - 1.0) / period; }
+    static DiscountCurve bootstrap() {
+        const double maturities[] = { 0.5, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 20, 25, 30, 35, 40, 45, 50 };
+        const double rates[] = { -0.00216, -0.00208, -0.00222, -0.00216, -0.0019, -0.0014, -0.00072, 0.00011, 0.00103, 0.00196, 0.00285,
+                                 0.00367, 0.0044, 0.00604, 0.00733, 0.00767, 0.00773, 0.00765, 0.00752, 0.007138, 0.007 };
+        DiscountCurve c;
+        for (int i = 0; i < 21; ++i) {
+            const double M = maturities[i], r = rates[i];
+            c.t.push_back(M); c.logdf.push_back(c.logdf.back());
+            auto swapValue = [&](double ld) {                       // receiver-float par swap: 1 - DF(M) - r·annuity
+                c.logdf.back() = ld;
+                double annuity = 0.0;
+                if (M < 1.0) annuity = M * c.df(M);
+                else for (double tp = 1.0; tp <= M + 1e-9; tp += 1.0) annuity += c.df(tp);
+                return 1.0 - c.df(M) - r * annuity;
+            };
+            double lo = -3.0, hi = 1.0;                              // value is decreasing in log DF(M)
+            for (int it = 0; it < 200; ++it) { const double mid = 0.5 * (lo + hi); if (swapValue(mid) > 0) lo = mid; else hi = mid; }
+            c.logdf.back() = 0.5 * (lo + hi);
+        }
+        return c;
+    }
+};
+
+struct Swaption {                       // createCalibrationItem (:475-520): ATM, VOLATILITYNORMAL, SwaptionSimple
+    double exercise = 0; int numberOfPeriods = 0; double swapPeriodLength = 0.5;
+    std::vector<double> swapTenor; double swaprate = 0, targetVolatility = 0, annuity = 0;
+};
+
+struct Market {
+    DiscountCurve curve = DiscountCurve::bootstrap();
+    double lastTime = 40.0, dt = 0.5;                                // :275-277
+    TimeDiscretization timeDiscretization{ 0.0, 80, 0.5 };           // simulation grid = LIBOR period grid (:278)
+    std::vector<Swaption> swaptions;
+    Market() {
+        const auto& vols = atmNormalVolatilities();
+        for (size_t e = 0; e < atmExpiryYears().size(); ++e)
+            for (size_t k = 0; k < atmTenorYears().size(); ++k) {
+                const double exercise = std::round(atmExpiryYears()[e] / 0.25) * 0.25, tenor = atmTenorYears()[k];
+                if (exercise < 1.0) continue;                        // :252-254
+                // a swap reaching beyond the 40y LIBOR grid cannot be valued; finmath's calibration silently drops such
+                // products (the exception is swallowed) — they are excluded explicitly here
+                if (exercise + tenor > lastTime + 1e-9) continue;
+                Swaption s;
+                s.exercise = exercise; s.numberOfPeriods = (int)std::lround(tenor / 0.5);
+                for (int p = 0; p <= s.numberOfPeriods; ++p) s.swapTenor.push_back(exercise + p * 0.5);
+                double floating = 0.0, annuity = 0.0;                // Swap.getForwardSwapRate (:665-667)
+                for (int p = 0; p < s.numberOfPeriods; ++p) {
+                    const double d = curve.df(s.swapTenor[p + 1]);
+                    floating += curve.forward(s.swapTenor[p], 0.5) * 0.5 * d; annuity += 0.5 * d;
+                }
+                s.swaprate = floating / annuity; s.annuity = annuity;
+                s.targetVolatility = vols[e * atmTenorYears().size() + k];
+                swaptions.push_back(std::move(s));
+            }
+    }
+    int numberOfLibors() const { return timeDiscretization.getNumberOfTimeSteps(); }
+};
+
+// LIBORVolatilityModelPiecewiseConstant on the grid {0,1,2,5,10,20,30,40}² with initial value 0.5 % (:287)
+struct VolatilityModel {
+    std::vector<double> grid{ 0.0, 1.0, 2.0, 5.0, 10.0, 20.0, 30.0, 40.0 };
+    std::vector<double> parameter = std::vector<double>(64, 0.50 / 100);
+    int bin(double x) const { int k = 0; while (k < 7 && grid[(size_t)k] < x - 1e-12) ++k; return k; }
+    int parameterIndex(double time, double maturity) const { return bin(time) * 8 + bin(maturity - time); }
+    double volatility(double time, double maturity) const { return maturity <= time + 1e-12 ? 0.0 : parameter[(size_t)parameterIndex(time, maturity)]; }
+    // parameters that some (simulation time, LIBOR) pair actually reads
+    std::vector<int> activeParameters(const Market& m) const {
+        std::vector<char> used(64, 0);
+        const auto& td = m.timeDiscretization;
+        for (int i = 0; i < td.getNumberOfTimeSteps(); ++i)
+            for (int j = i + 1; j < m.numberOfLibors(); ++j) used[(size_t)parameterIndex(td.getTime(i), td.getTime(j))] = 1;
+        std::vector<int> idx;
+        for (int k = 0; k < 64; ++k) if (used[(size_t)k]) idx.push_back(k);
+        return idx;
+    }
+};
+
+// ------------------------------------------------------------------ simulation (Euler, spot measure, normal state space)
+
+struct Simulation {
+    std::vector<std::vector<RV>> libor;     // [time index][component]
+    std::vector<RV> numeraire;              // [time index]
+};
+
+struct Backend {
+    const RandomVariableFactory* factory = nullptr;
+    const BrownianMotion* brownianMotion = nullptr;
+    std::function<void()> flush = [] {};    // executes pending (lazily fused) work; no-op on an eager back end
+    int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum)
+};
+
+inline Simulation simulate(const Market& m, const VolatilityModel& vol, const Backend& be, int lastTimeIndex) {
+    const auto& td = m.timeDiscretization;
+    const int n = m.numberOfLibors();
+    const double delta = m.dt;
+    Simulation sim;
+    sim.libor.resize((size_t)lastTimeIndex + 1);
+    sim.numeraire.resize((size_t)lastTimeIndex + 1);
+    sim.libor[0].resize((size_t)n);
+    for (int j = 0; j < n; ++j) sim.libor[0][(size_t)j] = be.factory->createRandomVariable(0.0, m.curve.forward(td.getTime(j), delta));
+    sim.numeraire[0] = be.factory->createRandomVariable(0.0, 1.0);
+    for (int i = 0; i < lastTimeIndex; ++i) {
+        const double t = td.getTime(i), dt = td.getTimeStep(i);
+        const RV dW = be.brownianMotion->getBrownianIncrement(i, 0);
+        auto& cur = sim.libor[(size_t)i];
+        auto& nxt = sim.libor[(size_t)i + 1];
+        nxt.resize((size_t)n);
+        for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = cur[(size_t)j];           // fixed LIBORs
+        RV factorSum;                                                                    // Σ_k λ_k δ/(1+δ L_k): running over components
+        int inChunk = 0;
+        for (int j = i + 1; j < n; ++j) {
+            const double lambda = vol.volatility(t, td.getTime(j));                      // one factor: loading = volatility
+            const RV& L = cur[(size_t)j];
+            const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
+            factorSum = factorSum ? factorSum->add(transform) : transform;
+            const RV drift = factorSum->mult(lambda);
+            nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);           // Euler step, normal state space
+            if (++inChunk == be.chunk) { be.flush(); inChunk = 0; }
+        }
+        sim.numeraire[(size_t)i + 1] = sim.numeraire[(size_t)i]->accrue(cur[(size_t)i], delta);   // rolled-over bank account
+        be.flush();
+    }
+    return sim;
+}
+
+// SwaptionSimple with ValueUnit VOLATILITYNORMAL: backward induction of the swap value at exercise, payoff floored at 0,
+// numeraire-relative, Monte-Carlo average, Bachelier inversion (ATM: closed form).
+inline RV swaptionValue(const Market& m, const Simulation& sim, const Swaption& s) {
+    const auto& td = m.timeDiscretization;
+    const int exerciseIndex = td.getTimeIndex(s.exercise);
+    RV value;
+    for (int p = s.numberOfPeriods - 1; p >= 0; --p) {
+        const int j = td.getTimeIndex(s.swapTenor[(size_t)p]);
+        const RV& libor = sim.libor[(size_t)exerciseIndex][(size_t)j];
+        const RV payoff = libor->sub(s.swaprate)->mult(s.swapPeriodLength);
+        value = (value ? value->add(payoff) : payoff)->discount(libor, s.swapPeriodLength);
+    }
+    return value->floor(0.0)->div(sim.numeraire[(size_t)exerciseIndex]);
+}
+inline double bachelierAtmImpliedVolatility(double optionValue, double optionMaturity, double annuity) {
+    return optionValue * std::sqrt(2.0 * 3.14159265358979323846) / (annuity * std::sqrt(optionMaturity));
+}
+
+struct Valuation { std::vector<double> modelVolatility; double seconds_simulation = 0, seconds_valuation = 0; };
+
+inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Backend& be) {
+    using clk = std::chrono::steady_clock;
+    Valuation out;
+    int lastIndex = 0;
+    for (const Swaption& s : m.swaptions) lastIndex = std::max(lastIndex, m.timeDiscretization.getTimeIndex(s.exercise));
+    const auto t0 = clk::now();
+    const Simulation sim = simulate(m, vol, be, lastIndex);
+    const auto t1 = clk::now();
+    std::vector<RV> values;
+    values.reserve(m.swaptions.size());
+    for (const Swaption& s : m.swaptions) { values.push_back(swaptionValue(m, sim, s)); }
+    be.flush();
+    for (size_t k = 0; k < m.swaptions.size(); ++k)
+        out.modelVolatility.push_back(bachelierAtmImpliedVolatility(values[k]->getAverage(), m.swaptions[k].exercise, m.swaptions[k].annuity));
+    const auto t2 = clk::now();
+    out.seconds_simulation = std::chrono::duration<double>(t1 - t0).count();
+    out.seconds_valuation = std::chrono::duration<double>(t2 - t1).count();
+    return out;
+}
+
+// ------------------------------------------------------------------ Levenberg–Marquardt with finite differences (:314-340)
+
+struct CalibrationResult {
+    VolatilityModel model; int iterations = 0, evaluations = 0;
+    double meanDeviation = 0, rmsDeviation = 0, initialRms = 0, seconds = 0, seconds_simulation = 0, seconds_valuation = 0;
+    std::vector<double> modelVolatility;
+};
+
+inline bool solveSymmetric(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {   // Gaussian elimination, partial pivoting
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(A[(size_t)r * n + c]) > std::fabs(A[(size_t)piv * n + c])) piv = r;
+        if (std::fabs(A[(size_t)piv * n + c]) < 1e-300) return false;
+        if (piv != c) { for (int k = 0; k < n; ++k) std::swap(A[(size_t)c * n + k], A[(size_t)piv * n + k]); std::swap(b[(size_t)c], b[(size_t)piv]); }
+        for (int r = c + 1; r < n; ++r) {
+            const double f = A[(size_t)r * n + c] / A[(size_t)c * n + c];
+            for (int k = c; k < n; ++k) A[(size_t)r * n + k] -= f * A[(size_t)c * n + k];
+            b[(size_t)r] -= f * b[(size_t)c];
+        }
+    }
+    x.assign((size_t)n, 0.0);
+    for (int r = n - 1; r >= 0; --r) { double s = b[(size_t)r]; for (int k = r + 1; k < n; ++k) s -= A[(size_t)r * n + k] * x[(size_t)k]; x[(size_t)r] = s / A[(size_t)r * n + r]; }
+    return true;
+}
+
+inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIterations = 200, double accuracy = 1e-7,
+                                   double lambda = 0.1, double parameterStep = 1e-4, bool verbose = false) {
+    using clk = std::chrono::steady_clock;
+    const auto start = clk::now();
+    CalibrationResult res;
+    VolatilityModel vol;
+    const std::vector<int> active = vol.activeParameters(m);
+    const int np = (int)active.size(), nr = (int)m.swaptions.size();
+    auto residuals = [&](const VolatilityModel& v, std::vector<double>& r, std::vector<double>* modelVols) {
+        const Valuation val = evaluate(m, v, be);
+        res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
+        r.resize((size_t)nr);
+        for (int k = 0; k < nr; ++k) r[(size_t)k] = val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility;
+        if (modelVols) *modelVols = val.modelVolatility;
+    };
+    auto sumsq = [](const std::vector<double>& r) { double s = 0; for (double x : r) s += x * x; return s; };
+    std::vector<double> r, rTrial, modelVols;
+    residuals(vol, r, &modelVols);
+    double err = sumsq(r);
+    res.initialRms = std::sqrt(err / nr);
+    for (int it = 0; it < maxIterations; ++it) {
+        // Jacobian by forward differences: one re-simulation per active parameter (common random numbers)
+        std::vector<double> J((size_t)nr * np);
+        for (int a = 0; a < np; ++a) {
+            VolatilityModel v = vol;
+            v.parameter[(size_t)active[(size_t)a]] += parameterStep;
+            residuals(v, rTrial, nullptr);
+            for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (rTrial[(size_t)k] - r[(size_t)k]) / parameterStep;
+        }
+        std::vector<double> JtJ((size_t)np * np, 0.0), Jtr((size_t)np, 0.0);
+        for (int a = 0; a < np; ++a) {
+            for (int b = 0; b < np; ++b) { double s = 0; for (int k = 0; k < nr; ++k) s += J[(size_t)k * np + a] * J[(size_t)k * np + b]; JtJ[(size_t)a * np + b] = s; }
+            double s = 0; for (int k = 0; k < nr; ++k) s += J[(size_t)k * np + a] * r[(size_t)k]; Jtr[(size_t)a] = -s;
+        }
+        bool improved = false;
+        for (int attempt = 0; attempt < 8 && !improved; ++attempt) {
+            std::vector<double> A = JtJ, step;
+            for (int a = 0; a < np; ++a) A[(size_t)a * np + a] += lambda * std::max(JtJ[(size_t)a * np + a], 1e-12);   // Levenberg regularisation
+            if (!solveSymmetric(A, Jtr, np, step)) { lambda *= 4; continue; }
+            VolatilityModel v = vol;
+            for (int a = 0; a < np; ++a) v.parameter[(size_t)active[(size_t)a]] += step[(size_t)a];
+            std::vector<double> mv;
+            residuals(v, rTrial, &mv);
+            const double e = sumsq(rTrial);
+            if (e < err) { improved = true; const double rel = (err - e) / err; vol = v; r = rTrial; err = e; modelVols = mv; lambda = std::max(lambda / 3.0, 1e-9); if (rel < accuracy) it = maxIterations; }
+            else lambda *= 4.0;
+        }
+        res.iterations++;
+        if (verbose) std::fprintf(stderr, "  LM iteration %d: rms %.6e  lambda %.3g  evaluations %d\n", res.iterations, std::sqrt(err / nr), lambda, res.evaluations);
+        if (!improved || std::sqrt(err / nr) < accuracy) break;
+    }
+    res.model = vol; res.modelVolatility = modelVols;
+    double sum = 0; for (double x : r) sum += x;
+    res.meanDeviation = sum / nr; res.rmsDeviation = std::sqrt(err / nr);
+    res.seconds = std::chrono::duration<double>(clk::now() - start).count();
+    return res;
+}
+
+}} // namespace fmhost::lmm

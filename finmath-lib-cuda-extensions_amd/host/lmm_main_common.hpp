@@ -1,0 +1,58 @@
+// lmm_main_common.hpp — command line + JSON report shared by the two LMM driver executables
+// (lmm_hip: product, links libfmhip.so only;  oracle/host/lmm_cpu: CPU twin, test infrastructure / cpu_baseline).
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include "lmm.hpp"
+
+namespace fmhost { namespace lmm {
+
+struct Options {
+    int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
+    int64_t pathOffset = 0; int evaluations = 1;
+};
+inline Options parseOptions(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--paths") o.paths = std::atoll(next());
+        else if (a == "--seed") o.seed = std::atoll(next());
+        else if (a == "--max-iterations") o.maxIterations = std::atoi(next());
+        else if (a == "--mode") o.mode = next();                  // calibrate | evaluate
+        else if (a == "--evaluations") o.evaluations = std::atoi(next());
+        else if (a == "--path-offset") o.pathOffset = std::atoll(next());
+        else if (a == "--verbose") o.verbose = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); std::exit(2); }
+    }
+    return o;
+}
+
+// mode evaluate: one objective evaluation (simulate + value all swaptions) with the initial parameters, repeated
+// `evaluations` times; prints every model volatility with 17 digits so that two back ends can be compared exactly.
+inline void runAndReport(const Options& o, const Backend& be, const char* backendName, const std::function<std::string()>& extraJson) {
+    Market m;
+    if (o.mode == "evaluate") {
+        VolatilityModel vol;
+        Valuation v;
+        double sim = 0, val = 0;
+        for (int k = 0; k < o.evaluations; ++k) { v = evaluate(m, vol, be); sim += v.seconds_simulation; val += v.seconds_valuation; }
+        std::printf("{\"backend\": \"%s\", \"mode\": \"evaluate\", \"paths\": %lld, \"swaptions\": %zu, \"evaluations\": %d, "
+                    "\"seconds_simulation_per_evaluation\": %.6f, \"seconds_valuation_per_evaluation\": %.6f%s, \"model_volatility\": [",
+                    backendName, (long long)o.paths, m.swaptions.size(), o.evaluations, sim / o.evaluations, val / o.evaluations, extraJson().c_str());
+        for (size_t k = 0; k < v.modelVolatility.size(); ++k) std::printf("%s%.17g", k ? ", " : "", v.modelVolatility[k]);
+        std::printf("]}\n");
+        return;
+    }
+    const CalibrationResult r = calibrate(m, be, o.maxIterations, 1e-7, 0.1, 1e-4, o.verbose);
+    std::printf("{\"backend\": \"%s\", \"mode\": \"calibrate\", \"paths\": %lld, \"swaptions\": %zu, \"active_parameters\": %zu, "
+                "\"iterations\": %d, \"evaluations\": %d, \"seconds\": %.4f, \"seconds_simulation\": %.4f, \"seconds_valuation\": %.4f, "
+                "\"initial_rms\": %.6e, \"rms_deviation\": %.6e, \"mean_deviation\": %.6e%s, \"parameters\": [",
+                backendName, (long long)o.paths, m.swaptions.size(), VolatilityModel().activeParameters(m).size(), r.iterations, r.evaluations,
+                r.seconds, r.seconds_simulation, r.seconds_valuation, r.initialRms, r.rmsDeviation, r.meanDeviation, extraJson().c_str());
+    for (size_t k = 0; k < r.model.parameter.size(); ++k) std::printf("%s%.10g", k ? ", " : "", r.model.parameter[k]);
+    std::printf("]}\n");
+}
+
+}} // namespace fmhost::lmm
