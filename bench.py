@@ -92,8 +92,44 @@ def cpu_baseline(target_seconds=12.0):
                       f"C restatement of RandomVariableFromFloatArray (one loop + one fresh array per op)"}
 
 
+def lmm_workload(args):
+    """BASELINE.json configs[3]: LMM ATM swaption calibration (LIBORMarketModelCalibrationATMTest inputs) at 1 M paths on one
+    MI355X — the native driver host/lmm.hpp over the C-ABI — next to the same driver on the CPU twin (bounded sample:
+    objective evaluations at the same path count; a full CPU calibration would take hours)."""
+    import subprocess
+    lmm_hip = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
+    lmm_cpu = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
+    paths = args.paths
+    t0 = time.perf_counter()
+    out = subprocess.run([lmm_hip, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)],
+                         capture_output=True, text=True, check=True)
+    wall = time.perf_counter() - t0
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    line = {"metric": "LMM calib wall-time, 1M paths", "value": r["seconds"], "unit": "s", "n_gpus": 1, "steps": r["iterations"],
+            "warmup": 0, "ms_per_step": r["seconds"] / max(1, r["iterations"]) * 1e3, "higher_is_better": False, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LIBOR Market Model ATM swaption calibration (80 forward rates, 1 factor, spot measure, normal state space, "
+                                   "144 swaptions, 50 volatility parameters, Levenberg-Marquardt with finite differences)",
+                       "paths": paths, "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
+                       "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
+                       "rms_deviation": r["rms_deviation"], "mean_deviation": r["mean_deviation"],
+                       "acceptance": "abs(mean deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
+                       "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"], "process_wall_s": wall},
+            "roofline": None}
+    if not args.no_cpu_baseline:
+        c = subprocess.run([lmm_cpu, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"], capture_output=True, text=True, check=True)
+        cj = json.loads(c.stdout.strip().splitlines()[-1])
+        per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]
+        line["cpu_baseline"] = {"value": per_eval * r["evaluations"], "unit": "s", "cores": 1, "kind": "port",
+                                "sample": f"1 objective evaluation of the same model at {paths} paths on the CPU twin = {per_eval:.2f} s, "
+                                          f"scaled by the {r['evaluations']} evaluations the calibration needed"}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["stream", "lmm"], default="stream")
+    ap.add_argument("--lmm-iterations", type=int, default=12)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
@@ -101,6 +137,8 @@ def main():
     ap.add_argument("--paths", type=int, default=N_PATHS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "lmm":
+        return lmm_workload(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

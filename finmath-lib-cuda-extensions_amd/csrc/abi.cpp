@@ -115,6 +115,9 @@ int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); }); }
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     return guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr); });
 }
+int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
+    return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine::get().reduce_batch(vectors, count, shifts, out); });
+}
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
 }

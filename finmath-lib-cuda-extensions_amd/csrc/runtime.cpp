@@ -81,7 +81,8 @@ Engine& Engine::get() { static Engine* e = new Engine(); return *e; }
 
 void Engine::require_init() const {
     if (!initialized_) throw Error(FMHIP_ERR_NOT_INITIALIZED, "fmhip_init has not been called");
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    static thread_local int bound_device = -1;          // hipSetDevice is per thread; skip it on the hot path once bound
+    if (bound_device != device_) { hip_check(hipSetDevice(device_), "hipSetDevice"); bound_device = device_; }
 }
 
 void Engine::init(int device_index) {
@@ -122,6 +123,7 @@ void Engine::shutdown() {
         }
     }
     nodes_.clear();
+    pending_.clear();
     for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
     programs_.clear();
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
@@ -218,7 +220,7 @@ void Engine::node_unref_int(Node* nd) { nd->refs_int--; node_maybe_free(nd); }
 void Engine::node_maybe_free(Node* nd) {
     if (nd->refs_ext > 0 || nd->refs_int > 0) return;
     if (nd->buf) buffer_unref(nd->buf);
-    else drop_expression(nd);
+    else { pending_.erase(nd); drop_expression(nd); }
     delete nd;
 }
 
@@ -604,6 +606,7 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     int w = 1;
     for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
     nd->weight = w;
+    pending_.insert(nd);
     if (!fusion || w > FUSION_MAX_WEIGHT) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
@@ -626,24 +629,23 @@ struct Engine::Dag {
 // several outputs of the same launch).  Returns false when it cannot run as one launch.
 bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
     dag.roots = roots;
-    std::unordered_map<Node*, int> id_of;
-    std::unordered_map<Node*, int> in_dag_uses;
-    std::unordered_set<Node*> seen;
+    const uint64_t ep = ++epoch_;                   // nodes with mark == ep have been visited by THIS build
     std::vector<std::pair<Node*, int>> stack;
+    auto visit = [&](Node* nd) { nd->mark = ep; nd->tmp_id = -1; nd->tmp_uses = 0; };
     for (Node* root : roots) {
-        if (seen.count(root)) continue;             // a root that is also an operand of an earlier root
+        if (root->mark == ep) continue;             // a root that is also an operand of an earlier root
+        visit(root);
         stack.push_back({ root, 0 });
-        seen.insert(root);
         while (!stack.empty()) {                    // iterative post-order
             auto& top = stack.back();
             Node* nd = top.first;
             if (top.second < nd->n_in) {
                 Node* c = nd->in[top.second++];
                 if (c->buf) {
-                    if (!seen.count(c)) { seen.insert(c); dag.leaves.push_back(c); }
+                    if (c->mark != ep) { visit(c); dag.leaves.push_back(c); }
                 } else {
-                    in_dag_uses[c]++;
-                    if (!seen.count(c)) { seen.insert(c); stack.push_back({ c, 0 }); }
+                    if (c->mark != ep) { visit(c); stack.push_back({ c, 0 }); }
+                    c->tmp_uses++;
                 }
             } else {
                 dag.order.push_back(nd);
@@ -653,31 +655,31 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
     }
     if ((int)dag.leaves.size() > FM_MAX_IN || (int)dag.order.size() > FM_MAX_OPS) return false;
     const int n_in = (int)dag.leaves.size();
-    for (int k = 0; k < n_in; ++k) id_of[dag.leaves[k]] = k;
-    dag.sig.reserve(dag.order.size() * 12 + 16);
-    dag.sig += "m" + std::to_string(math_mode) + "i" + std::to_string(n_in) + ";";
+    for (int k = 0; k < n_in; ++k) dag.leaves[k]->tmp_id = k;
+    // structural signature: a short byte string (opcode + operand ids per op); scalars and vectors are NOT part of it
+    dag.sig.clear();
+    dag.sig.reserve(dag.order.size() * 4 + 16);
+    dag.sig.push_back((char)('0' + math_mode)); dag.sig.push_back((char)n_in);
     for (size_t i = 0; i < dag.order.size(); ++i) {
         Node* nd = dag.order[i];
-        id_of[nd] = n_in + (int)i;
+        nd->tmp_id = n_in + (int)i;
         SsaOp op{ nd->opcode, -1, -1, -1, nd->scalar };
         int* slots[3] = { &op.a, &op.b, &op.c };
-        for (int k = 0; k < nd->n_in; ++k) *slots[k] = id_of[nd->in[k]];
+        for (int k = 0; k < nd->n_in; ++k) *slots[k] = nd->in[k]->tmp_id;
         dag.ops.push_back(op);
         if (op_info(nd->opcode).scalar) dag.scalars.push_back((float)nd->scalar);
-        dag.sig += std::to_string(nd->opcode) + "," + std::to_string(op.a) + "," + std::to_string(op.b) + "," + std::to_string(op.c) + ";";
+        dag.sig.push_back((char)nd->opcode); dag.sig.push_back((char)(op.a + 1)); dag.sig.push_back((char)(op.b + 1)); dag.sig.push_back((char)(op.c + 1));
     }
     if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
-    // outputs: every root, plus every intermediate somebody else still needs
-    std::unordered_set<Node*> is_out;
-    for (Node* r : roots) if (is_out.insert(r).second) { dag.outs.push_back(r); dag.out_ids.push_back(id_of[r]); }
+    // outputs: every root, plus every intermediate somebody else still needs (tmp_uses = consumers inside this DAG)
+    for (Node* r : roots) if (r->tmp_uses >= 0) { dag.outs.push_back(r); dag.out_ids.push_back(r->tmp_id); r->tmp_uses = -1 - r->tmp_uses; }
     for (Node* nd : dag.order) {
-        if (is_out.count(nd)) continue;
-        const int inside = in_dag_uses.count(nd) ? in_dag_uses[nd] : 0;
-        if (nd->refs_ext > 0 || nd->refs_int > inside) { is_out.insert(nd); dag.outs.push_back(nd); dag.out_ids.push_back(id_of[nd]); }
+        if (nd->tmp_uses < 0) continue;             // already an output (root)
+        if (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) { dag.outs.push_back(nd); dag.out_ids.push_back(nd->tmp_id); }
     }
     if ((int)dag.outs.size() > FM_MAX_OUT) return false;
-    dag.sig += "o";
-    for (int v : dag.out_ids) dag.sig += std::to_string(v) + ",";
+    dag.sig.push_back((char)0xff);
+    for (int v : dag.out_ids) dag.sig.push_back((char)(v + 1));
     return true;
 }
 
@@ -713,7 +715,7 @@ bool Engine::run_dags(std::vector<Dag>& dags) {
     }
     // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t i = 0; i < dags.size(); ++i)
-        for (size_t k = 0; k < dags[i].outs.size(); ++k) dags[i].outs[k]->buf = out_bufs[i][k];
+        for (size_t k = 0; k < dags[i].outs.size(); ++k) { dags[i].outs[k]->buf = out_bufs[i][k]; pending_.erase(dags[i].outs[k]); }
     for (size_t i = 0; i < dags.size(); ++i)
         for (size_t k = 0; k < dags[i].outs.size(); ++k) {
             Node* nd = dags[i].outs[k];
@@ -752,11 +754,12 @@ void Engine::flush_all() {
     require_init();
     for (int round = 0; round < 1000000; ++round) {
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
-        for (auto& kv : nodes_) if (!kv.second->buf && kv.second->refs_int == 0) roots.push_back(kv.second);
+        for (Node* nd : pending_) if (nd->refs_int == 0 && nd->refs_ext > 0) roots.push_back(nd);
         if (roots.empty()) {
-            bool any = false;
-            for (auto& kv : nodes_) if (!kv.second->buf) { any = true; materialize({ kv.second }); break; }
-            if (!any) return;
+            Node* live = nullptr;
+            for (Node* nd : pending_) if (nd->refs_ext > 0) { live = nd; break; }
+            if (!live) return;
+            materialize({ live });
             continue;
         }
         std::sort(roots.begin(), roots.end(), [](Node* a, Node* b) { return a->id < b->id; });
@@ -764,19 +767,18 @@ void Engine::flush_all() {
         std::vector<int> parent(roots.size());
         for (size_t i = 0; i < roots.size(); ++i) parent[i] = (int)i;
         auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-        std::unordered_map<Node*, int> owner;
+        const uint64_t ep = ++epoch_;
         std::vector<Node*> stack;
         for (size_t i = 0; i < roots.size(); ++i) {
             stack.push_back(roots[i]);
-            owner[roots[i]] = (int)i;
+            roots[i]->mark = ep; roots[i]->tmp_id = (int)i;
             while (!stack.empty()) {
                 Node* nd = stack.back(); stack.pop_back();
                 for (int k = 0; k < nd->n_in; ++k) {
                     Node* c = nd->in[k];
                     if (c->buf) continue;
-                    auto f = owner.find(c);
-                    if (f != owner.end()) { const int a = find((int)i), b = find(f->second); if (a != b) parent[b] = a; }
-                    else { owner[c] = (int)i; stack.push_back(c); }
+                    if (c->mark == ep) { const int a = find((int)i), b = find(c->tmp_id); if (a != b) parent[b] = a; }
+                    else { c->mark = ep; c->tmp_id = (int)i; stack.push_back(c); }
                 }
             }
         }
@@ -794,7 +796,7 @@ void Engine::flush_all() {
         for (int c : comp_order) {
             Dag d;
             if (!build_dag(comps[c], d)) { for (Node* r : comps[c]) leftovers.push_back(r); continue; }
-            const std::string key = d.sig + "#" + std::to_string(d.roots[0]->n);
+            std::string key = d.sig; key.push_back('#'); key += std::to_string(d.roots[0]->n);
             if (!groups.count(key)) group_order.push_back(key);
             groups[key].push_back(std::move(d));
         }
@@ -827,6 +829,35 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     rows[0].scalars = nullptr;
     rows[0].shifts = &shift;
     launch(prog, nd->n, rows, host_out, dev_out);
+}
+
+void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out) {
+    require_init();
+    if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+    std::vector<Node*> nds((size_t)count);
+    for (int i = 0; i < count; ++i) nds[(size_t)i] = node(hs[i]);
+    for (int i = 1; i < count; ++i)
+        if (nds[(size_t)i]->n != nds[0]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "batched reduction over vectors of different size");
+    bool pending = false;
+    for (Node* nd : nds) pending |= !nd->buf;
+    if (pending) flush_all();                                   // one batched flush instead of one launch per vector
+    for (Node* nd : nds) if (!nd->buf) materialize({ nd });
+    static const char* key = "__reduce1";
+    Program* prog;
+    auto it = program_cache_.find(key);
+    if (it != program_cache_.end()) prog = it->second;
+    else { prog = compile({}, 1, {}, { 0 }, nullptr, true); program_cache_[key] = prog; }
+    const int max_rows = 1024;
+    for (int off = 0; off < count; off += max_rows) {
+        const int m = std::min(max_rows, count - off);
+        std::vector<RowSpec> rows((size_t)m);
+        for (int i = 0; i < m; ++i) {
+            rows[(size_t)i].in.push_back(nds[(size_t)(off + i)]->buf->ptr);
+            rows[(size_t)i].scalars = nullptr;
+            rows[(size_t)i].shifts = shifts ? &shifts[off + i] : nullptr;
+        }
+        launch(prog, nds[0]->n, rows, host_out + off, nullptr);
+    }
 }
 
 // ---------------------------------------------------------------- explicit programs

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/fmhip.h"
@@ -63,6 +64,9 @@ struct Node {
     Node*   in[3] = { nullptr, nullptr, nullptr };
     double  scalar = 0.0;
     int     weight = 0;         // upper bound of pending ops below this node (fusion budget)
+    // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
+    uint64_t mark = 0;
+    int     tmp_id = 0, tmp_uses = 0;
 };
 
 // ---------------------------------------------------------------- compiled programs
@@ -108,6 +112,7 @@ public:
 
     // reductions
     void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out);
+    void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out);
 
     // programs
     fmhip_program program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,
@@ -138,9 +143,11 @@ private:
     Pool pool_;
     int64_t next_id_ = 1;
     std::unordered_map<int64_t, Node*> nodes_;
+    std::unordered_set<Node*> pending_;                          // nodes without storage (lazy expressions)
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
     int64_t n_launches_ = 0, n_ops_executed_ = 0;
+    uint64_t epoch_ = 0;
     bool profiling_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events_;
 

@@ -156,6 +156,10 @@ struct Backend {
     const RandomVariableFactory* factory = nullptr;
     const BrownianMotion* brownianMotion = nullptr;
     std::function<void()> flush = [] {};    // executes pending (lazily fused) work; no-op on an eager back end
+    std::function<long long()> launches = [] { return 0LL; };   // kernel launches so far (statistics only)
+    // all Monte-Carlo expectations of one objective evaluation (default: one getAverage() per product)
+    std::function<std::vector<double>(const std::vector<RV>&)> averages = [](const std::vector<RV>& v) {
+        std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum)
 };
 
@@ -180,11 +184,13 @@ inline Simulation simulate(const Market& m, const VolatilityModel& vol, const Ba
         int inChunk = 0;
         for (int j = i + 1; j < n; ++j) {
             const double lambda = vol.volatility(t, td.getTime(j));                      // one factor: loading = volatility
-            const RV& L = cur[(size_t)j];
-            const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
-            factorSum = factorSum ? factorSum->add(transform) : transform;
-            const RV drift = factorSum->mult(lambda);
-            nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);           // Euler step, normal state space
+            {   // temporaries die before the flush: a live handle would make them extra outputs of the fused launch
+                const RV& L = cur[(size_t)j];
+                const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
+                factorSum = factorSum ? factorSum->add(transform) : transform;
+                const RV drift = factorSum->mult(lambda);
+                nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);       // Euler step, normal state space
+            }
             if (++inChunk == be.chunk) { be.flush(); inChunk = 0; }
         }
         sim.numeraire[(size_t)i + 1] = sim.numeraire[(size_t)i]->accrue(cur[(size_t)i], delta);   // rolled-over bank account
@@ -211,7 +217,7 @@ inline double bachelierAtmImpliedVolatility(double optionValue, double optionMat
     return optionValue * std::sqrt(2.0 * 3.14159265358979323846) / (annuity * std::sqrt(optionMaturity));
 }
 
-struct Valuation { std::vector<double> modelVolatility; double seconds_simulation = 0, seconds_valuation = 0; };
+struct Valuation { std::vector<double> modelVolatility; double seconds_simulation = 0, seconds_valuation = 0; long long launches_simulation = 0, launches_valuation = 0; };
 
 inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Backend& be) {
     using clk = std::chrono::steady_clock;
@@ -219,15 +225,19 @@ inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Bac
     int lastIndex = 0;
     for (const Swaption& s : m.swaptions) lastIndex = std::max(lastIndex, m.timeDiscretization.getTimeIndex(s.exercise));
     const auto t0 = clk::now();
+    const long long l0 = be.launches();
     const Simulation sim = simulate(m, vol, be, lastIndex);
     const auto t1 = clk::now();
+    const long long l1 = be.launches();
     std::vector<RV> values;
     values.reserve(m.swaptions.size());
     for (const Swaption& s : m.swaptions) { values.push_back(swaptionValue(m, sim, s)); }
     be.flush();
+    const std::vector<double> optionValues = be.averages(values);
     for (size_t k = 0; k < m.swaptions.size(); ++k)
-        out.modelVolatility.push_back(bachelierAtmImpliedVolatility(values[k]->getAverage(), m.swaptions[k].exercise, m.swaptions[k].annuity));
+        out.modelVolatility.push_back(bachelierAtmImpliedVolatility(optionValues[k], m.swaptions[k].exercise, m.swaptions[k].annuity));
     const auto t2 = clk::now();
+    out.launches_simulation = l1 - l0; out.launches_valuation = be.launches() - l1;
     out.seconds_simulation = std::chrono::duration<double>(t1 - t0).count();
     out.seconds_valuation = std::chrono::duration<double>(t2 - t1).count();
     return out;

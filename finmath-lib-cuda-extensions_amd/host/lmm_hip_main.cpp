@@ -13,6 +13,8 @@ int main(int argc, char** argv) {
         lmm::Backend be;
         be.factory = &factory; be.brownianMotion = &bm;
         be.flush = [] { check(fmhip_flush()); };
+        be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
+        be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         fmhip_pool_stats_t s0; check(fmhip_pool_stats(&s0));
         lmm::runAndReport(o, be, "hip", [&] {
             fmhip_pool_stats_t s; check(fmhip_pool_stats(&s));

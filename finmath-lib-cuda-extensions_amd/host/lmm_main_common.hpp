@@ -39,8 +39,8 @@ inline void runAndReport(const Options& o, const Backend& be, const char* backen
         double sim = 0, val = 0;
         for (int k = 0; k < o.evaluations; ++k) { v = evaluate(m, vol, be); sim += v.seconds_simulation; val += v.seconds_valuation; }
         std::printf("{\"backend\": \"%s\", \"mode\": \"evaluate\", \"paths\": %lld, \"swaptions\": %zu, \"evaluations\": %d, "
-                    "\"seconds_simulation_per_evaluation\": %.6f, \"seconds_valuation_per_evaluation\": %.6f%s, \"model_volatility\": [",
-                    backendName, (long long)o.paths, m.swaptions.size(), o.evaluations, sim / o.evaluations, val / o.evaluations, extraJson().c_str());
+                    "\"seconds_simulation_per_evaluation\": %.6f, \"seconds_valuation_per_evaluation\": %.6f, \"launches_simulation\": %lld, \"launches_valuation\": %lld%s, \"model_volatility\": [",
+                    backendName, (long long)o.paths, m.swaptions.size(), o.evaluations, sim / o.evaluations, val / o.evaluations, v.launches_simulation, v.launches_valuation, extraJson().c_str());
         for (size_t k = 0; k < v.modelVolatility.size(); ++k) std::printf("%s%.17g", k ? ", " : "", v.modelVolatility[k]);
         std::printf("]}\n");
         return;

@@ -361,6 +361,26 @@ private:
 
 inline RV RandomVariable::average() const { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), getAverage()); }
 
+// All expectations of one objective evaluation in ONE launch + ONE read-back (extension beyond the interface: the
+// interface's getAverage() returns a double immediately, i.e. one synchronisation per product).  Falls back to
+// getAverage() for values that are not stochastic RandomVariableHip objects.
+inline std::vector<double> getAverages(const std::vector<RV>& values) {
+    std::vector<double> out(values.size());
+    std::vector<fmhip_vec> handles; std::vector<size_t> where;
+    int64_t n = -1; bool uniform = true;
+    for (size_t k = 0; k < values.size(); ++k) {
+        auto h = dynamic_cast<const RandomVariableHip*>(values[k].get());
+        if (h && !h->isDeterministic() && h->size() > 0) { if (n < 0) n = h->size(); uniform &= (h->size() == n); handles.push_back(h->deviceVector()->handle()); where.push_back(k); }
+        else out[k] = values[k]->getAverage();
+    }
+    if (!handles.empty() && uniform) {
+        std::vector<fmhip_moments> m(handles.size());
+        check(fmhip_reduce_moments_batch(handles.data(), (int)handles.size(), nullptr, m.data()));
+        for (size_t i = 0; i < handles.size(); ++i) out[where[i]] = m[i].sum / (double)n;
+    } else for (size_t k : where) out[k] = values[k]->getAverage();
+    return out;
+}
+
 class RandomVariableHipFactory final : public RandomVariableFactory {      // RandomVariableCudaFactory.java:27-34
 public:
     RV createRandomVariable(double value) const override { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), value); }

@@ -205,6 +205,10 @@ int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out);
  * all-reduced with RCCL); asynchronous on the runtime stream. */
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles);
 
+/* `count` vectors of equal size reduced by ONE launch and one 32·count-byte read-back (all expectations of one objective
+ * evaluation at once).  shifts may be NULL (= 0 for all). */
+int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out);
+
 /* ---------------------------------------------------------------- fused programs */
 
 /* One SSA instruction. Values are numbered: 0 … n_inputs-1 are the program inputs, n_inputs+i is the
