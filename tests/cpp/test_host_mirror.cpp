@@ -1,0 +1,142 @@
+// test_host_mirror.cpp — the reference's RandomVariableGPUTest restated for the C++ host mirror (fmhost::RandomVariableHip)
+// against the CPU twin (fmhost::RandomVariableFromFloatArray over the C oracle), through the same interface.
+// Known answers: RandomVariableGPUTest.java:69-188; differential operator test: :191-360 (enforced bit-exactly here).
+// Built and run by tests/test_gpu_cpp_mirror.py.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../../finmath-lib-cuda-extensions_amd/host/random_variable.hpp"
+#include "../../oracle/host/random_variable_cpu.hpp"
+
+using namespace fmhost;
+static int failures = 0;
+#define EXPECT(cond, what) do { if (!(cond)) { std::printf("FAIL %s (%s:%d)\n", what, __FILE__, __LINE__); ++failures; } } while (0)
+
+static bool sameBits(const std::vector<double>& a, const std::vector<double>& b, bool libm) {
+    if (a.size() != b.size()) return false;
+    size_t diff = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (a[i] != a[i] && b[i] != b[i]) continue;
+        if (a[i] == b[i]) continue;
+        if (!libm) return false;
+        if (std::fabs(a[i] - b[i]) > 1e-7 * (1 + std::fabs(b[i]))) return false;     // RandomVariableGPUTest.java:217
+        ++diff;
+    }
+    return diff <= a.size() / 10000;
+}
+
+static void knownAnswers(const RandomVariableFactory& f, const char* name) {
+    RV rv = f.createRandomVariable(2.0);                                             // :69-86
+    rv = rv->mult(2.0)->add(1.0)->squared()->sub(4.0)->div(7.0);
+    EXPECT(rv->getAverage() == 3.0 && rv->getVariance() == 0.0, name);
+    rv = f.createRandomVariable(0.0, std::vector<double>{ -4.0, -2.0, 0.0, 2.0, 4.0 });  // :89-122
+    rv = rv->add(4.0)->div(2.0)->mult(2.0)->div(2.0);
+    EXPECT(std::fabs(rv->getAverage() - 2.0) <= 1e-7 && rv->getVariance() == 2.0, name);
+    RV rv2 = f.createRandomVariable(3.0)->mult(rv);
+    EXPECT(rv2->getAverage() == 6.0 && rv2->getVariance() == 18.0, name);
+    for (int size : { 2, 3, 4, 5, 7, 10, 13, 99, 100, 1000, 1024, 2047, 2048, 2049, 20000, 200000 }) {   // :125-153
+        std::vector<double> v((size_t)size);
+        for (int i = 0; i < size; ++i) v[(size_t)i] = i;
+        const double want = size * (size - 1.0) / 2.0 / size;
+        EXPECT(std::fabs(f.createRandomVariable(0.0, v)->getAverage() - want) <= want * 1e-6, name);
+    }
+    RV x = f.createRandomVariable(0.0, std::vector<double>{ 3.0, 1.0, 0.0, 2.0, 4.0, 1.0 / 3.0 });      // :156-188
+    RV c1 = x->sqrt()->sub(x->pow(0.5)), c2 = x->squared()->sub(x->pow(2.0));
+    EXPECT(std::fabs(c1->getAverage()) <= 1e-7 && std::fabs(c1->getVariance()) <= 1e-7, name);
+    EXPECT(std::fabs(c2->getAverage()) <= 1e-7 && std::fabs(c2->getVariance()) <= 1e-7, name);
+    EXPECT(std::fabs(std::sqrt(x->getVariance()) - x->getStandardDeviation()) <= 1e-7, name);
+}
+
+int main() {
+    check(fmhip_init(-1));
+    RandomVariableHipFactory hip;
+    RandomVariableFloatFactory cpu;
+    knownAnswers(hip, "known answers (hip)");
+    knownAnswers(cpu, "known answers (cpu twin)");
+
+    const int n = 100000;                                                            // :194-201
+    std::vector<double> stream((size_t)n);
+    orc_java_random_doubles(31415, n, stream.data());
+    const double third = 1.0 / 3.0;
+    using F = std::function<RV(const RV&, const RV&)>;
+    struct Case { const char* name; F f; bool libm; };
+    const std::vector<Case> cases = {
+        { "squared", [](const RV& x, const RV&) { return x->squared(); }, false },
+        { "add_s", [&](const RV& x, const RV&) { return x->add(third); }, false },
+        { "add_xy", [](const RV& x, const RV& y) { return x->add(y); }, false }, { "add_yx", [](const RV& x, const RV& y) { return y->add(x); }, false },
+        { "sub_xy", [](const RV& x, const RV& y) { return x->sub(y); }, false }, { "sub_yx", [](const RV& x, const RV& y) { return y->sub(x); }, false },
+        { "bus_xy", [](const RV& x, const RV& y) { return x->bus(y); }, false }, { "bus_yx", [](const RV& x, const RV& y) { return y->bus(x); }, false },
+        { "bus_xx", [](const RV& x, const RV&) { return x->bus(x->mult(2.0)); }, false },
+        { "cap_s", [&](const RV& x, const RV&) { return x->cap(third); }, false }, { "cap_yx", [](const RV& x, const RV& y) { return y->cap(x); }, false },
+        { "cap_xy", [](const RV& x, const RV& y) { return x->cap(y); }, false },
+        { "floor_s", [&](const RV& x, const RV&) { return x->floor(third); }, false }, { "floor_yx", [](const RV& x, const RV& y) { return y->floor(x); }, false },
+        { "floor_xx", [](const RV& x, const RV&) { return x->floor(x->squared()); }, false },
+        { "mult_xx", [](const RV& x, const RV&) { return x->mult(x); }, false }, { "mult_yx", [](const RV& x, const RV& y) { return y->mult(x); }, false },
+        { "mult_s", [](const RV& x, const RV&) { return x->mult(3.1415); }, false },
+        { "div_xx", [](const RV& x, const RV&) { return x->div(x->add(1.0)); }, false }, { "div_yx", [](const RV& x, const RV& y) { return y->div(x); }, false },
+        { "div_xy", [](const RV& x, const RV& y) { return x->div(y); }, false }, { "div_s", [](const RV& x, const RV&) { return x->div(3.1415); }, false },
+        { "vid_xy", [](const RV& x, const RV& y) { return x->vid(y); }, false }, { "vid_yx", [](const RV& x, const RV& y) { return y->vid(x); }, false },
+        { "vid_s", [](const RV& x, const RV&) { return x->vid(2.0); }, false }, { "bus_s", [](const RV& x, const RV&) { return x->bus(2.0); }, false },
+        { "exp", [](const RV& x, const RV&) { return x->exp(); }, true }, { "log", [](const RV& x, const RV&) { return x->log(); }, true },
+        { "pow", [](const RV& x, const RV&) { return x->pow(1.5); }, true },
+        { "sqrt", [](const RV& x, const RV&) { return x->sqrt(); }, false }, { "invert", [](const RV& x, const RV&) { return x->invert(); }, false },
+        { "abs", [](const RV& x, const RV&) { return x->sub(0.5)->abs(); }, false }, { "isNaN", [](const RV& x, const RV&) { return x->sub(0.5)->sqrt()->isNaN(); }, false },
+        { "accrue_xx", [](const RV& x, const RV&) { return x->accrue(x, 2.0); }, false }, { "accrue_xy", [&](const RV& x, const RV& y) { return x->accrue(y, third); }, false },
+        { "accrue_yx", [&](const RV& x, const RV& y) { return y->accrue(x, third); }, false },
+        { "discount_xx", [](const RV& x, const RV&) { return x->discount(x, 2.0); }, false }, { "discount_xy", [&](const RV& x, const RV& y) { return x->discount(y, third); }, false },
+        { "discount_yx", [&](const RV& x, const RV& y) { return y->discount(x, third); }, false },
+        { "addProduct_xxx", [](const RV& x, const RV&) { return x->addProduct(x, x); }, false }, { "addProduct_xxy", [](const RV& x, const RV& y) { return x->addProduct(x, y); }, false },
+        { "addProduct_xyx", [](const RV& x, const RV& y) { return x->addProduct(y, x); }, false }, { "addProduct_yxx", [](const RV& x, const RV& y) { return y->addProduct(x, x); }, false },
+        { "addProduct_yxy", [](const RV& x, const RV& y) { return y->addProduct(x, y); }, false },
+        { "addProduct_s_xx", [&](const RV& x, const RV&) { return x->addProduct(x, third); }, false }, { "addProduct_s_yx", [&](const RV& x, const RV& y) { return y->addProduct(x, third); }, false },
+        { "addProduct_s_xy", [&](const RV& x, const RV& y) { return x->addProduct(y, third); }, false },
+        { "choose", [](const RV& x, const RV& y) { return x->sub(0.5)->choose(x, y); }, false }, { "choose_det", [](const RV& x, const RV& y) { return y->choose(x, x->squared()); }, false },
+        { "addRatio", [](const RV& x, const RV&) { return x->addRatio(x->add(1.0), x->add(2.0)); }, false }, { "subRatio", [](const RV& x, const RV& y) { return x->subRatio(y, x->add(2.0)); }, false },
+        { "chain", [](const RV& x, const RV& y) { return x->add(4.0)->div(2.0)->mult(y)->sub(x)->squared()->cap(9.0)->floor(0.25)->addProduct(x, y)->discount(x, 0.5); }, false },
+    };
+    for (int fusion = 0; fusion <= 1; ++fusion) {
+        check(fmhip_set_fusion(fusion, nullptr));
+        for (const Case& c : cases) {
+            const RV xh = hip.createRandomVariable(0.0, stream), yh = hip.createRandomVariable(0.0, stream[0]);
+            const RV xc = cpu.createRandomVariable(0.0, stream), yc = cpu.createRandomVariable(0.0, stream[0]);
+            const RV rh = c.f(xh, yh), rc = c.f(xc, yc);
+            const bool ok = sameBits(rh->getRealizations(), rc->getRealizations(), c.libm) && rh->getFiltrationTime() == rc->getFiltrationTime();
+            if (!ok) { std::printf("FAIL case %s (fusion %d)\n", c.name, fusion); ++failures; }
+        }
+        // mixed types: the higher type priority takes over, the foreign operand is uploaded (RandomVariableCuda.java:759-766, :1392)
+        const RV xh = hip.createRandomVariable(2.0, stream), xc = cpu.createRandomVariable(1.0, stream);
+        const RV r1 = xh->add(xc), r2 = xc->add(xh), want = xc->add(xc);
+        EXPECT(dynamic_cast<const RandomVariableHip*>(r1.get()) && dynamic_cast<const RandomVariableHip*>(r2.get()), "type priority");
+        EXPECT(sameBits(r1->getRealizations(), want->getRealizations(), false) && sameBits(r2->getRealizations(), want->getRealizations(), false), "foreign upload");
+        EXPECT(r1->getFiltrationTime() == 2.0 && r2->getFiltrationTime() == 2.0, "filtration time");
+    }
+    check(fmhip_set_fusion(0, nullptr));
+    // reductions
+    {
+        const RV xh = hip.createRandomVariable(0.0, stream), xc = cpu.createRandomVariable(0.0, stream);
+        EXPECT(std::fabs(xh->getAverage() - xc->getAverage()) <= 1e-13, "average");
+        EXPECT(std::fabs(xh->getVariance() - xc->getVariance()) <= 1e-13, "variance");
+        EXPECT(xh->getMin() == xc->getMin() && xh->getMax() == xc->getMax(), "min/max");
+        EXPECT(std::fabs(xh->getStandardError() - xc->getStandardError()) <= 1e-13, "standard error");
+        bool threw = false;
+        try { xh->doubleValue(); } catch (const UnsupportedOperation&) { threw = true; }
+        EXPECT(threw, "doubleValue on stochastic throws");
+        const std::vector<double> av = getAverages({ xh, xh->squared(), hip.createRandomVariable(1.5) });
+        EXPECT(av[0] == xh->getAverage() && av[1] == xh->squared()->getAverage() && av[2] == 1.5, "getAverages");
+    }
+    // Brownian motion: identical increments on both back ends
+    {
+        TimeDiscretization td(0.0, 3, 0.25);
+        BrownianMotionHip bh(td, 2, 4097, 1234);
+        BrownianMotionCpu bc(td, 2, 4097, 1234);
+        for (int t = 0; t < 3; ++t) for (int f = 0; f < 2; ++f)
+            EXPECT(sameBits(bh.getBrownianIncrement(t, f)->getRealizations(), bc.getBrownianIncrement(t, f)->getRealizations(), false)
+                   && bh.getBrownianIncrement(t, f)->getFiltrationTime() == td.getTime(t + 1), "brownian increment");
+    }
+    check(fmhip_pool_purge());
+    std::printf("%s: %zu operator cases x 2 modes, %d failures\n", failures ? "FAILED" : "OK", cases.size(), failures);
+    return failures ? 1 : 0;
+}
