@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: BrownianMotionHip 1M paths x 200 steps x 5 factors (4.0 GB of N(0,dt) increments, seed 31415)
+driving a Heston Monte-Carlo (Euler full truncation, factors 0 and 1) on one MI355X.  Prints one JSON line: generation
+rate (GB/s written, the kernel is write-bound: 4 B per normal), Heston wall time, price vs the Black-Scholes limit."""
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+mc = importlib.import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+
+fm.init(0)
+n, steps, factors, dt = 1_000_000, 200, 5, 0.01
+S0, R, T, K = 1.0, 0.05, 2.0, 1.05
+td = fm.TimeDiscretization(0.0, steps, dt)
+times = []
+for rep in range(3):
+    bm = fm.BrownianMotionHip(td, factors, n, 31415 + rep)
+    fm.synchronize(); t0 = time.perf_counter()
+    bm.getBrownianIncrement(0, 0)                 # generates all steps x factors vectors in one launch
+    fm.synchronize(); times.append(time.perf_counter() - t0)
+    if rep < 2: del bm; fm.purge()
+gen_s = min(times)
+nbytes = 4.0 * n * steps * factors
+fm.set_fusion(True)
+res = {}
+for xi in (0.0, 0.3):
+    fm.synchronize(); t0 = time.perf_counter()
+    before = fm.pool_stats()
+    value, _ = mc.heston_call_mc(bm, S0, R, 0.09, 1.0, 0.09, xi, -0.5, T, K)
+    fm.synchronize(); wall = time.perf_counter() - t0
+    after = fm.pool_stats()
+    res[xi] = {"price": value, "wall_s": wall, "launches": after.n_kernel_launches - before.n_kernel_launches,
+               "path_ops_per_s": (after.n_ops_executed - before.n_ops_executed) * n / wall}
+print(json.dumps({
+    "workload": "BrownianMotionHip 1M paths x 200 steps x 5 factors + Heston MC (configs[2])",
+    "generation": {"bytes": nbytes, "seconds": gen_s, "GBps_written": nbytes / gen_s / 1e9, "frac_of_8TBps": nbytes / gen_s / 8e12,
+                   "normals_per_s": n * steps * factors / gen_s},
+    "heston_xi0": res[0.0], "heston_xi03": res[0.3],
+    "black_scholes_analytic": mc.black_scholes_call_analytic(S0, R, 0.30, T, K),
+    "abs_error_xi0": abs(res[0.0]["price"] - mc.black_scholes_call_analytic(S0, R, 0.30, T, K)),
+    "acceptance": "abs error < 0.005 (MonteCarloBlackScholesModelTest.java:156)"}))
