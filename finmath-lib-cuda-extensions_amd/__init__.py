@@ -15,7 +15,7 @@ import ctypes as _C
 from . import _native
 from ._native import FmhipError, Moments, PoolStats, ProgOp, build
 from .random_variable import OP, DeviceVector, RandomVariableHip, RandomVariableHipFactory
-from .brownian_motion import BrownianMotionHip, TimeDiscretization
+from .brownian_motion import BrownianMotionHip, BrownianMotionFromMersenneRandomNumbers, TimeDiscretization, mersenne_increments
 from .program import Program
 
 

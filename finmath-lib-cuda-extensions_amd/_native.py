@@ -24,7 +24,7 @@ SYMBOLS = [
     "fmhip_reduce_moments", "fmhip_reduce_moments_batch", "fmhip_reduce_moments_device",
     "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count",
     "fmhip_program_run", "fmhip_program_run_into",
-    "fmhip_bm_generate",
+    "fmhip_bm_generate", "fmhip_mersenne_increments", "fmhip_bm_generate_mersenne", "fmhip_inverse_normal_cdf",
     "fmhip_pool_clean", "fmhip_pool_purge", "fmhip_pool_stats",
     "fmhip_profile_enable", "fmhip_profile_read",
 ]
@@ -100,6 +100,8 @@ def lib():
         "fmhip_program_run": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
         "fmhip_program_run_into": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
         "fmhip_bm_generate": [i64, i32, i32, i64, i64, C.POINTER(dbl), pv],
+        "fmhip_mersenne_increments": [C.c_int32, i32, i32, i64, C.POINTER(dbl), C.POINTER(dbl)],
+        "fmhip_bm_generate_mersenne": [C.c_int32, i32, i32, i64, C.POINTER(dbl), pv],
         "fmhip_pool_clean": [], "fmhip_pool_purge": [], "fmhip_pool_stats": [C.POINTER(PoolStats)],
         "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],
     }
@@ -107,6 +109,8 @@ def lib():
         fn = getattr(L, name)
         fn.argtypes = args
         fn.restype = C.c_int
+    L.fmhip_inverse_normal_cdf.argtypes = [dbl]
+    L.fmhip_inverse_normal_cdf.restype = dbl
     L.fmhip_last_error.argtypes = []
     L.fmhip_last_error.restype = C.c_char_p
     _lib = L

@@ -100,3 +100,31 @@ class BrownianMotionHip:
     def __repr__(self):
         return (f"BrownianMotionHip(steps={self.timeDiscretization.getNumberOfTimeSteps()}, "
                 f"numberOfPaths={self.numberOfPaths}, numberOfFactors={self.numberOfFactors}, seed={self.seed})")
+
+
+class BrownianMotionFromMersenneRandomNumbers(BrownianMotionHip):
+    """finmath-lib's CPU generator (MT19937 + inverse normal CDF), the Brownian motion every reference test uses
+    (LIBORMarketModelCalibrationATMTest.java:283, MonteCarloBlackScholesModelTest.java:78-85); increments are generated on
+    the host and uploaded through the factory path (double[] → fp32).  Restated from published specifications — the draw
+    order is unverified (finmath-lib is not vendored), see csrc/mersenne.cpp."""
+
+    def _generate(self):
+        td = self.timeDiscretization
+        n_steps = td.getNumberOfTimeSteps()
+        dt = np.array([td.getTimeStep(i) for i in range(n_steps)], dtype=np.float64)
+        handles = (C.c_int64 * (n_steps * self.numberOfFactors))()
+        N.check(N.lib().fmhip_bm_generate_mersenne(self.seed, n_steps, self.numberOfFactors, self.numberOfPaths,
+                                                   dt.ctypes.data_as(C.POINTER(C.c_double)), handles))
+        self._increments = [
+            [RandomVariableHip(td.getTime(i + 1), DeviceVector(handles[i * self.numberOfFactors + f], self.numberOfPaths))
+             for f in range(self.numberOfFactors)]
+            for i in range(n_steps)]
+
+
+def mersenne_increments(seed, dt, n_factors, n_paths):
+    """Host array [step][factor][path] of the same increments (no device needed)."""
+    dt = np.ascontiguousarray(dt, dtype=np.float64)
+    out = np.empty((dt.size, n_factors, n_paths), dtype=np.float64)
+    N.check(N.lib().fmhip_mersenne_increments(int(seed), dt.size, n_factors, n_paths, dt.ctypes.data_as(C.POINTER(C.c_double)),
+                                              out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out

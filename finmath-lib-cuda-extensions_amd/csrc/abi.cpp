@@ -4,6 +4,9 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
+
+namespace fm { void mersenne_increments(int32_t, int, int, int64_t, const double*, double*); double inverse_normal_cdf(double); }
 
 using fm::Engine;
 using fm::Error;
@@ -152,6 +155,27 @@ int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths,
                       const double* dt, fmhip_vec* out) {
     return guarded([&] { Engine::get().bm_generate(seed, n_steps, n_factors, n_paths, path_offset, dt, out); });
 }
+
+int fmhip_mersenne_increments(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, double* host_out) {
+    try {
+        if (n_steps <= 0 || n_factors <= 0 || n_paths < 0 || !dt || (!host_out && n_paths > 0)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad Brownian motion description");
+        fm::mersenne_increments(seed, n_steps, n_factors, n_paths, dt, host_out);
+        return FMHIP_OK;
+    } catch (const Error& e) { g_last_error = e.what(); return e.code; }
+}
+int fmhip_bm_generate_mersenne(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, fmhip_vec* out) {
+    return guarded([&] {
+        need(out, "out"); need(dt, "dt");
+        if (n_steps <= 0 || n_factors <= 0 || n_paths < 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad Brownian motion description");
+        std::vector<double> host((size_t)n_steps * n_factors * (size_t)n_paths);
+        fm::mersenne_increments(seed, n_steps, n_factors, n_paths, dt, host.data());
+        const size_t count = (size_t)n_steps * n_factors;
+        for (size_t k = 0; k < count; ++k) out[k] = 0;
+        try { for (size_t k = 0; k < count; ++k) out[k] = Engine::get().create_from_host(host.data() + k * (size_t)n_paths, true, n_paths); }
+        catch (...) { for (size_t k = 0; k < count; ++k) if (out[k]) { Engine::get().release(out[k]); out[k] = 0; } throw; }
+    });
+}
+double fmhip_inverse_normal_cdf(double p) { return fm::inverse_normal_cdf(p); }
 
 int fmhip_pool_clean(void) { return guarded([&] { Engine::get().pool_clean(); }); }
 int fmhip_pool_purge(void) { return guarded([&] { Engine::get().pool_purge(); }); }

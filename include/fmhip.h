@@ -253,6 +253,16 @@ int fmhip_program_run_into(fmhip_program p, int batch,
 int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
                       const double* dt, fmhip_vec* out);
 
+/* Host-side Mersenne-Twister Brownian motion (restatement of finmath-lib's BrownianMotionFromMersenneRandomNumbers, the
+ * generator the reference's tests feed to every factory: LIBORMarketModelCalibrationATMTest.java:283): MT19937 seeded like
+ * commons-math3 MersenneTwister(int), nextDouble(), inverse normal CDF (AS 241), times sqrt(dt); draw order path-major.
+ * fmhip_mersenne_increments fills host doubles out[(step*n_factors+factor)*n_paths + path] and needs no device;
+ * fmhip_bm_generate_mersenne uploads them as n_steps*n_factors vectors (narrowed to fp32 like any double[] upload). */
+int fmhip_mersenne_increments(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, double* host_out);
+int fmhip_bm_generate_mersenne(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, fmhip_vec* out);
+/* Inverse of the standard normal CDF (Wichura AS 241 / PPND16), exposed for tests. Returns the value (no status). */
+double fmhip_inverse_normal_cdf(double p);
+
 /* ---------------------------------------------------------------- pool */
 
 /* Return cached (unused) device buffers to the driver (DeviceMemoryPool.clean, :393). */

@@ -111,3 +111,18 @@ def test_heston_config3_full_size(gpu):
     assert launches < 200, launches
     del bm
     gpu.purge()
+
+
+def test_black_scholes_with_mersenne_brownian_motion(gpu):
+    """The reference test's own configuration: BrownianMotionFromMersenneRandomNumbers(seed 31415) feeding the GPU factory
+    (MonteCarloBlackScholesModelTest.java:78-85); README.md:212-215 reports MC 0.1898 vs analytic 0.1899."""
+    from importlib import import_module
+    mc = import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    td = gpu.TimeDiscretization(0.0, 2, 1.0)          # the option only needs the first two of the test's 100 unit steps
+    bm = gpu.BrownianMotionFromMersenneRandomNumbers(td, 1, 1_000_000, 31415)
+    value, rv = mc.black_scholes_call_mc(bm, S0, R, SIGMA, T, K)
+    analytic = mc.black_scholes_call_analytic(S0, R, SIGMA, T, K)
+    assert abs(value - analytic) < 0.005
+    host = gpu.mersenne_increments(31415, [1.0, 1.0], 1, 1000)
+    assert (bm.getBrownianIncrement(1, 0).realizations.to_float32()[:1000] == host[1, 0].astype(np.float32)).all()
+    assert bm.getBrownianIncrement(1, 0).getFiltrationTime() == 2.0
