@@ -149,9 +149,12 @@ def main():
     import torch                         # before libfmhip: one HIP runtime in the process (see _native.lib)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FMHIP_BENCH_FORCE_DIST=1 exercises the collective path with a single rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
     fm.init(local_rank)
@@ -165,17 +168,17 @@ def main():
 
     ext_stream = torch.cuda.ExternalStream(fm.stream_ptr(), device=torch.device("cuda", local_rank))
     partial = torch.zeros(B * 4, dtype=torch.float64, device=f"cuda:{local_rank}")
-    gathered = torch.zeros(world * B * 4, dtype=torch.float64, device=f"cuda:{local_rank}") if world > 1 else None
+    gathered = torch.zeros(world * B * 4, dtype=torch.float64, device=f"cuda:{local_rank}") if use_dist else None
 
     def step():
         # one launch: 12 ops over B triples + fused reductions; moments stay on the device
         prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
-        if world > 1:                    # the single exchange: expectation partials of all ranks
+        if use_dist:                     # the single exchange: expectation partials of all ranks
             with torch.cuda.stream(ext_stream):
                 dist.all_gather_into_tensor(gathered, partial)
 
     def barrier_sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         fm.synchronize()
         torch.cuda.synchronize()
@@ -188,14 +191,14 @@ def main():
         step()
     barrier_sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     # combined expectations (sanity: finite, and identical on every rank by construction)
     par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
-    if world > 1:
+    if use_dist:
         comb = par.combine_moments(gathered.view(world, B, 4))
     else:
         comb = partial.view(B, 4)
@@ -267,7 +270,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     del rows, out_rows
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
