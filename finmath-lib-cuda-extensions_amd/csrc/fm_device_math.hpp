@@ -5,8 +5,8 @@
 // (each elementary operation rounds to fp32 once: this file is compiled with -ffp-contract=off, the
 // counterpart of the reference's `nvcc -fmad false`, JCudaUtils.java:69-70), and exp/log/pow/sin/cos are
 // evaluated in fp64 and narrowed ONCE — the twin computes `(float)Math.exp(realizations[i])` (:905).  The fp64
-// intermediate is accurate to ≈2^-47, so the narrowed result differs from the twin's only when the exact value
-// lies within ≈2^-47 (relative) of an fp32 rounding boundary: ≈2^-23 of the elements, and then by one fp32 ulp.
+// intermediate is accurate to ≈2^-44…2^-47, so the narrowed result differs from the twin's only when the exact value
+// lies within that distance (relative) of an fp32 rounding boundary: ≈1e-6 of the elements, and then by one fp32 ulp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,8 +47,8 @@ __device__ __forceinline__ double jpow(double x, double y) {
 // 17 fp64 instructions instead of the ≈45 of the generic library exp — exp/log dominate the VALU budget of a
 // fused stream, and the kernel has to stay under the HBM roofline.
 __device__ __forceinline__ float exp_f(float a) {
-    double x = (double)a;
-    x = __builtin_fmin(__builtin_fmax(x, -110.0), 90.0);           // ±inf and huge arguments: result is 0 / +inf anyway
+    // clamp in fp32 (one v_med3_f32): ±inf and huge arguments give 0 / +inf anyway, and k stays a small integer
+    double x = (double)__builtin_amdgcn_fmed3f(a, -110.0f, 90.0f);
     const double k = __builtin_rint(x * 1.4426950408889634);       // log2(e)
     double r = __builtin_fma(k, -6.93147180369123816490e-01, x);   // ln2 hi (low 32 bits zero: k*hi exact)
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);          // ln2 lo
@@ -69,8 +69,10 @@ __device__ __forceinline__ float exp_f(float a) {
 }
 
 // ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).
-// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) (fp32 reciprocal seed + one Newton step + one residual
-// correction: no fp64 division);  log m = 2s·(1 + z/3 + z²/5 + … + z^8/17), z = s² <= 0.0295 (truncation 2^-50).
+// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) with an fp32 reciprocal seed and ONE Newton step (relative
+// error 2^-44: no fp64 division);  log m = 2s·(1 + z/3 + z²/5 + … + z^8/17), z = s² <= 0.0295 (truncation 2^-50).
+// Zero, negative, infinite and NaN arguments take the hardware v_log_f32 result, which has exactly the IEEE special
+// values needed (-inf, NaN, +inf, NaN): one class test + one select instead of four compare/select pairs.
 __device__ __forceinline__ float log_f(float a) {
     const double x = (double)a;                                     // denormal floats become normal doubles
     double m = __builtin_amdgcn_frexp_mant(x);                      // [0.5, 1)
@@ -82,8 +84,7 @@ __device__ __forceinline__ float log_f(float a) {
     const double d = m + 1.0;                                       // exact (m carries <= 24 significant bits)
     const double q0 = (double)__builtin_amdgcn_rcpf((float)d);      // ≈ 1/d, 2^-22
     const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);   // Newton: 2^-44
-    const double s0 = f * q1;
-    const double s = __builtin_fma(__builtin_fma(-d, s0, f), q1, s0);      // residual correction: ≈ 2^-52
+    const double s = f * q1;
     const double z = s * s;
     double p = 1.0 / 17.0;
     p = __builtin_fma(p, z, 1.0 / 15.0);
@@ -97,11 +98,10 @@ __device__ __forceinline__ float log_f(float a) {
     const double lm = __builtin_fma(s2, p * z, s2);
     const double ed = (double)e;
     const double r = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
-    float res = (float)r;
-    res = (a == 0.0f) ? -__builtin_huge_valf() : res;               // log(±0) = -inf
-    res = (a < 0.0f) ? __builtin_nanf("") : res;                    // log(negative) = NaN
-    res = (a == __builtin_huge_valf()) ? a : res;                   // log(+inf) = +inf
-    return (a != a) ? a : res;
+    // class mask: sNaN|qNaN|-inf|-normal|-denormal|-0|+0|+inf = everything except +denormal (0x080) and +normal (0x100)
+    const bool special = __builtin_amdgcn_classf(a, 0x27f);
+    // (scaled by 2^64 first: v_log_f32 flushes denormal inputs, which would turn log(-denormal) = NaN into -inf)
+    return special ? __builtin_amdgcn_logf(a * 0x1p+64f) : (float)r;
 }
 
 // ---- FAST math mode (fmhip_set_math_mode(FMHIP_MATH_FAST)): exp and log on the hardware transcendental unit
