@@ -1,5 +1,5 @@
 import importlib, sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
 fm.init(0)
 n, B = 1_000_000, 16
