@@ -99,24 +99,36 @@ def lmm_workload(args):
     import subprocess
     lmm_hip = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
     lmm_cpu = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
-    paths = args.paths
+    paths = args.paths                      # per GPU; configs[4] = 1M paths on each of 8 GPUs (path sharding, weak scaling)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    cmd = [lmm_hip, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)]
+    if world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1":
+        # one native process per GPU (LOCAL_RANK picks the device); they find each other through an RCCL unique-id file
+        idfile = os.path.join("/tmp", f"fmhip_nccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")   # same launcher parent on every rank
+        cmd += ["--world", str(world), "--rank", str(rank), "--nccl-id-file", idfile]
     t0 = time.perf_counter()
-    out = subprocess.run([lmm_hip, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)],
-                         capture_output=True, text=True, check=True)
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError(f"lmm_hip rank {rank} failed: {out.stderr}")
     wall = time.perf_counter() - t0
+    if rank != 0:
+        return
+    if "--nccl-id-file" in cmd and os.path.exists(cmd[-1]):
+        os.remove(cmd[-1])
     r = json.loads(out.stdout.strip().splitlines()[-1])
-    line = {"metric": "LMM calib wall-time, 1M paths", "value": r["seconds"], "unit": "s", "n_gpus": 1, "steps": r["iterations"],
+    line = {"metric": f"LMM calib wall-time, {world}x1M paths" if world > 1 else "LMM calib wall-time, 1M paths",
+            "value": r["seconds"], "unit": "s", "n_gpus": world, "steps": r["iterations"],
             "warmup": 0, "ms_per_step": r["seconds"] / max(1, r["iterations"]) * 1e3, "higher_is_better": False, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LIBOR Market Model ATM swaption calibration (80 forward rates, 1 factor, spot measure, normal state space, "
                                    "144 swaptions, 50 volatility parameters, Levenberg-Marquardt with finite differences)",
-                       "paths": paths, "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
+                       "paths": paths * world, "paths_per_gpu": paths, "rccl_all_reduces": r.get("rccl_all_reduces", 0), "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
                        "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
                        "rms_deviation": r["rms_deviation"], "mean_deviation": r["mean_deviation"],
                        "acceptance": "abs(mean deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
                        "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"], "process_wall_s": wall},
             "roofline": None}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         c = subprocess.run([lmm_cpu, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"], capture_output=True, text=True, check=True)
         cj = json.loads(c.stdout.strip().splitlines()[-1])
         per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]

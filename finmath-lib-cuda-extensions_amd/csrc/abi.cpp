@@ -119,7 +119,10 @@ int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     return guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr); });
 }
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
-    return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine::get().reduce_batch(vectors, count, shifts, out); });
+    return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine::get().reduce_batch(vectors, count, shifts, out, nullptr); });
+}
+int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
+    return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch(vectors, count, shifts, nullptr, device_out); });
 }
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });

@@ -831,7 +831,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     launch(prog, nd->n, rows, host_out, dev_out);
 }
 
-void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out) {
+void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out) {
     require_init();
     if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
     std::vector<Node*> nds((size_t)count);
@@ -856,7 +856,7 @@ void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, 
             rows[(size_t)i].scalars = nullptr;
             rows[(size_t)i].shifts = shifts ? &shifts[off + i] : nullptr;
         }
-        launch(prog, nds[0]->n, rows, host_out + off, nullptr);
+        launch(prog, nds[0]->n, rows, host_out ? host_out + off : nullptr, dev_out ? (char*)dev_out + (size_t)off * 32 : nullptr);
     }
 }
 

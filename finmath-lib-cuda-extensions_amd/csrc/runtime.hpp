@@ -112,7 +112,7 @@ public:
 
     // reductions
     void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out);
-    void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out);
+    void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out);
 
     // programs
     fmhip_program program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,

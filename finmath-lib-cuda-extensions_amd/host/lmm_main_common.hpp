@@ -11,6 +11,7 @@ namespace fmhost { namespace lmm {
 struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
+    int world = 1, rank = 0; std::string ncclIdFile;      // path sharding over GPUs: one process per GPU
 };
 inline Options parseOptions(int argc, char** argv) {
     Options o;
@@ -23,6 +24,9 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--mode") o.mode = next();                  // calibrate | evaluate
         else if (a == "--evaluations") o.evaluations = std::atoi(next());
         else if (a == "--path-offset") o.pathOffset = std::atoll(next());
+        else if (a == "--world") o.world = std::atoi(next());
+        else if (a == "--rank") o.rank = std::atoi(next());
+        else if (a == "--nccl-id-file") o.ncclIdFile = next();
         else if (a == "--verbose") o.verbose = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); std::exit(2); }
     }

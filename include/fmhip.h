@@ -208,6 +208,9 @@ int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_do
 /* `count` vectors of equal size reduced by ONE launch and one 32·count-byte read-back (all expectations of one objective
  * evaluation at once).  shifts may be NULL (= 0 for all). */
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out);
+/* Same, results (count x 4 doubles) left in caller-owned DEVICE memory, asynchronous on the runtime stream — the send buffer
+ * of the one RCCL all-reduce per objective evaluation when paths are sharded over GPUs. */
+int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out);
 
 /* ---------------------------------------------------------------- fused programs */
 

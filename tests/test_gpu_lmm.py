@@ -57,3 +57,14 @@ def test_reduce_moments_batch(gpu, oracle):
     for i in range(k):
         m = vecs[i].moments(0.01 * i)
         assert (out[i].sum, out[i].sumsq, out[i].min, out[i].max) == (m.sum, m.sumsq, m.min, m.max)
+
+
+def test_sharded_driver_path_with_rccl_world_of_one(tmp_path):
+    """The path-sharded driver (BASELINE.json configs[4]) with a world of ONE rank: RCCL communicator bootstrap through the
+    id file, device-side batched expectation partials, ncclAllReduce on the runtime stream.  The result must equal the
+    unsharded run; and a 'rank 1 of 2'-style path offset must equal --path-offset (shard invariance of the generator)."""
+    plain = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate")
+    dist = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate", "--world", 1, "--rank", 0, "--nccl-id-file", tmp_path / "id")
+    assert dist["rccl_all_reduces"] >= 1 and dist["world"] == 1
+    a, b = np.array(plain["model_volatility"]), np.array(dist["model_volatility"])
+    assert np.max(np.abs(a - b) / a) <= 1e-12
