@@ -173,7 +173,7 @@ def main():
     dev_name, cus, hbm = fm.device_info()
     n, B = args.paths, args.batch
 
-    prog = build_stream_s(fm)
+    prog = build_stream_s(fm)            # explicit program: queued for the specialised-kernel tier (hiprtc) at creation
     rows = synthetic_inputs(fm, B, n, rank)
     out_rows = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
     fm.synchronize()
@@ -197,6 +197,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    fm.jit_wait()                        # steady state: the background compilation of the specialised kernel has finished
+    tier, jit_vgprs = prog.tier()
+    step()
     barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -227,10 +230,25 @@ def main():
     alg_bytes = 4.0 * (3 + 1) * n * B
     achieved = alg_bytes / avg_kernel_s / 1e9
 
+    # additional information: the same program on the interpreter tier (what a program runs on until its kernel is compiled)
+    interp_kernel_s = None
+    if tier == 1:
+        prev_jit = fm.set_jit(fm.JIT_OFF)
+        for _ in range(3):
+            prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
+        fm.profile_enable(True)
+        for _ in range(10):
+            prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
+        i_ms, i_n = fm.profile_read()
+        fm.profile_enable(False)
+        fm.set_jit(prev_jit)
+        interp_kernel_s = i_ms / 1e3 / max(1, i_n)
+
     # additional information (not the headline): the same stream with FMHIP_MATH_FAST (hardware exp/log, <= 2 ulp)
     fm.set_math_mode(fm.MATH_FAST)
     prog_fast = build_stream_s(fm)
     fm.set_math_mode(fm.MATH_EXACT)
+    fm.jit_wait()
     for _ in range(3):
         prog_fast.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
     fm.profile_enable(True)
@@ -268,9 +286,16 @@ def main():
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "fm::fm_program_kernel<1, false, 8, 9, 3, float __vector(9)>", "avg_kernel_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": ("fm_jit_<hash>_t (specialised kernel of stream S, generated + compiled at run time)" if tier == 1
+                                    else "fm::fm_program_kernel<1, false, 8, 9, 3, float __vector(9)>"),
+                         "tier": "specialised" if tier == 1 else "interpreter", "vgprs": jit_vgprs,
+                         "avg_kernel_us": avg_kernel_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
             "mean_w": mean_w,
+            "interpreter_tier": None if interp_kernel_s is None else {
+                "note": "same program on the bytecode interpreter kernel (tier 0, no compilation)",
+                "avg_kernel_us": interp_kernel_s * 1e6, "achieved_GBps": alg_bytes / interp_kernel_s / 1e9,
+                "frac": alg_bytes / interp_kernel_s / 1e9 / HBM_PEAK_GBS},
+            "jit": fm.jit_stats(),
             "fast_math": {"note": "same workload with fmhip_set_math_mode(FMHIP_MATH_FAST): exp/log on v_exp_f32/v_log_f32, "
                                   "within 2 fp32 ulp (accuracy class of the reference kernels' CUDA expf/logf); not the headline",
                           "avg_kernel_us": fast_kernel_s * 1e6, "achieved_GBps": alg_bytes / fast_kernel_s / 1e9,

@@ -64,6 +64,29 @@ def set_math_mode(mode: int) -> int:
     return prev.value
 
 
+JIT_OFF, JIT_AUTO, JIT_SYNC = 0, 1, 2
+
+
+def set_jit(mode: int) -> int:
+    """Execution tier policy: JIT_OFF = interpreter kernel only; JIT_AUTO (default) = explicit programs and hot lazy programs
+    are compiled to specialised kernels in the background; JIT_SYNC = compiled before their first launch.  Returns the
+    previous mode.  Both tiers are bit-identical."""
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_set_jit(int(mode), _C.byref(prev)))
+    return prev.value
+
+
+def jit_wait() -> None:
+    """Block until the background compiler is idle."""
+    _native.check(lib().fmhip_jit_wait())
+
+
+def jit_stats() -> dict:
+    c, f, p, s = _C.c_int64(0), _C.c_int64(0), _C.c_int64(0), _C.c_double(0)
+    _native.check(lib().fmhip_jit_stats(_C.byref(c), _C.byref(f), _C.byref(p), _C.byref(s)))
+    return {"compiled": c.value, "failed": f.value, "pending": p.value, "compile_seconds": s.value}
+
+
 def flush() -> None:
     _native.check(lib().fmhip_flush())
 

@@ -24,6 +24,7 @@ SYMBOLS = [
     "fmhip_reduce_moments", "fmhip_reduce_moments_batch", "fmhip_reduce_moments_batch_device", "fmhip_reduce_moments_device",
     "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count",
     "fmhip_program_run", "fmhip_program_run_into",
+    "fmhip_set_jit", "fmhip_jit_wait", "fmhip_jit_stats", "fmhip_program_tier", "fmhip_program_source",
     "fmhip_bm_generate", "fmhip_mersenne_increments", "fmhip_bm_generate_mersenne", "fmhip_inverse_normal_cdf",
     "fmhip_pool_clean", "fmhip_pool_purge", "fmhip_pool_stats",
     "fmhip_profile_enable", "fmhip_profile_read",
@@ -103,6 +104,10 @@ def lib():
         "fmhip_mersenne_increments": [C.c_int32, i32, i32, i64, C.POINTER(dbl), C.POINTER(dbl)],
         "fmhip_bm_generate_mersenne": [C.c_int32, i32, i32, i64, C.POINTER(dbl), pv],
         "fmhip_pool_clean": [], "fmhip_pool_purge": [], "fmhip_pool_stats": [C.POINTER(PoolStats)],
+        "fmhip_set_jit": [i32, C.POINTER(i32)], "fmhip_jit_wait": [],
+        "fmhip_jit_stats": [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl)],
+        "fmhip_program_tier": [i64, C.POINTER(i32), C.POINTER(i32)],
+        "fmhip_program_source": [C.POINTER(ProgOp), i32, i32, C.POINTER(i32), i32, C.POINTER(i32), i32, C.c_char_p, i64, C.POINTER(i64)],
         "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],
     }
     for name, args in sig.items():

@@ -135,6 +135,47 @@ int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
         *out = Engine::get().program_create(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce);
     });
 }
+int fmhip_set_jit(int mode, int* previous) {
+    return guarded([&] {
+        if (mode != FMHIP_JIT_OFF && mode != FMHIP_JIT_AUTO && mode != FMHIP_JIT_SYNC) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown JIT mode");
+        if (previous) *previous = Engine::get().jit_mode;
+        Engine::get().jit_mode = mode;
+    });
+}
+int fmhip_jit_wait(void) {
+    // not under the engine mutex: other threads keep launching while this one waits for the compiler thread
+    try { Engine::get().jit_wait(); return FMHIP_OK; } catch (...) { return FMHIP_ERR_HIP; }
+}
+int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds) {
+    return guarded([&] {
+        const fm::JitStats s = Engine::get().jit_stats();
+        if (compiled) *compiled = s.compiled;
+        if (failed) *failed = s.failed;
+        if (pending) *pending = s.pending;
+        if (compile_seconds) *compile_seconds = s.seconds;
+    });
+}
+int fmhip_program_tier(fmhip_program p, int* tier, int* vgprs) {
+    return guarded([&] {
+        Engine::get().require_init();
+        fm::Program* pr = Engine::get().program(p);
+        const bool ready = Engine::get().jit_mode != FMHIP_JIT_OFF && pr->jit && pr->jit->state.load() == fm::JitSlot::READY;
+        if (tier) *tier = ready ? 1 : 0;
+        if (vgprs) *vgprs = ready ? pr->jit->vgprs : 0;
+    });
+}
+int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, const int32_t* out_values, int n_outputs,
+                         const int32_t* reduce_values, int n_reduce, char* buffer, int64_t capacity, int64_t* needed) {
+    return guarded([&] {
+        const std::string src = Engine::get().program_source(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce);
+        if (needed) *needed = (int64_t)src.size();
+        if (buffer && capacity > 0) {
+            const size_t k = std::min<size_t>(src.size(), (size_t)capacity - 1);
+            std::memcpy(buffer, src.data(), k);
+            buffer[k] = 0;
+        }
+    });
+}
 int fmhip_program_release(fmhip_program p) { return guarded([&] { Engine::get().program_release(p); }); }
 int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
     return guarded([&] {

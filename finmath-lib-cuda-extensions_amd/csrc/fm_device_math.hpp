@@ -8,9 +8,10 @@
 // intermediate is accurate to ≈2^-44…2^-47, so the narrowed result differs from the twin's only when the exact value
 // lies within that distance (relative) of an fp32 rounding boundary: ≈1e-6 of the elements, and then by one fp32 ulp.
 #pragma once
+#ifndef __HIPCC_RTC__           // the JIT tier compiles this header with hiprtc, which brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/fmhip.h"
+#endif
 #include "fm_program.h"
 
 namespace fm {
@@ -46,6 +47,15 @@ __device__ __forceinline__ double jpow(double x, double y) {
 // 2^k applied with ldexp; the final fp64→fp32 conversion rounds once (RNE, denormals honoured).
 // 17 fp64 instructions instead of the ≈45 of the generic library exp — exp/log dominate the VALU budget of a
 // fused stream, and the kernel has to stay under the HBM roofline.
+// p·r + c with a CONSTANT c held in a scalar register pair.  Written as an explicit three-address v_fma_f64: left to the
+// compiler, a Horner step becomes `v_mov_b64 tmp, c; v_fmac_f64 tmp, p, r` (two-address form, c copied first) in most
+// places — one extra VALU instruction per step, ≈25 % of a fused exp/log stream — and the 19 coefficients sit in 38 VGPRs.
+__device__ __forceinline__ double fma_c(double p, double r, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+    return d;
+}
+
 __device__ __forceinline__ float exp_f(float a) {
     // clamp in fp32 (one v_med3_f32): ±inf and huge arguments give 0 / +inf anyway, and k stays a small integer
     double x = (double)__builtin_amdgcn_fmed3f(a, -110.0f, 90.0f);
@@ -53,14 +63,14 @@ __device__ __forceinline__ float exp_f(float a) {
     double r = __builtin_fma(k, -6.93147180369123816490e-01, x);   // ln2 hi (low 32 bits zero: k*hi exact)
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);          // ln2 lo
     double p = 2.50521083854417187751e-08;                         // 1/11!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-07);           // 1/10!
-    p = __builtin_fma(p, r, 2.75573192239858906526e-06);           // 1/9!
-    p = __builtin_fma(p, r, 2.48015873015873015873e-05);           // 1/8!
-    p = __builtin_fma(p, r, 1.98412698412698412698e-04);           // 1/7!
-    p = __builtin_fma(p, r, 1.38888888888888888889e-03);           // 1/6!
-    p = __builtin_fma(p, r, 8.33333333333333333333e-03);           // 1/5!
-    p = __builtin_fma(p, r, 4.16666666666666666667e-02);           // 1/4!
-    p = __builtin_fma(p, r, 1.66666666666666666667e-01);           // 1/3!
+    p = fma_c(p, r, 2.75573192239858906526e-07);                   // 1/10!
+    p = fma_c(p, r, 2.75573192239858906526e-06);                   // 1/9!
+    p = fma_c(p, r, 2.48015873015873015873e-05);                   // 1/8!
+    p = fma_c(p, r, 1.98412698412698412698e-04);                   // 1/7!
+    p = fma_c(p, r, 1.38888888888888888889e-03);                   // 1/6!
+    p = fma_c(p, r, 8.33333333333333333333e-03);                   // 1/5!
+    p = fma_c(p, r, 4.16666666666666666667e-02);                   // 1/4!
+    p = fma_c(p, r, 1.66666666666666666667e-01);                   // 1/3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -87,13 +97,13 @@ __device__ __forceinline__ float log_f(float a) {
     const double s = f * q1;
     const double z = s * s;
     double p = 1.0 / 17.0;
-    p = __builtin_fma(p, z, 1.0 / 15.0);
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, 1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, 1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, 1.0 / 3.0);
+    p = fma_c(p, z, 1.0 / 15.0);
+    p = fma_c(p, z, 1.0 / 13.0);
+    p = fma_c(p, z, 1.0 / 11.0);
+    p = fma_c(p, z, 1.0 / 9.0);
+    p = fma_c(p, z, 1.0 / 7.0);
+    p = fma_c(p, z, 1.0 / 5.0);
+    p = fma_c(p, z, 1.0 / 3.0);
     const double s2 = s + s;
     const double lm = __builtin_fma(s2, p * z, s2);
     const double ed = (double)e;

@@ -1,0 +1,132 @@
+// fm_kernel_parts.hpp — device building blocks shared by the interpreter (kernels.hip) and by the specialised kernels the
+// JIT tier generates (jit.cpp → hiprtc): global-address-space vector pointers, wave64 DPP reduction, the per-pass
+// {Σ, Σ², min, max} accumulation and the workgroup combine.  Sharing them is what makes the two tiers produce
+// BIT-IDENTICAL results (same per-lane accumulation order, same wave/LDS combine, same partial layout for
+// fm_finalize_kernel), so a program may switch tier between two launches without any observable difference.
+#pragma once
+#include "fm_program.h"
+#include "fm_device_math.hpp"
+
+namespace fm {
+
+// Vector pointers arrive as 64-bit integers in the row block; casting them to the GLOBAL address space keeps the
+// data path on global_load/global_store_dwordx4 (a plain C++ pointer would be "generic" → flat_load, which also
+// ties up lgkmcnt).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 __attribute__((address_space(1))) gfloat4;
+
+// wave64 data movement without LDS: v_mov_b32 with a DPP control (quad_perm / row_mirror / row_bcast).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(x), (int)__float_as_uint(x), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double x) {
+    const uint64_t b = (uint64_t)__double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)b, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(b >> 32), (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// Full wave64 reduction of {Σ, Σ², min, max}; the result is valid in lane 63.  Fixed combination order ⇒ deterministic.
+__device__ __forceinline__ void wave_reduce(double& s1, double& s2, float& mn, float& mx) {
+#define FM_STEP(CTRL, MASK)                                                                             \
+    { const double t1 = dpp_d<CTRL, MASK>(s1), t2 = dpp_d<CTRL, MASK>(s2);                              \
+      const float tn = dpp_f<CTRL, MASK>(mn), tx = dpp_f<CTRL, MASK>(mx);                               \
+      s1 += t1; s2 += t2; mn = jmin(mn, tn); mx = jmax(mx, tx); }
+    FM_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
+    FM_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
+    FM_STEP(0x141, 0xf)     // row_half_mirror
+    FM_STEP(0x140, 0xf)     // row_mirror  → every lane of a row holds the row total
+    // across the four rows of 16: row_bcast15 into rows 1,3 then row_bcast31 into rows 2,3 (gfx9 DPP)
+    { const double t1 = dpp_d<0x142, 0xa>(s1), t2 = dpp_d<0x142, 0xa>(s2);
+      const float tn = dpp_f<0x142, 0xa>(mn), tx = dpp_f<0x142, 0xa>(mx);
+      const bool on = ((threadIdx.x >> 4) & 1) != 0;                       // rows 1 and 3 received data
+      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
+    { const double t1 = dpp_d<0x143, 0xc>(s1), t2 = dpp_d<0x143, 0xc>(s2);
+      const float tn = dpp_f<0x143, 0xc>(mn), tx = dpp_f<0x143, 0xc>(mx);
+      const bool on = ((threadIdx.x >> 5) & 1) != 0;                       // rows 2 and 3 received data
+      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
+#undef FM_STEP
+}
+
+// One pass of a fused reduction: E values per lane into the lane's fp64 accumulators (fp64 accumulation of fp32 values,
+// as the twin does: RandomVariableFromFloatArray.java:325-333, :373-381).  min/max use the hardware v_min_f32 /
+// v_max_f32 (which order -0 < +0 like java.lang.Math.min/max) and track NaN separately in a wave-level ballot mask
+// (scalar registers): NaN anywhere ⇒ the reduction result is NaN.
+template <int E>
+__device__ __forceinline__ void red_accumulate(const float (&x)[E], const double shift, const bool pass_full,
+                                               const uint32_t (&i4)[E / FM_VEC], const int64_t n,
+                                               double& acc_sum, double& acc_sq, float& acc_min, float& acc_max,
+                                               unsigned long long& nan_mask)
+{
+    if (pass_full && shift == 0.0) {        // getAverage / first pass of getVariance: no subtraction
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double dv = (double)x[j];
+            acc_sum += dv;
+            acc_sq = __builtin_fma(dv, dv, acc_sq);
+            acc_min = hw_min(acc_min, x[j]);
+            acc_max = hw_max(acc_max, x[j]);
+            nan_mask |= __ballot(x[j] != x[j]);
+        }
+    } else if (pass_full) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double dv = (double)x[j] - shift;
+            acc_sum += dv;
+            acc_sq = __builtin_fma(dv, dv, acc_sq);
+            acc_min = hw_min(acc_min, x[j]);
+            acc_max = hw_max(acc_max, x[j]);
+            nan_mask |= __ballot(x[j] != x[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool ok = (int64_t)i4[j / 4] * FM_VEC + (j & 3) < n;
+            const double dv = ok ? (double)x[j] - shift : 0.0;
+            acc_sum += dv;
+            acc_sq = __builtin_fma(dv, dv, acc_sq);
+            acc_min = ok ? hw_min(acc_min, x[j]) : acc_min;
+            acc_max = ok ? hw_max(acc_max, x[j]) : acc_max;
+            nan_mask |= __ballot(ok && (x[j] != x[j]));
+        }
+    }
+}
+
+// Workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup and reduction:
+// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.
+template <int NRED>
+__device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], const double (&acc_sq)[NRED],
+                                              const float (&acc_min)[NRED], const float (&acc_max)[NRED],
+                                              const unsigned long long (&nan_mask)[NRED],
+                                              double* __restrict__ partials, const uint32_t row)
+{
+    __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
+    __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+        double s1 = acc_sum[r], s2 = acc_sq[r];
+        float mn = acc_min[r], mx = acc_max[r];
+        if (nan_mask[r] != 0ull) { mn = __builtin_nanf(""); mx = mn; }      // wave-uniform
+        wave_reduce(s1, s2, mn, mx);
+        if (lane == 63) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) {
+            double s1 = lds_sum[r][0], s2 = lds_sq[r][0];
+            float mn = lds_min[r][0], mx = lds_max[r][0];
+#pragma unroll
+            for (int wv = 1; wv < FM_BLOCK / 64; ++wv) {
+                s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
+                mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
+            }
+            double* __restrict__ out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
+            out[0] = s1; out[1] = s2; out[2] = (double)mn; out[3] = (double)mx;
+        }
+    }
+}
+
+} // namespace fm

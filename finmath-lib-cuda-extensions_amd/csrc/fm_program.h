@@ -14,7 +14,12 @@
 // operands, reduction shifts) lives in a per-row "row block", so identical op streams over different
 // vectors/scalars (e.g. all LIBOR components of one Euler step) run as ONE launch.
 #pragma once
+#ifdef __HIPCC_RTC__            // hiprtc (JIT tier): no libc headers; fixed-width types come from its built-in runtime header
+using __hip_internal::int32_t; using __hip_internal::uint32_t; using __hip_internal::int64_t; using __hip_internal::uint64_t;
+using size_t = decltype(sizeof(0));
+#else
 #include <stdint.h>
+#endif
 
 namespace fm {
 
@@ -46,6 +51,12 @@ enum UOp : uint32_t {
     U_EXP_FAST, U_LOG_FAST,
     U__COUNT
 };
+
+// Number of register operands (R[r1], R[r2]) a micro-op reads besides the accumulator.
+constexpr int fm_uop_operands(uint32_t code) {
+    return (code == U_LDA || (code >= U_CAP && code <= U_ADDPRODUCT_VS_B)) ? 1
+         : (code >= U_ADDPRODUCT_A && code <= U_CHOOSE_N) ? 2 : 0;
+}
 
 // Instruction word: code[0:7] r1[8:11] r2[12:15] store[16:19] scalar_slot[24:31].
 // Every micro-op writes A to R[store]; the LAST register of the file is a dummy that is never allocated ("no

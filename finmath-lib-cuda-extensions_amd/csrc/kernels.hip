@@ -18,18 +18,13 @@
 #include <hip/hip_runtime.h>
 #include "fm_program.h"
 #include "fm_device_math.hpp"
+#include "fm_kernel_parts.hpp"
 #include "kernels.h"
 
 namespace fm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x9 __attribute__((ext_vector_type(9)));   // > 8 elements: dynamic indexing stays on s_set_gpr_idx (<= 8 would be expanded into v_cndmask chains)
-// Vector pointers arrive as 64-bit integers in the row block; casting them to the GLOBAL address space keeps the
-// data path on global_load/global_store_dwordx4 (a plain C++ pointer would be "generic" → flat_load, which also
-// ties up lgkmcnt).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef f32x4 __attribute__((address_space(1))) gfloat4;
-
 // ---------------------------------------------------------------------------------------------
 // Fused program interpreter
 // ---------------------------------------------------------------------------------------------
@@ -56,40 +51,6 @@ typedef f32x4 __attribute__((address_space(1))) gfloat4;
         _Pragma("unroll") for (int j = 0; j < E; ++j) { p[j] = R[j][r1]; q[j] = R[j][r2]; }             \
         _Pragma("unroll") for (int j = 0; j < E; ++j) a[j] = ueval<CODE>(a[j], p[j], q[j], s);          \
         } break;
-
-// wave64 data movement without LDS: v_mov_b32 with a DPP control (quad_perm / row_mirror / row_bcast).
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_f(float x) {
-    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(x), (int)__float_as_uint(x), CTRL, ROW_MASK, 0xf, false));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp_d(double x) {
-    const uint64_t b = (uint64_t)__double_as_longlong(x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)b, (int)(uint32_t)b, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(b >> 32), (int)(uint32_t)(b >> 32), CTRL, ROW_MASK, 0xf, false);
-    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
-}
-// Full wave64 reduction of {Σ, Σ², min, max}; the result is valid in lane 63.  Fixed combination order ⇒ deterministic.
-__device__ __forceinline__ void wave_reduce(double& s1, double& s2, float& mn, float& mx) {
-#define FM_STEP(CTRL, MASK)                                                                             \
-    { const double t1 = dpp_d<CTRL, MASK>(s1), t2 = dpp_d<CTRL, MASK>(s2);                              \
-      const float tn = dpp_f<CTRL, MASK>(mn), tx = dpp_f<CTRL, MASK>(mx);                               \
-      s1 += t1; s2 += t2; mn = jmin(mn, tn); mx = jmax(mx, tx); }
-    FM_STEP(0xB1, 0xf)      // quad_perm [1,0,3,2]
-    FM_STEP(0x4E, 0xf)      // quad_perm [2,3,0,1]
-    FM_STEP(0x141, 0xf)     // row_half_mirror
-    FM_STEP(0x140, 0xf)     // row_mirror  → every lane of a row holds the row total
-    // across the four rows of 16: row_bcast15 into rows 1,3 then row_bcast31 into rows 2,3 (gfx9 DPP)
-    { const double t1 = dpp_d<0x142, 0xa>(s1), t2 = dpp_d<0x142, 0xa>(s2);
-      const float tn = dpp_f<0x142, 0xa>(mn), tx = dpp_f<0x142, 0xa>(mx);
-      const bool on = ((threadIdx.x >> 4) & 1) != 0;                       // rows 1 and 3 received data
-      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
-    { const double t1 = dpp_d<0x143, 0xc>(s1), t2 = dpp_d<0x143, 0xc>(s2);
-      const float tn = dpp_f<0x143, 0xc>(mn), tx = dpp_f<0x143, 0xc>(mx);
-      const bool on = ((threadIdx.x >> 5) & 1) != 0;                       // rows 2 and 3 received data
-      s1 = on ? s1 + t1 : s1; s2 = on ? s2 + t2 : s2; mn = on ? jmin(mn, tn) : mn; mx = on ? jmax(mx, tx) : mx; }
-#undef FM_STEP
-}
 
 // E elements per lane (E/4 tiles of 1024 elements per pass), RegVec = register-file vector (NREG floats).
 //   variant 0: E = 4, 16 registers  — programs with many live values
@@ -228,70 +189,12 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             float x[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = R[j][reg];
-            if (pass_full && shift == 0.0) {        // getAverage / first pass of getVariance: no subtraction
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const double dv = (double)x[j];
-                    acc_sum[r] += dv;
-                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
-                    acc_min[r] = hw_min(acc_min[r], x[j]);
-                    acc_max[r] = hw_max(acc_max[r], x[j]);
-                    nan_mask[r] |= __ballot(x[j] != x[j]);
-                }
-            } else if (pass_full) {
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const double dv = (double)x[j] - shift;
-                    acc_sum[r] += dv;
-                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
-                    acc_min[r] = hw_min(acc_min[r], x[j]);
-                    acc_max[r] = hw_max(acc_max[r], x[j]);
-                    nan_mask[r] |= __ballot(x[j] != x[j]);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    const bool ok = (int64_t)i4[j / 4] * FM_VEC + (j & 3) < n;
-                    const double dv = ok ? (double)x[j] - shift : 0.0;
-                    acc_sum[r] += dv;
-                    acc_sq[r] = __builtin_fma(dv, dv, acc_sq[r]);
-                    acc_min[r] = ok ? hw_min(acc_min[r], x[j]) : acc_min[r];
-                    acc_max[r] = ok ? hw_max(acc_max[r], x[j]) : acc_max[r];
-                    nan_mask[r] |= __ballot(ok && (x[j] != x[j]));
-                }
-            }
+            red_accumulate<E>(x, shift, pass_full, i4, n, acc_sum[r], acc_sq[r], acc_min[r], acc_max[r], nan_mask[r]);
         }
     }
 
     // ---- workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup
-    if constexpr (NRED > 0) {
-        __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
-        __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int r = 0; r < NRED; ++r) {
-            double s1 = acc_sum[r], s2 = acc_sq[r];
-            float mn = acc_min[r], mx = acc_max[r];
-            if (nan_mask[r] != 0ull) { mn = __builtin_nanf(""); mx = mn; }      // wave-uniform
-            wave_reduce(s1, s2, mn, mx);
-            if (lane == 63) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int r = 0; r < NRED; ++r) {
-                double s1 = lds_sum[r][0], s2 = lds_sq[r][0];
-                float mn = lds_min[r][0], mx = lds_max[r][0];
-#pragma unroll
-                for (int wv = 1; wv < FM_BLOCK / 64; ++wv) {
-                    s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
-                    mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
-                }
-                double* __restrict__ out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
-                out[0] = s1; out[1] = s2; out[2] = (double)mn; out[3] = (double)mx;
-            }
-        }
-    }
+    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row);
 }
 
 // Deterministic second stage: one workgroup per (row, reduction) sums the block partials in a fixed order.

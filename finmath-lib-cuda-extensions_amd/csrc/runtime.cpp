@@ -106,6 +106,13 @@ void Engine::init(int device_index) {
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     ring_off_ = 0;
     device_ = device_index;
+    if (const char* e = std::getenv("FMHIP_JIT")) {
+        const std::string v(e);
+        if (v == "off" || v == "0") jit_mode = FMHIP_JIT_OFF;
+        else if (v == "sync" || v == "2") jit_mode = FMHIP_JIT_SYNC;
+        else if (v == "auto" || v == "1") jit_mode = FMHIP_JIT_AUTO;
+    }
+    jit_.start(device_index);
     initialized_ = true;
 }
 
@@ -113,6 +120,7 @@ void Engine::shutdown() {
     if (!initialized_) return;
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
+    jit_.stop();                        // joins the compiler thread, unloads the specialised kernels
     for (auto& kv : nodes_) {           // leak-safe teardown: free storage of every live vector
         Node* nd = kv.second;
         if (nd->buf && --nd->buf->refs == 0) {
@@ -495,6 +503,8 @@ Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const 
 
 // ---------------------------------------------------------------- launch
 
+static const double JIT_HOT_WORK = 1e11;    // element-ops on the interpreter before a lazy program is queued for specialisation
+
 void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments)
 {
     const int batch = (int)rows.size();
@@ -567,7 +577,21 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
             hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate");
             hip_check(hipEventRecord(ev0, stream_), "hipEventRecord");
         }
-        hip_check(launch_program(args, dev_rows, (double*)partials, (uint32_t)bpr, (uint32_t)batch, stream_), "launch fm_program_kernel");
+        // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
+        // (≈50 ms of device time: a compilation costs ≈1 s of one host core); explicit programs at creation.
+        if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
+            p->interpreted_work += (double)n * batch * p->n_ops;
+            if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
+        } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
+            p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
+        if (jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY) {
+            const uint64_t* rows_arg = dev_rows; double* partials_arg = (double*)partials;
+            void* params[] = { &args, &rows_arg, &partials_arg };
+            hip_check(hipModuleLaunchKernel(batch == 1 ? p->jit->fn_inline : p->jit->fn_table, (unsigned)bpr, (unsigned)batch, 1, FM_BLOCK, 1, 1,
+                                            0, stream_, params, nullptr), "launch specialised kernel");
+            n_jit_launches_++;
+        } else
+            hip_check(launch_program(args, dev_rows, (double*)partials, (uint32_t)bpr, (uint32_t)batch, stream_), "launch fm_program_kernel");
         if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
         if (n_red > 0) {
@@ -871,9 +895,19 @@ fmhip_program Engine::program_create(const fmhip_prog_op* ops, int n_ops, int n_
     std::vector<SsaOp> s(n_ops);
     for (int i = 0; i < n_ops; ++i) s[i] = { ops[i].opcode, ops[i].a, ops[i].b, ops[i].c, ops[i].scalar };
     Program* p = compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr, true);
+    if (jit_mode != FMHIP_JIT_OFF) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);    // explicit = declared hot
     const int64_t id = next_id_++;
     programs_[id] = p;
     return id;
+}
+
+std::string Engine::program_source(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out, const int32_t* reds, int n_red) {
+    if (n_ops < 0 || n_out < 0 || n_red < 0 || (n_ops > 0 && !ops) || (n_out > 0 && !outs) || (n_red > 0 && !reds))
+        throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad program description");
+    std::vector<SsaOp> s(n_ops);
+    for (int i = 0; i < n_ops; ++i) s[i] = { ops[i].opcode, ops[i].a, ops[i].b, ops[i].c, ops[i].scalar };
+    std::unique_ptr<Program> p(compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr, true));
+    return jit_generate_source(p->proto);
 }
 
 Program* Engine::program(fmhip_program h) {

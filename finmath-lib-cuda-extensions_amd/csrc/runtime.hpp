@@ -23,6 +23,7 @@
 
 #include "../../include/fmhip.h"
 #include "fm_program.h"
+#include "jit.hpp"
 
 namespace fm {
 
@@ -76,6 +77,9 @@ struct Program {
     DevProgramArgs proto{};                 // ops / out_reg / red_reg / counts filled in
     std::vector<float> scalars;             // default scalar operands (explicit API)
     int refs = 1;
+    // execution tier (jit.hpp): work done on the interpreter so far, and the specialised kernel once requested
+    double interpreted_work = 0.0;          // elements x micro-ops
+    std::shared_ptr<JitSlot> jit;
 };
 
 struct SsaOp { int opcode; int a, b, c; double scalar; };
@@ -118,6 +122,11 @@ public:
     fmhip_program program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,
                                  const int32_t* reds, int n_red);
     void program_release(fmhip_program p);
+    std::string program_source(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out, const int32_t* reds, int n_red);
+    int jit_mode = FMHIP_JIT_AUTO;
+    void jit_wait() { jit_.wait_idle(); }
+    JitStats jit_stats() { return jit_.stats(); }
+    int64_t jit_launches() const { return n_jit_launches_; }
     Program* program(fmhip_program p);
     void program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
                      const double* shifts, fmhip_moments* moments, void* dev_moments);
@@ -141,12 +150,13 @@ private:
     int device_ = -1;
     hipStream_t stream_ = nullptr;
     Pool pool_;
+    Jit jit_;
     int64_t next_id_ = 1;
     std::unordered_map<int64_t, Node*> nodes_;
     std::unordered_set<Node*> pending_;                          // nodes without storage (lazy expressions)
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
-    int64_t n_launches_ = 0, n_ops_executed_ = 0;
+    int64_t n_launches_ = 0, n_ops_executed_ = 0, n_jit_launches_ = 0;
     uint64_t epoch_ = 0;
     bool profiling_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events_;

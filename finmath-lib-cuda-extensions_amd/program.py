@@ -39,12 +39,32 @@ class Program:
     def reduce(self, value: int) -> None:
         self.reduces.append(value)
 
-    def compile(self) -> "Program":
+    def _description(self):
         arr = (N.ProgOp * max(1, len(self.ops)))()
         for i, (code, a, b, c, s) in enumerate(self.ops):
             arr[i] = N.ProgOp(code, a, b, c, s)
         outs = (C.c_int32 * max(1, len(self.outputs)))(*self.outputs)
         reds = (C.c_int32 * max(1, len(self.reduces)))(*self.reduces)
+        return arr, outs, reds
+
+    def source(self) -> str:
+        """Generated HIP source of the specialised (JIT tier) kernel pair of this op stream; needs no device."""
+        arr, outs, reds = self._description()
+        need = C.c_int64(0)
+        args = (arr, len(self.ops), self.n_inputs, outs, len(self.outputs), reds, len(self.reduces))
+        N.check(N.lib().fmhip_program_source(*args, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        N.check(N.lib().fmhip_program_source(*args, buf, need.value + 1, C.byref(need)))
+        return buf.value.decode()
+
+    def tier(self):
+        """(tier, vgprs): tier 0 = interpreter, 1 = specialised kernel ready."""
+        t, v = C.c_int32(0), C.c_int32(0)
+        N.check(N.lib().fmhip_program_tier(self.handle, C.byref(t), C.byref(v)))
+        return t.value, v.value
+
+    def compile(self) -> "Program":
+        arr, outs, reds = self._description()
         h = C.c_int64(0)
         N.check(N.lib().fmhip_program_create(arr, len(self.ops), self.n_inputs, outs, len(self.outputs),
                                              reds, len(self.reduces), C.byref(h)))

@@ -246,6 +246,27 @@ int fmhip_program_run_into(fmhip_program p, int batch,
                            const fmhip_vec* inputs, const fmhip_vec* outputs,
                            const double* reduce_shift, fmhip_moments* moments, void* device_moments);
 
+/* ---------------------------------------------------------------- execution tiers
+ * A compiled program (explicit, or built by the lazy front-end) starts on the bytecode interpreter kernel and may be
+ * promoted to a SPECIALISED kernel: straight-line gfx950 code generated from its op stream and compiled at run time
+ * (hiprtc) on a background thread.  Both tiers are built from the same device functions with the same floating-point
+ * flags and give bit-identical results.  The reference has no counterpart (one precompiled PTX kernel per method,
+ * RandomVariableCuda.java:78-117, :539-557). */
+#define FMHIP_JIT_OFF  0     /* interpreter only */
+#define FMHIP_JIT_AUTO 1     /* default: explicit programs at creation, lazy programs once they are hot; asynchronous */
+#define FMHIP_JIT_SYNC 2     /* compile before the first launch (deterministic tier: tests, benchmarks) */
+/* Default from the environment variable FMHIP_JIT = off | auto | sync. */
+int fmhip_set_jit(int mode, int* previous);
+/* Blocks until every queued compilation has finished. */
+int fmhip_jit_wait(void);
+int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds);
+/* *tier: 0 = interpreter, 1 = specialised kernel ready (the next launch uses it); *vgprs = its register count. */
+int fmhip_program_tier(fmhip_program program, int* tier, int* vgprs);
+/* The generated source of a program's specialised kernel (needs no device).  Copies at most `capacity` bytes
+ * including the terminating 0 and stores the full length (without the 0) in *needed. */
+int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, const int32_t* out_values, int n_outputs,
+                         const int32_t* reduce_values, int n_reduce, char* buffer, int64_t capacity, int64_t* needed);
+
 /* ---------------------------------------------------------------- Brownian increments */
 
 /* Fill n_steps*n_factors new vectors of n_paths N(0, dt_step) increments:

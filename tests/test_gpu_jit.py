@@ -1,0 +1,202 @@
+"""Execution tiers (include/fmhip.h "execution tiers"): every compiled program runs either on the bytecode interpreter
+kernel or on a specialised kernel generated from its op stream and compiled with hiprtc.  The two tiers must be
+BIT-IDENTICAL (outputs and fused moments), and both equal to the oracle."""
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def dv(gpu, arr):
+    return gpu.DeviceVector.from_host(np.asarray(arr, dtype=np.float32))
+
+
+@pytest.fixture()
+def tiers(gpu):
+    """Runs `fn` once per tier and returns both results; restores the mode."""
+    def run(fn):
+        prev = gpu.set_jit(gpu.JIT_OFF)
+        try:
+            a = fn()
+            gpu.set_jit(gpu.JIT_SYNC)
+            b = fn()
+        finally:
+            gpu.set_jit(prev)
+        return a, b
+    return run
+
+
+def inputs(oracle, n, seed=1):
+    x = oracle.f_from_double(oracle.java_random_doubles(seed, n))
+    y = oracle.f_from_double(oracle.java_random_doubles(seed + 1, n) + 0.5)
+    z = oracle.f_from_double(oracle.java_random_doubles(seed + 2, n) - 0.5)
+    return x, y, z
+
+
+def stream_s(gpu):
+    p = gpu.Program(3)
+    x, y, z = 0, 1, 2
+    t = p.op("SUB", p.op("MULT", p.op("DIV_S", p.op("ADD_S", x, s=4.0), s=2.0), y), z)
+    u = p.op("SQRT", p.op("ABS", p.op("LOG", p.op("EXP", t))))
+    v = p.op("ADDPRODUCT", p.op("FLOOR_S", p.op("CAP_S", u, s=1.5), s=0.25), y, z)
+    w = p.op("CHOOSE", t, v, x)
+    p.output(w)
+    p.reduce(w)
+    return p
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 2048, 2049, 8192, 100003])
+def test_stream_s_tiers_identical(gpu, oracle, tiers, n):
+    x, y, z = inputs(oracle, n)
+
+    def run():
+        p = stream_s(gpu).compile()
+        rows = [[dv(gpu, x), dv(gpu, y), dv(gpu, z)], [dv(gpu, y), dv(gpu, x), dv(gpu, z)]]
+        outs, m = p.run(rows, shifts=[0.125])
+        return [o[0].to_float32() for o in outs], m, p.tier()[0]
+
+    (o0, m0, t0), (o1, m1, t1) = tiers(run)
+    assert t0 == 0 and t1 == 1                      # the second run really used the specialised kernel
+    for a, b in zip(o0, o1):
+        assert_bits_equal(a, b, f"tier outputs n={n}")
+    assert m0.tobytes() == m1.tobytes()             # same accumulation order, same combine: identical fp64 moments
+
+
+SINGLE = [("SQUARED", 1, False), ("SQRT", 1, False), ("EXP", 1, False), ("LOG", 1, False), ("INVERT", 1, False), ("ABS", 1, False),
+          ("SIN", 1, False), ("COS", 1, False), ("ISNAN", 1, False),
+          ("CAP_S", 1, True), ("FLOOR_S", 1, True), ("ADD_S", 1, True), ("SUB_S", 1, True), ("BUS_S", 1, True), ("MULT_S", 1, True),
+          ("DIV_S", 1, True), ("VID_S", 1, True), ("POW_S", 1, True),
+          ("CAP", 2, False), ("FLOOR", 2, False), ("ADD", 2, False), ("SUB", 2, False), ("MULT", 2, False), ("DIV", 2, False),
+          ("ACCRUE", 2, True), ("DISCOUNT", 2, True), ("ADDPRODUCT_VS", 2, True),
+          ("ADDPRODUCT", 3, False), ("ADDRATIO", 3, False), ("SUBRATIO", 3, False), ("CHOOSE", 3, False)]
+
+
+@pytest.mark.parametrize("name,nvec,has_s", SINGLE)
+def test_every_opcode_tiers_identical_and_match_oracle(gpu, oracle, tiers, name, nvec, has_s):
+    """One program per opcode, with the operand first as the accumulator and then as a register operand
+    (both micro-op forms _A/_B), on seeded data plus IEEE edge values."""
+    n = 20011
+    x, y, z = inputs(oracle, n, seed=7)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754942e-38, 3.4028235e38, 88.0, -104.0, 0.5, 2.0],
+                    dtype=np.float32)
+    x[:edge.size] = edge; y[:edge.size] = edge[::-1]; z[:edge.size] = np.roll(edge, 3)
+    s = 1.0 / 3.0
+
+    def run():
+        res = []
+        for order in range(2):
+            p = gpu.Program(3)
+            a = p.op("ADD_S", 0, s=0.0) if order == 0 else 0        # order 0: first operand comes out of the accumulator
+            b = p.op("ADD_S", 1, s=0.0) if order == 1 else 1
+            args = [a, b, 2][:nvec]
+            w = p.op(name, *args, s=s) if has_s else p.op(name, *args)
+            p.output(w); p.reduce(w)
+            p.compile()
+            outs, m = p.run([[dv(gpu, x), dv(gpu, y), dv(gpu, z)]])
+            res.append((outs[0][0].to_float32(), m))
+        return res
+
+    with np.errstate(all="ignore"):
+        r0, r1 = tiers(run)
+        for (o0, m0), (o1, m1) in zip(r0, r1):
+            assert_bits_equal(o0, o1, name)
+            assert m0.tobytes() == m1.tobytes()
+        # and against the oracle (x + 0.0 is not the identity for -0.0: apply it on the oracle side too)
+        xa = oracle.f_v1s1("ADD_S", x, 0.0)
+        if nvec == 1:
+            want = oracle.f_v1s1(name, xa, s) if has_s else oracle.f_v1s0(name, xa)
+        elif nvec == 2:
+            want = oracle.f_v2s1(name, xa, y, s) if has_s else oracle.f_v2s0(name, xa, y)
+        else:
+            want = oracle.f_v3s0(name, xa, y, z)
+        got = r1[0][0]
+        if name in ("EXP", "LOG", "SIN", "COS", "POW_S"):
+            ia, ib = got.view(np.int32).astype(np.int64), want.view(np.int32).astype(np.int64)
+            ok = (np.abs(ia - ib) <= 1) | (np.isnan(got) & np.isnan(want))
+            assert ok.all() and ((ia != ib) & ~np.isnan(got)).mean() <= 1e-4, name
+        else:
+            assert_bits_equal(got, want, name)
+
+
+def test_many_live_values_program(gpu, oracle, tiers):
+    """A wide program (4-element / 16-register variant: 10 live values, 3 outputs, 2 reductions)."""
+    n = 30001
+    x, y, z = inputs(oracle, n, seed=11)
+
+    def run():
+        p = gpu.Program(3)
+        vals = [p.op("ADD_S", 0, s=float(k)) for k in range(10)]
+        acc = vals[0]
+        for k in range(1, 10):
+            acc = p.op("ADDPRODUCT", acc, vals[k], 1 if k % 2 else 2)
+        e = p.op("EXP", p.op("MULT_S", acc, s=0.01))
+        q = p.op("DIV", e, vals[3])
+        p.output(acc); p.output(e); p.output(q)
+        p.reduce(e); p.reduce(q)
+        p.compile()
+        outs, m = p.run([[dv(gpu, x), dv(gpu, y), dv(gpu, z)]], shifts=[0.0, 1.5])
+        return [o.to_float32() for o in outs[0]], m
+
+    (o0, m0), (o1, m1) = tiers(run)
+    for a, b in zip(o0, o1):
+        assert_bits_equal(a, b, "wide program")
+    assert m0.tobytes() == m1.tobytes()
+
+
+def test_lazy_front_end_on_specialised_kernels(gpu, oracle):
+    """RandomVariable-style lazy chains with JIT_SYNC: every fused launch runs a specialised kernel; results as the oracle."""
+    n = 50021
+    x, y, z = inputs(oracle, n, seed=21)
+    prev_jit = gpu.set_jit(gpu.JIT_SYNC)
+    prev_fusion = gpu.set_fusion(True)
+    try:
+        before = gpu.jit_stats()
+        a, b = dv(gpu, x), dv(gpu, y)
+        r = a.v1s1("ADD_S", 4.0).v2s0("DIV", b).v1s0("SQUARED").v3s0("ADDPRODUCT", a, b).v1s1("FLOOR_S", 0.5)
+        got = r.to_float32()
+        m = r.moments(0.0)
+        after = gpu.jit_stats()
+    finally:
+        gpu.set_fusion(prev_fusion)
+        gpu.set_jit(prev_jit)
+    t = oracle.f_v1s1("ADD_S", x, 4.0); t = oracle.f_v2s0("DIV", t, y); t = oracle.f_v1s0("SQUARED", t)
+    t = oracle.f_v3s0("ADDPRODUCT", t, x, y); want = oracle.f_v1s1("FLOOR_S", t, 0.5)
+    assert_bits_equal(got, want, "lazy chain on the specialised tier")
+    assert after["compiled"] > before["compiled"] and after["failed"] == 0
+    assert abs(m.sum - float(np.sum(want.astype(np.float64)))) <= 1e-9 * abs(m.sum)
+
+
+def test_auto_mode_promotes_explicit_programs_in_the_background(gpu, oracle):
+    n = 4099
+    x, y, z = inputs(oracle, n, seed=31)
+    prev = gpu.set_jit(gpu.JIT_AUTO)
+    try:
+        p = stream_s(gpu).compile()                 # queued at creation, does not block
+        rows = [[dv(gpu, x), dv(gpu, y), dv(gpu, z)]]
+        outs0, m0 = p.run(rows)                     # whichever tier is ready
+        gpu.jit_wait()
+        assert p.tier()[0] == 1 and p.tier()[1] > 0
+        outs1, m1 = p.run(rows)
+        assert_bits_equal(outs0[0][0].to_float32(), outs1[0][0].to_float32(), "auto mode")
+        assert m0.tobytes() == m1.tobytes()
+        assert gpu.jit_stats()["failed"] == 0 and gpu.jit_stats()["pending"] == 0
+    finally:
+        gpu.set_jit(prev)
+
+
+def test_fast_math_programs_specialise_too(gpu, oracle, tiers):
+    n = 10007
+    x, y, z = inputs(oracle, n, seed=41)
+    prev = gpu.set_math_mode(gpu.MATH_FAST)
+    try:
+        def run():
+            p = stream_s(gpu).compile()
+            outs, m = p.run([[dv(gpu, x), dv(gpu, y), dv(gpu, z)]])
+            return outs[0][0].to_float32(), m
+        (o0, m0), (o1, m1) = tiers(run)
+    finally:
+        gpu.set_math_mode(prev)
+    assert_bits_equal(o0, o1, "fast math tiers")
+    assert m0.tobytes() == m1.tobytes()
