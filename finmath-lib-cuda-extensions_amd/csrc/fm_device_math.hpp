@@ -43,7 +43,7 @@ __device__ __forceinline__ double jpow(double x, double y) {
 }
 
 // ---- exp: fp64 evaluation for an fp32 argument, narrowed once (`(float)Math.exp(realizations[i])`, twin :905).
-// x = k·ln2 + r, |r| <= ln2/2;  e^r by a degree-11 Taylor polynomial (truncation 0.3466^12/12! = 2^-47);
+// x = k·ln2 + r, |r| <= ln2/2;  e^r by a degree-10 near-minimax polynomial (2^-48.6);
 // 2^k applied with ldexp; the final fp64→fp32 conversion rounds once (RNE, denormals honoured).
 // 17 fp64 instructions instead of the ≈45 of the generic library exp — exp/log dominate the VALU budget of a
 // fused stream, and the kernel has to stay under the HBM roofline.
@@ -58,60 +58,68 @@ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 
 __device__ __forceinline__ float exp_f(float a) {
     // clamp in fp32 (one v_med3_f32): ±inf and huge arguments give 0 / +inf anyway, and k stays a small integer
-    double x = (double)__builtin_amdgcn_fmed3f(a, -110.0f, 90.0f);
-    const double k = __builtin_rint(x * 1.4426950408889634);       // log2(e)
+    const double x = (double)__builtin_amdgcn_fmed3f(a, -110.0f, 90.0f);
+    // k = round(x·log2 e) by the 1.5·2^52 trick: after the addition the integer sits in the low mantissa bits (two's
+    // complement), so the int for ldexp is the low dword of t — no v_rndne_f64 / v_cvt_i32_f64.
+    const double t = __builtin_fma(x, 1.4426950408889634, 6755399441055744.0);
+    const double k = t - 6755399441055744.0;
+    const int ki = (int)(uint32_t)__double_as_longlong(t);
     double r = __builtin_fma(k, -6.93147180369123816490e-01, x);   // ln2 hi (low 32 bits zero: k*hi exact)
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);          // ln2 lo
-    double p = 2.50521083854417187751e-08;                         // 1/11!
-    p = fma_c(p, r, 2.75573192239858906526e-07);                   // 1/10!
-    p = fma_c(p, r, 2.75573192239858906526e-06);                   // 1/9!
-    p = fma_c(p, r, 2.48015873015873015873e-05);                   // 1/8!
-    p = fma_c(p, r, 1.98412698412698412698e-04);                   // 1/7!
-    p = fma_c(p, r, 1.38888888888888888889e-03);                   // 1/6!
-    p = fma_c(p, r, 8.33333333333333333333e-03);                   // 1/5!
-    p = fma_c(p, r, 4.16666666666666666667e-02);                   // 1/4!
-    p = fma_c(p, r, 1.66666666666666666667e-01);                   // 1/3!
+    // e^r = 1 + r + r²/2 + r³·q(r): q = near-minimax polynomial of degree 7 on |r| <= 0.3468 (tools/minimax_coefficients.py;
+    // relative error of e^r 2^-48.6 — one Horner step less than the degree-11 Taylor tail, and 3x more accurate)
+    double p = 0x1.286f24b3f714bp-22;
+    p = fma_c(p, r, 0x1.72ad803971e4dp-19);
+    p = fma_c(p, r, 0x1.a019d81272de4p-16);
+    p = fma_c(p, r, 0x1.a019c3487562dp-13);
+    p = fma_c(p, r, 0x1.6c16c17016625p-10);
+    p = fma_c(p, r, 0x1.1111111710d7bp-7);
+    p = fma_c(p, r, 0x1.5555555555369p-5);
+    p = fma_c(p, r, 0x1.5555555554f90p-3);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    const float res = (float)__builtin_ldexp(p, (int)k);
+    const float res = (float)__builtin_ldexp(p, ki);
     return (a != a) ? a : res;
 }
 
 // ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).
 // x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) with an fp32 reciprocal seed and ONE Newton step (relative
-// error 2^-44: no fp64 division);  log m = 2s·(1 + z/3 + z²/5 + … + z^8/17), z = s² <= 0.0295 (truncation 2^-50).
-// Zero, negative, infinite and NaN arguments take the hardware v_log_f32 result, which has exactly the IEEE special
-// values needed (-inf, NaN, +inf, NaN): one class test + one select instead of four compare/select pairs.
+// error 2^-44: no fp64 division);  log m = 2s·(1 + z·g(z)), z = s² <= 0.0295, g of degree 5 (2^-50).
+// Zero, negative, infinite and NaN arguments take the hardware v_log_f32 of the mantissa, which has exactly the IEEE
+// special values needed (-inf, NaN, +inf, NaN): one class test + one select instead of four compare/select pairs.
 __device__ __forceinline__ float log_f(float a) {
-    const double x = (double)a;                                     // denormal floats become normal doubles
-    double m = __builtin_amdgcn_frexp_mant(x);                      // [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;
+    // mantissa/exponent split and the centring on [sqrt(1/2), sqrt(2)) in fp32 (denormals are honoured by v_frexp_*_f32,
+    // every step is exact), then everything else in fp64
+    float m32 = __builtin_amdgcn_frexp_mantf(a);                    // [0.5, 1), sign of a; ±0, ±inf, NaN pass through
+    int e = __builtin_amdgcn_frexp_expf(a);
+    const float lg = __builtin_amdgcn_logf(m32);                    // used only for the special cases below
+    const bool lo = m32 < 0.70710678f;
+    m32 = lo ? m32 + m32 : m32;
     e = lo ? e - 1 : e;
+    const double m = (double)m32;
     const double f = m - 1.0;                                       // exact
     const double d = m + 1.0;                                       // exact (m carries <= 24 significant bits)
-    const double q0 = (double)__builtin_amdgcn_rcpf((float)d);      // ≈ 1/d, 2^-22
+    const double q0 = (double)__builtin_amdgcn_rcpf(m32 + 1.0f);    // ≈ 1/d, 2^-22 (a seed: the fp32 sum need not be exact)
     const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);   // Newton: 2^-44
     const double s = f * q1;
     const double z = s * s;
-    double p = 1.0 / 17.0;
-    p = fma_c(p, z, 1.0 / 15.0);
-    p = fma_c(p, z, 1.0 / 13.0);
-    p = fma_c(p, z, 1.0 / 11.0);
-    p = fma_c(p, z, 1.0 / 9.0);
-    p = fma_c(p, z, 1.0 / 7.0);
-    p = fma_c(p, z, 1.0 / 5.0);
-    p = fma_c(p, z, 1.0 / 3.0);
+    // log m = 2s·(1 + z·g(z)): g = near-minimax polynomial of degree 5 on [0, 0.02945] (tools/minimax_coefficients.py;
+    // relative error of log m 2^-50.4, well under the 2^-44 of the Newton reciprocal) instead of 1/3 + z/5 + … + z^7/17
+    double p = 0x1.546d249f36cb2p-4;
+    p = fma_c(p, z, 0x1.7382a9fa2e7aep-4);
+    p = fma_c(p, z, 0x1.c71fcdfe2f300p-4);
+    p = fma_c(p, z, 0x1.249246299fc8ep-3);
+    p = fma_c(p, z, 0x1.9999999b878d7p-3);
+    p = fma_c(p, z, 0x1.55555555553b7p-2);
     const double s2 = s + s;
     const double lm = __builtin_fma(s2, p * z, s2);
     const double ed = (double)e;
     const double r = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
-    // class mask: sNaN|qNaN|-inf|-normal|-denormal|-0|+0|+inf = everything except +denormal (0x080) and +normal (0x100)
+    // class mask: sNaN|qNaN|-inf|-normal|-denormal|-0|+0|+inf = everything except +denormal (0x080) and +normal (0x100).
+    // For those arguments log2 of the MANTISSA (negative → NaN, ±0 → -inf, +inf → +inf, NaN → NaN) is exactly the IEEE result.
     const bool special = __builtin_amdgcn_classf(a, 0x27f);
-    // (scaled by 2^64 first: v_log_f32 flushes denormal inputs, which would turn log(-denormal) = NaN into -inf)
-    return special ? __builtin_amdgcn_logf(a * 0x1p+64f) : (float)r;
+    return special ? lg : (float)r;
 }
 
 // ---- FAST math mode (fmhip_set_math_mode(FMHIP_MATH_FAST)): exp and log on the hardware transcendental unit

@@ -60,6 +60,8 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
                                                unsigned long long& nan_mask)
 {
     if (pass_full && shift == 0.0) {        // getAverage / first pass of getVariance: no subtraction
+        // No per-element NaN test here: Σx² is NaN exactly when some x is NaN (inf² = +inf, and a sum of non-negative
+        // terms cannot produce one otherwise); red_finish() reads that off the accumulator once per workgroup.
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const double dv = (double)x[j];
@@ -67,7 +69,6 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
             acc_sq = __builtin_fma(dv, dv, acc_sq);
             acc_min = hw_min(acc_min, x[j]);
             acc_max = hw_max(acc_max, x[j]);
-            nan_mask |= __ballot(x[j] != x[j]);
         }
     } else if (pass_full) {
 #pragma unroll
@@ -91,6 +92,13 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
             nan_mask |= __ballot(ok && (x[j] != x[j]));
         }
     }
+}
+
+// After the last pass of a workgroup: NaN detection of the unshifted fast path (see red_accumulate).  With a shift the
+// accumulator can also be NaN from inf - inf, so those paths keep their per-element test.
+__device__ __forceinline__ void red_finish(const double shift, const double acc_sq, unsigned long long& nan_mask)
+{
+    if (shift == 0.0) nan_mask |= __ballot(acc_sq != acc_sq);
 }
 
 // Workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup and reduction:
