@@ -126,6 +126,9 @@ def lmm_workload(args):
                        "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
                        "rms_deviation": r["rms_deviation"], "mean_deviation": r["mean_deviation"],
                        "acceptance": "abs(mean deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
+                       "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
+                       "specialisations_pending_at_exit": r.get("specialisations_pending"),
+                       "specialisation_seconds": r.get("specialisation_seconds"),
                        "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"], "process_wall_s": wall},
             "roofline": None}
     if not args.no_cpu_baseline and world == 1:

@@ -82,9 +82,9 @@ def jit_wait() -> None:
 
 
 def jit_stats() -> dict:
-    c, f, p, s = _C.c_int64(0), _C.c_int64(0), _C.c_int64(0), _C.c_double(0)
-    _native.check(lib().fmhip_jit_stats(_C.byref(c), _C.byref(f), _C.byref(p), _C.byref(s)))
-    return {"compiled": c.value, "failed": f.value, "pending": p.value, "compile_seconds": s.value}
+    c, f, p, s, d = _C.c_int64(0), _C.c_int64(0), _C.c_int64(0), _C.c_double(0), _C.c_int64(0)
+    _native.check(lib().fmhip_jit_stats(_C.byref(c), _C.byref(f), _C.byref(p), _C.byref(s), _C.byref(d)))
+    return {"compiled": c.value, "failed": f.value, "pending": p.value, "compile_seconds": s.value, "disk_cache_hits": d.value}
 
 
 def flush() -> None:

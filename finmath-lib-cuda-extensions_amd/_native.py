@@ -105,7 +105,7 @@ def lib():
         "fmhip_bm_generate_mersenne": [C.c_int32, i32, i32, i64, C.POINTER(dbl), pv],
         "fmhip_pool_clean": [], "fmhip_pool_purge": [], "fmhip_pool_stats": [C.POINTER(PoolStats)],
         "fmhip_set_jit": [i32, C.POINTER(i32)], "fmhip_jit_wait": [],
-        "fmhip_jit_stats": [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl)],
+        "fmhip_jit_stats": [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl), C.POINTER(i64)],
         "fmhip_program_tier": [i64, C.POINTER(i32), C.POINTER(i32)],
         "fmhip_program_source": [C.POINTER(ProgOp), i32, i32, C.POINTER(i32), i32, C.POINTER(i32), i32, C.c_char_p, i64, C.POINTER(i64)],
         "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],

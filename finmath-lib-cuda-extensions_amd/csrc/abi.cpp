@@ -146,13 +146,14 @@ int fmhip_jit_wait(void) {
     // not under the engine mutex: other threads keep launching while this one waits for the compiler thread
     try { Engine::get().jit_wait(); return FMHIP_OK; } catch (...) { return FMHIP_ERR_HIP; }
 }
-int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds) {
+int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds, int64_t* disk_cache_hits) {
     return guarded([&] {
         const fm::JitStats s = Engine::get().jit_stats();
         if (compiled) *compiled = s.compiled;
         if (failed) *failed = s.failed;
         if (pending) *pending = s.pending;
         if (compile_seconds) *compile_seconds = s.seconds;
+        if (disk_cache_hits) *disk_cache_hits = s.disk_hits;
     });
 }
 int fmhip_program_tier(fmhip_program p, int* tier, int* vgprs) {

@@ -31,10 +31,11 @@ struct JitSlot {
     hipModule_t module = nullptr;
     hipFunction_t fn_inline = nullptr, fn_table = nullptr;      // row block in the kernarg segment / in the row table
     int vgprs = 0;
+    bool from_disk = false;                                     // code object came from the persistent cache
     double compile_seconds = 0.0;
 };
 
-struct JitStats { int64_t compiled = 0, failed = 0, pending = 0; double seconds = 0.0; };
+struct JitStats { int64_t compiled = 0, failed = 0, pending = 0, disk_hits = 0; double seconds = 0.0; };
 
 // Source text of the specialised kernel pair of a program (deterministic: it doubles as the cache key).
 std::string jit_generate_source(const DevProgramArgs& proto);

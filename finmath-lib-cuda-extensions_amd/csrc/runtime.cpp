@@ -503,7 +503,7 @@ Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const 
 
 // ---------------------------------------------------------------- launch
 
-static const double JIT_HOT_WORK = 1e11;    // element-ops on the interpreter before a lazy program is queued for specialisation
+static const double JIT_HOT_WORK = 2e10;    // element-ops on the interpreter before a lazy program is queued for specialisation
 
 void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments)
 {
@@ -578,7 +578,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
             hip_check(hipEventRecord(ev0, stream_), "hipEventRecord");
         }
         // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
-        // (≈50 ms of device time: a compilation costs ≈1 s of one host core); explicit programs at creation.
+        // (≈10 ms of device time: a compilation costs ≈0.2 s of one background host core); explicit programs at creation.
         if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
             p->interpreted_work += (double)n * batch * p->n_ops;
             if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);

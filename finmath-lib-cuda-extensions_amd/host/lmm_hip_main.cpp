@@ -74,11 +74,14 @@ int main(int argc, char** argv) {
         auto extra = [&] {
             fmhip_pool_stats_t s; check(fmhip_pool_stats(&s));
             char name[128] = { 0 }; int cus = 0; int64_t hbm = 0; fmhip_device_info(name, 128, &cus, &hbm);
-            char buf[640];
+            int64_t jc = 0, jf = 0, jp = 0, jd = 0; double js = 0.0; fmhip_jit_stats(&jc, &jf, &jp, &js, &jd);
+            char buf[768];
             std::snprintf(buf, sizeof buf, ", \"kernel_launches\": %lld, \"path_ops\": %.6e, \"device_bytes_reserved\": %lld, \"device\": \"%s\", "
-                          "\"world\": %d, \"rank\": %d, \"total_paths\": %lld, \"rccl_all_reduces\": %lld",
+                          "\"world\": %d, \"rank\": %d, \"total_paths\": %lld, \"rccl_all_reduces\": %lld, "
+                          "\"specialised_kernels\": %lld, \"specialisations_from_disk_cache\": %lld, \"specialisations_pending\": %lld, \"specialisation_seconds\": %.3f",
                           (long long)(s.n_kernel_launches - s0.n_kernel_launches), (double)(s.n_ops_executed - s0.n_ops_executed) * (double)o.paths,
-                          (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives);
+                          (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives,
+                          (long long)jc, (long long)jd, (long long)jp, js);
             return std::string(buf);
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);

@@ -259,7 +259,9 @@ int fmhip_program_run_into(fmhip_program p, int batch,
 int fmhip_set_jit(int mode, int* previous);
 /* Blocks until every queued compilation has finished. */
 int fmhip_jit_wait(void);
-int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds);
+/* compiled = kernels ready (of which disk_cache_hits were loaded from the persistent code-object cache,
+ * $FMHIP_JIT_CACHE_DIR, default ~/.cache/fmhip-jit, "off" disables), compile_seconds = host time spent on them. */
+int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds, int64_t* disk_cache_hits);
 /* *tier: 0 = interpreter, 1 = specialised kernel ready (the next launch uses it); *vgprs = its register count. */
 int fmhip_program_tier(fmhip_program program, int* tier, int* vgprs);
 /* The generated source of a program's specialised kernel (needs no device).  Copies at most `capacity` bytes

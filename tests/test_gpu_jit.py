@@ -200,3 +200,28 @@ def test_fast_math_programs_specialise_too(gpu, oracle, tiers):
         gpu.set_math_mode(prev)
     assert_bits_equal(o0, o1, "fast math tiers")
     assert m0.tobytes() == m1.tobytes()
+
+
+def test_persistent_code_object_cache(tmp_path):
+    """A second PROCESS finds the specialised kernels of the first in $FMHIP_JIT_CACHE_DIR: no recompilation, same bits."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import importlib, sys, json, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "fm = importlib.import_module('finmath-lib-cuda-extensions_amd')\n"
+        "fm.init(0); fm.set_jit(fm.JIT_SYNC)\n"
+        "x = fm.DeviceVector.from_host(np.linspace(0.1, 2.0, 5003, dtype=np.float32))\n"
+        "p = fm.Program(1); w = p.op('LOG', p.op('EXP', p.op('MULT_S', 0, s=1.25))); p.output(w); p.reduce(w); p.compile()\n"
+        "outs, m = p.run([[x]])\n"
+        "print(json.dumps({'stats': fm.jit_stats(), 'sum': float(m[0, 0, 0]), 'bits': int(outs[0][0].to_float32().view(np.uint32).sum())}))\n")
+    env = dict(os.environ, FMHIP_JIT_CACHE_DIR=str(tmp_path))
+    runs = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert runs[0]["stats"]["compiled"] == 1 and runs[0]["stats"]["disk_cache_hits"] == 0
+    assert runs[1]["stats"]["compiled"] == 1 and runs[1]["stats"]["disk_cache_hits"] == 1
+    assert runs[0]["sum"] == runs[1]["sum"] and runs[0]["bits"] == runs[1]["bits"]
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".co")]) == 1
