@@ -158,6 +158,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries the ONE JSON line and nothing else: native libraries (RCCL prints a version banner on the first
+    # communicator) write to file descriptor 1 directly, so fd 1 is pointed at stderr and the line goes to the saved fd.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N …")
@@ -307,7 +312,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
 
     del rows, out_rows
     if use_dist:

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <unordered_set>
@@ -85,6 +86,15 @@ void Engine::require_init() const {
     if (bound_device != device_) { hip_check(hipSetDevice(device_), "hipSetDevice"); bound_device = device_; }
 }
 
+HostProfile g_host_profile;
+void HostProfile::report() const {
+    static const char* names[N_SLOTS] = { "call (record one method)", "release", "flush_all (total)", "  build_dag", "  run_dags (total)", "    launch (total)",
+                                          "      kernel launch API", "      row table upload", "reduce / reduce_batch (total)" };
+    std::fprintf(stderr, "[fmhip host profile]\n");
+    for (int i = 0; i < N_SLOTS; ++i)
+        std::fprintf(stderr, "  %-32s %10lld calls %9.3f s %9.2f us/call\n", names[i], count[i], seconds[i], count[i] ? seconds[i] / count[i] * 1e6 : 0.0);
+}
+
 void Engine::init(int device_index) {
     if (device_index < 0) {
         const char* e = std::getenv("FMHIP_DEVICE_INDEX");
@@ -113,11 +123,13 @@ void Engine::init(int device_index) {
         else if (v == "auto" || v == "1") jit_mode = FMHIP_JIT_AUTO;
     }
     jit_.start(device_index);
+    g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr;
     initialized_ = true;
 }
 
 void Engine::shutdown() {
     if (!initialized_) return;
+    if (g_host_profile.on) g_host_profile.report();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     jit_.stop();                        // joins the compiler thread, unloads the specialised kernels
@@ -235,6 +247,7 @@ void Engine::node_maybe_free(Node* nd) {
 void Engine::retain(fmhip_vec h) { require_init(); node(h)->refs_ext++; }
 
 void Engine::release(fmhip_vec h) {
+    HostTimer timer(HostProfile::RELEASE);
     require_init();
     Node* nd = node(h);
     if (--nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
@@ -507,6 +520,7 @@ static const double JIT_HOT_WORK = 2e10;    // element-ops on the interpreter be
 
 void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments)
 {
+    HostTimer timer(HostProfile::LAUNCH);
     const int batch = (int)rows.size();
     if (batch <= 0) return;
     if (batch > 65535) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch too large");
@@ -556,6 +570,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     }
     if (batch == 1) std::memcpy(args.inline_row, table, rw * 8);
     else {
+        HostTimer t2(HostProfile::ROW_UPLOAD);
         hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, table, table_bytes, hipMemcpyHostToDevice, stream_), "row table H2D");
         dev_rows = (const uint64_t*)((char*)ring_dev_ + ring_off);
     }
@@ -584,6 +599,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
             if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
         } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
             p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
+        HostTimer t3(HostProfile::LAUNCH_API);
         if (jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY) {
             const uint64_t* rows_arg = dev_rows; double* partials_arg = (double*)partials;
             void* params[] = { &args, &rows_arg, &partials_arg };
@@ -615,6 +631,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
 static const int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is executed on its own accord
 
 fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
+    HostTimer timer(HostProfile::CALL);
     require_init();
     const OpInfo inf = op_info(opcode);
     if (inf.n_vec == 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown opcode " + std::to_string(opcode));
@@ -652,6 +669,7 @@ struct Engine::Dag {
 // Linearise the pending expressions below `roots` into ONE program (roots may share intermediates: they become
 // several outputs of the same launch).  Returns false when it cannot run as one launch.
 bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
+    HostTimer timer(HostProfile::BUILD_DAG);
     dag.roots = roots;
     const uint64_t ep = ++epoch_;                   // nodes with mark == ep have been visited by THIS build
     std::vector<std::pair<Node*, int>> stack;
@@ -709,6 +727,7 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
 
 // Execute structurally identical, mutually independent DAGs as ONE launch (one batch row per DAG).
 bool Engine::run_dags(std::vector<Dag>& dags) {
+    HostTimer timer(HostProfile::RUN_DAGS);
     Dag& d0 = dags[0];
     const int64_t n = d0.roots[0]->n;
     Program* prog = nullptr;
@@ -775,6 +794,7 @@ void Engine::materialize(const std::vector<Node*>& targets) {
 // connected component and run as ONE multi-output launch; components with identical structure (same ops, different
 // vectors and scalars — e.g. all LIBOR components of an Euler step) are batched as rows of one launch.
 void Engine::flush_all() {
+    HostTimer timer(HostProfile::FLUSH);
     require_init();
     for (int round = 0; round < 1000000; ++round) {
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
@@ -856,6 +876,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
 }
 
 void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out) {
+    HostTimer timer(HostProfile::REDUCE);
     require_init();
     if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
     std::vector<Node*> nds((size_t)count);

@@ -12,6 +12,7 @@
 //   one launch per method (:539-557)                  op streams compiled to one launch (Program)
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <mutex>
@@ -188,5 +189,21 @@ private:
 };
 
 void hip_check(hipError_t e, const char* what);
+
+// Host-side time accounting of the front-end (FMHIP_HOST_PROFILE=1 prints the table at shutdown): where the wall time of
+// a launch-bound caller (the LMM calibration: 31 000 method calls and 700 launches per objective evaluation) goes.
+struct HostProfile {
+    enum Slot { CALL, RELEASE, FLUSH, BUILD_DAG, RUN_DAGS, LAUNCH, LAUNCH_API, ROW_UPLOAD, REDUCE, N_SLOTS };
+    bool on = false;
+    double seconds[N_SLOTS] = { 0 };
+    long long count[N_SLOTS] = { 0 };
+    void report() const;
+};
+extern HostProfile g_host_profile;
+struct HostTimer {
+    HostProfile::Slot slot; bool on; std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(HostProfile::Slot s) : slot(s), on(g_host_profile.on) { if (on) t0 = std::chrono::steady_clock::now(); }
+    ~HostTimer() { if (on) { g_host_profile.seconds[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); g_host_profile.count[slot]++; } }
+};
 
 } // namespace fm
