@@ -17,6 +17,7 @@ from ._native import FmhipError, Moments, PoolStats, ProgOp, build
 from .random_variable import OP, DeviceVector, RandomVariableHip, RandomVariableHipFactory
 from .brownian_motion import BrownianMotionHip, BrownianMotionFromMersenneRandomNumbers, TimeDiscretization, mersenne_increments
 from .program import Program
+from .differentiable import RandomVariableDifferentiableAAD, RandomVariableDifferentiableAADFactory
 
 
 def lib():
