@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
                 if (k < (int)n_in) {
                     const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[k]);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) v[t] = p[i4c[t]];
+                    for (int t = 0; t < T; ++t) v[t] = load_stream(p, i4c[t]);
                 }
 #pragma unroll
                 for (int t = 0; t < T; ++t) { R[4 * t + 0][k] = v[t].x; R[4 * t + 1][k] = v[t].y; R[4 * t + 2][k] = v[t].z; R[4 * t + 3][k] = v[t].w; }
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 const f32x4 v = { R[4 * t + 0][reg], R[4 * t + 1][reg], R[4 * t + 2][reg], R[4 * t + 3][reg] };
-                if (lane_valid[t]) q[i4[t]] = v;
+                if (lane_valid[t]) store_stream(q, i4[t], v);
             }
         }
 
@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A)
                 z[j] = v;
             }
         }
-        out[i4] = make_float4(sq * z[0], sq * z[1], sq * z[2], sq * z[3]);
+        // written once, read by a later launch long after it has left the caches (4 GB at config 3): streaming store
+        __builtin_nontemporal_store(f32x4{ sq * z[0], sq * z[1], sq * z[2], sq * z[3] }, reinterpret_cast<f32x4*>(out) + i4);
     }
 }
 

@@ -16,8 +16,10 @@
 // only, so the same model code runs on any implementation — exactly how finmath-lib injects a factory
 // (LIBORMarketModelCalibrationATMTest.java:351-358).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -69,6 +71,14 @@ public:
     virtual RV invert() const = 0;
     virtual RV abs() const = 0;
     virtual RV isNaN() const = 0;
+    virtual RV sin() const = 0;                                     // GPU class throws (:1373-1384); semantics from the twin (:927-954)
+    virtual RV cos() const = 0;
+    // host-side cold paths: the reference sorts / maps on the host as well (:970-1091; twin :473-602, :667-748)
+    virtual RV apply(const std::function<double(double)>& f) const = 0;
+    double getQuantile(double quantile) const;                      // index convention of the GPU class (:983: 1 - quantile)
+    double getQuantileExpectation(double quantileStart, double quantileEnd) const;
+    std::vector<double> getHistogram(const std::vector<double>& intervalPoints) const;                     // :1026-1068
+    std::vector<std::vector<double>> getHistogram(int numberOfPoints, double standardDeviations) const;    // :1070-1091
     // vector operand
     virtual RV cap(const RV& rv) const = 0;
     virtual RV floor(const RV& rv) const = 0;
@@ -233,6 +243,14 @@ public:
     RV invert() const override  { return unary(FMHIP_OP_INVERT, 1.0 / value_); }
     RV abs() const override     { return unary(FMHIP_OP_ABS, std::fabs(value_)); }
     RV isNaN() const override   { return unary(FMHIP_OP_ISNAN, value_ != value_ ? 1.0 : 0.0); }
+    RV sin() const override     { return unary(FMHIP_OP_SIN, std::sin(value_)); }
+    RV cos() const override     { return unary(FMHIP_OP_COS, std::cos(value_)); }
+    RV apply(const std::function<double(double)>& f) const override {       // twin :667-676: map on the host, narrow, new variable
+        if (isDeterministic()) return of(time_, f(value_));
+        std::vector<double> v = getRealizations();
+        for (double& x : v) x = f(x);
+        return of(time_, DeviceVector::fromHost(v), n_);
+    }
 
     // ---- vector operand (:1391-1580)
     RV add(const RV& rv) const override {
@@ -359,6 +377,59 @@ private:
     int priority_;
 };
 
+inline double RandomVariable::getQuantile(double quantile) const {
+    if (isDeterministic()) return doubleValue();
+    const int64_t n = size();
+    if (n == 0) return std::nan("");
+    std::vector<double> v = getRealizations();
+    std::sort(v.begin(), v.end());
+    const int64_t idx = (int64_t)std::floor((double)(n + 1) * (1.0 - quantile) - 1.0 + 0.5);
+    return v[(size_t)std::min(std::max<int64_t>(idx, 0), n - 1)];
+}
+inline double RandomVariable::getQuantileExpectation(double quantileStart, double quantileEnd) const {
+    if (isDeterministic()) return doubleValue();
+    const int64_t n = size();
+    if (n == 0) return std::nan("");
+    if (quantileStart > quantileEnd) return getQuantileExpectation(quantileEnd, quantileStart);
+    std::vector<double> v = getRealizations();
+    std::sort(v.begin(), v.end());
+    auto index = [n](double q) { return std::min(std::max<int64_t>((int64_t)std::floor((double)(n + 1) * q - 1.0 + 0.5), 0), n - 1); };
+    const int64_t i0 = index(quantileStart), i1 = index(quantileEnd);
+    double sum = 0.0;
+    for (int64_t i = i0; i <= i1; ++i) sum += v[(size_t)i];
+    return sum / (double)(i1 - i0 + 1);
+}
+inline std::vector<double> RandomVariable::getHistogram(const std::vector<double>& intervalPoints) const {
+    std::vector<double> hist(intervalPoints.size() + 1, 0.0);
+    if (isDeterministic()) {
+        const double value = doubleValue();
+        for (size_t k = 0; k < intervalPoints.size(); ++k) if (value > intervalPoints[k]) { hist[k] = 1.0; break; }
+        hist[intervalPoints.size()] = 1.0;
+        return hist;
+    }
+    std::vector<double> v = getRealizations();
+    std::sort(v.begin(), v.end());
+    size_t prev = 0;
+    for (size_t k = 0; k < intervalPoints.size(); ++k) {
+        const size_t cur = std::max<size_t>((size_t)(std::upper_bound(v.begin(), v.end(), intervalPoints[k]) - v.begin()), prev);
+        hist[k] = (double)(cur - prev);
+        prev = cur;
+    }
+    hist[intervalPoints.size()] = (double)(v.size() - prev);
+    if (!v.empty()) for (double& h : hist) h /= (double)v.size();
+    return hist;
+}
+inline std::vector<std::vector<double>> RandomVariable::getHistogram(int numberOfPoints, double standardDeviations) const {
+    const double center = getAverage(), radius = standardDeviations * getStandardDeviation(), step = (numberOfPoints - 1) / 2.0;
+    std::vector<double> points((size_t)numberOfPoints), anchors((size_t)numberOfPoints + 1);
+    for (int i = 0; i < numberOfPoints; ++i) {
+        const double alpha = (-(numberOfPoints - 1) / 2.0 + i) / step;
+        points[(size_t)i] = center + alpha * radius;
+        anchors[(size_t)i] = center + alpha * radius - radius / (2 * step);
+    }
+    anchors[(size_t)numberOfPoints] = center + radius + radius / (2 * step);
+    return { anchors, getHistogram(points) };
+}
 inline RV RandomVariable::average() const { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), getAverage()); }
 
 // All expectations of one objective evaluation in ONE launch + ONE read-back (extension beyond the interface: the

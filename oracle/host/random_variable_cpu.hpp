@@ -58,6 +58,14 @@ public:
     RV invert() const override  { return unary(FMHIP_OP_INVERT, 1.0 / value_); }
     RV abs() const override     { return unary(FMHIP_OP_ABS, std::fabs(value_)); }
     RV isNaN() const override   { return unary(FMHIP_OP_ISNAN, value_ != value_ ? 1.0 : 0.0); }
+    RV sin() const override     { return unary(FMHIP_OP_SIN, std::sin(value_)); }
+    RV cos() const override     { return unary(FMHIP_OP_COS, std::cos(value_)); }
+    RV apply(const std::function<double(double)>& f) const override {       // RandomVariableFromFloatArray.java:667-676
+        if (!a_) return of(time_, f(value_));
+        auto out = std::make_shared<std::vector<float>>(a_->size());
+        for (size_t i = 0; i < a_->size(); ++i) (*out)[i] = (float)f((double)(*a_)[i]);
+        return of(time_, out);
+    }
 
     RV add(const RV& rv) const override { return binary(rv, [&] { return rv->add(self()); }, value_ + det(rv), FMHIP_OP_ADD, FMHIP_OP_ADD_S, false); }    // :961
     RV sub(const RV& rv) const override { return binary(rv, [&] { return rv->bus(self()); }, value_ - det(rv), FMHIP_OP_SUB, FMHIP_OP_BUS_S, false); }    // :990

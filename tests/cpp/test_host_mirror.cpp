@@ -95,6 +95,8 @@ int main() {
         { "addProduct_s_xy", [&](const RV& x, const RV& y) { return x->addProduct(y, third); }, false },
         { "choose", [](const RV& x, const RV& y) { return x->sub(0.5)->choose(x, y); }, false }, { "choose_det", [](const RV& x, const RV& y) { return y->choose(x, x->squared()); }, false },
         { "addRatio", [](const RV& x, const RV&) { return x->addRatio(x->add(1.0), x->add(2.0)); }, false }, { "subRatio", [](const RV& x, const RV& y) { return x->subRatio(y, x->add(2.0)); }, false },
+        { "sin", [](const RV& x, const RV&) { return x->sin(); }, true }, { "cos", [](const RV& x, const RV&) { return x->mult(3.0)->cos(); }, true },
+        { "apply", [](const RV& x, const RV&) { return x->apply([](double v) { return v * v + 1.0 / 3.0; })->add(1.0); }, false },
         { "chain", [](const RV& x, const RV& y) { return x->add(4.0)->div(2.0)->mult(y)->sub(x)->squared()->cap(9.0)->floor(0.25)->addProduct(x, y)->discount(x, 0.5); }, false },
     };
     for (int fusion = 0; fusion <= 1; ++fusion) {
@@ -126,6 +128,25 @@ int main() {
         EXPECT(threw, "doubleValue on stochastic throws");
         const std::vector<double> av = getAverages({ xh, xh->squared(), hip.createRandomVariable(1.5) });
         EXPECT(av[0] == xh->getAverage() && av[1] == xh->squared()->getAverage() && av[2] == 1.5, "getAverages");
+    }
+    // host-side cold paths (sort on the host, both back ends through the same interface code)
+    {
+        const RV xh = hip.createRandomVariable(0.0, stream), xc = cpu.createRandomVariable(0.0, stream);
+        for (double q : { 0.0, 0.01, 0.25, 0.5, 0.99, 1.0 }) EXPECT(xh->getQuantile(q) == xc->getQuantile(q), "getQuantile");
+        EXPECT(std::fabs(xh->getQuantile(0.25) - 0.75) < 0.01, "getQuantile uses 1 - quantile (RandomVariableCuda.java:983)");
+        EXPECT(xh->getQuantileExpectation(0.1, 0.6) == xc->getQuantileExpectation(0.1, 0.6) && xh->getQuantileExpectation(0.6, 0.1) == xh->getQuantileExpectation(0.1, 0.6), "getQuantileExpectation");
+        EXPECT(std::fabs(xh->getQuantileExpectation(0.0, 1.0) - xh->getAverage()) < 1e-9, "full-range quantile expectation = average");
+        const std::vector<double> pts = { 0.1, 0.5, 0.9 };
+        const std::vector<double> hh = xh->getHistogram(pts), hc = xc->getHistogram(pts);
+        EXPECT(hh == hc && hh.size() == 4, "getHistogram");
+        EXPECT(std::fabs(hh[0] - 0.1) < 0.01 && std::fabs(hh[1] - 0.4) < 0.01 && std::fabs(hh[3] - 0.1) < 0.01, "histogram of a uniform sample");
+        const auto h2 = xh->getHistogram(5, 2.0);
+        EXPECT(h2.size() == 2 && h2[0].size() == 6 && h2[1].size() == 6, "getHistogram(points, sd)");
+        double total = 0.0; for (double v : h2[1]) total += v;
+        EXPECT(std::fabs(total - 1.0) < 1e-12, "histogram sums to one");
+        const RV det = hip.createRandomVariable(2.5);
+        EXPECT(det->getQuantile(0.3) == 2.5 && det->getQuantileExpectation(0.1, 0.9) == 2.5 && det->sin()->doubleValue() == std::sin(2.5)
+               && det->apply([](double v) { return 2 * v; })->doubleValue() == 5.0, "deterministic cold paths");
     }
     // Brownian motion: identical increments on both back ends
     {
