@@ -38,9 +38,11 @@ def prog(kind, red=True):
     return p.compile()
 import sys as _s
 MODES = [("exact", fm.MATH_EXACT), ("fast", fm.MATH_FAST)]
-for mname, mode in MODES:
+TIERS = [("interpreter", fm.JIT_OFF), ("specialised", fm.JIT_SYNC)]
+for (mname, mode), (tname, tier) in [(m, t) for m in MODES for t in TIERS]:
   fm.set_math_mode(mode)
-  print("math mode", mname)
+  fm.set_jit(tier)
+  print("math mode", mname, "| tier", tname)
   for kind, red in [("copy1", False), ("copy1", True), ("simple12", False), ("simple24", False), ("div1", False), ("sqrt1", False), ("exp1", False), ("log1", False), ("S_noexplog", True), ("S", True), ("S", False)]:
     if mname == "fast" and kind not in ("exp1", "log1", "S"): continue
     p = prog(kind, red)
