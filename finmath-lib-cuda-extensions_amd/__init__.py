@@ -24,9 +24,26 @@ def lib():
     return _native.lib()
 
 
+_atexit_registered = False
+
+
+def _shutdown_at_exit() -> None:
+    # interpreter exit: stop the background compiler thread and release the device before the C runtime's exit handlers run
+    try:
+        if _native._lib is not None and _native._lib.fmhip_is_initialized():
+            _native._lib.fmhip_shutdown()
+    except Exception:
+        pass
+
+
 def init(device_index: int = -1) -> None:
     """Bind this process to one GPU (one rank per GPU). -1: FMHIP_DEVICE_INDEX, LOCAL_RANK, else 0."""
+    global _atexit_registered
     _native.check(lib().fmhip_init(int(device_index)))
+    if not _atexit_registered:
+        import atexit
+        atexit.register(_shutdown_at_exit)
+        _atexit_registered = True
 
 
 def shutdown() -> None:

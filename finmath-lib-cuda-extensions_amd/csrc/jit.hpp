@@ -42,9 +42,10 @@ std::string jit_generate_source(const DevProgramArgs& proto);
 
 class Jit {
 public:
-    ~Jit() { stop(); }
+    ~Jit() { quiesce(); }                                       // static destruction: join only, no HIP calls (fmhip_shutdown unloads)
     void start(int device);
     void stop();                                               // joins the worker, unloads every module
+    void quiesce();                                            // joins the worker only (process exit: no HIP calls)
     // Returns the (shared) slot of this program; compiles synchronously when `sync`, else queues it for the worker.
     std::shared_ptr<JitSlot> request(const DevProgramArgs& proto, bool sync);
     void wait_idle();                                          // until the queue is drained

@@ -138,6 +138,7 @@ public:
     virtual int getNumberOfFactors() const = 0;
     virtual int64_t getNumberOfPaths() const = 0;
     virtual RV getRandomVariableForConstant(double value) const = 0;
+    RV getIncrement(int timeIndex, int factor) const { return getBrownianIncrement(timeIndex, factor); }    // IndependentIncrements (:205-208)
 };
 
 // ------------------------------------------------------------------ helpers shared by implementations
@@ -475,6 +476,12 @@ public:
     int64_t getNumberOfPaths() const override { return paths_; }
     int64_t getSeed() const { return seed_; }
     RV getRandomVariableForConstant(double value) const override { return RandomVariableHip::of(-std::numeric_limits<double>::infinity(), value); }
+    // :131-139 — new, independent generators (nothing is shared: increments are regenerated on first access)
+    std::shared_ptr<BrownianMotionHip> getCloneWithModifiedSeed(int64_t seed) const { return std::make_shared<BrownianMotionHip>(td_, factors_, paths_, seed, offset_); }
+    std::shared_ptr<BrownianMotionHip> getCloneWithModifiedTimeDiscretization(const TimeDiscretization& td) const { return std::make_shared<BrownianMotionHip>(td, factors_, paths_, seed_, offset_); }
+    bool operator==(const BrownianMotionHip& o) const {            // :230-259: same discretisation, factors, paths and seed
+        return factors_ == o.factors_ && paths_ == o.paths_ && seed_ == o.seed_ && offset_ == o.offset_ && td_.asVector() == o.td_.asVector();
+    }
 private:
     void generate() const {
         const int steps = td_.getNumberOfTimeSteps();

@@ -157,6 +157,14 @@ int main() {
             EXPECT(sameBits(bh.getBrownianIncrement(t, f)->getRealizations(), bc.getBrownianIncrement(t, f)->getRealizations(), false)
                    && bh.getBrownianIncrement(t, f)->getFiltrationTime() == td.getTime(t + 1), "brownian increment");
     }
+    {   // clones and equality (BrownianMotionCudaWithRandomVariableCuda.java:131-139, :230-259)
+        TimeDiscretization td(0.0, 2, 0.5);
+        BrownianMotionHip b(td, 1, 1001, 42);
+        auto same = b.getCloneWithModifiedTimeDiscretization(td), other = b.getCloneWithModifiedSeed(43);
+        EXPECT(b == *same && !(b == *other) && other->getSeed() == 43, "clone / equals");
+        EXPECT(sameBits(b.getIncrement(1, 0)->getRealizations(), same->getBrownianIncrement(1, 0)->getRealizations(), false), "clone reproduces the increments");
+        EXPECT(!sameBits(b.getIncrement(1, 0)->getRealizations(), other->getBrownianIncrement(1, 0)->getRealizations(), false), "another seed, other increments");
+    }
     check(fmhip_pool_purge());
     std::printf("%s: %zu operator cases x 2 modes, %d failures\n", failures ? "FAILED" : "OK", cases.size(), failures);
     return failures ? 1 : 0;
