@@ -187,21 +187,37 @@ def main():
     fm.synchronize()
 
     ext_stream = torch.cuda.ExternalStream(fm.stream_ptr(), device=torch.device("cuda", local_rank))
-    partial = torch.zeros(B * 4, dtype=torch.float64, device=f"cuda:{local_rank}")
-    gathered = torch.zeros(world * B * 4, dtype=torch.float64, device=f"cuda:{local_rank}") if use_dist else None
+    dev = f"cuda:{local_rank}"
+    # Two sets of expectation buffers: while the partials of step k travel (RCCL, on its own stream), step k+1 computes.
+    partials = [torch.zeros(B * 4, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathers = [torch.zeros(world * B * 4, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    partial = partials[0]
+    comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    computed = [torch.cuda.Event() for _ in range(2)] if use_dist else None
+    gathered_ev = [None, None]
+    step_no = [0]
 
     def step():
         # one launch: 12 ops over B triples + fused reductions; moments stay on the device
-        prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
-        if use_dist:                     # the single exchange: expectation partials of all ranks
-            with torch.cuda.stream(ext_stream):
-                dist.all_gather_into_tensor(gathered, partial)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if use_dist and gathered_ev[k] is not None and not gathered_ev[k].query():
+            ext_stream.wait_event(gathered_ev[k])            # the buffer pair of step k-2 has not been sent yet (rare): order after it
+        prog.run_into(rows, out_rows, want_moments=False, device_moments=partials[k].data_ptr())
+        if use_dist:                     # the single exchange: expectation partials of all ranks, overlapped with the next step
+            computed[k].record(ext_stream)
+            comm_stream.wait_event(computed[k])
+            with torch.cuda.stream(comm_stream):
+                dist.all_gather_into_tensor(gathers[k], partials[k])
+                gathered_ev[k] = torch.cuda.Event()
+                gathered_ev[k].record(comm_stream)
 
     def barrier_sync():
-        if use_dist:
-            dist.barrier()
-        fm.synchronize()
+        fm.synchronize()                 # this rank's work (runtime stream + collective stream) is done …
         torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()               # … and so is everybody else's
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -221,10 +237,11 @@ def main():
 
     # combined expectations (sanity: finite, and identical on every rank by construction)
     par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
+    last = (step_no[0] - 1) & 1
     if use_dist:
-        comb = par.combine_moments(gathered.view(world, B, 4))
+        comb = par.combine_moments(gathers[last].view(world, B, 4))
     else:
-        comb = partial.view(B, 4)
+        comb = partials[last].view(B, 4)
     mean_w = float((comb[:, 0] / (world * n)).mean().item())
     assert np.isfinite(mean_w)
 
