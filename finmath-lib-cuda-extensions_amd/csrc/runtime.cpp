@@ -551,14 +551,10 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     args.tiles_per_row = (uint32_t)tiles;
     const size_t rw = args.row_words;
     const size_t table_bytes = (size_t)batch * rw * 8;
-    uint64_t* table;
     const uint64_t* dev_rows = nullptr;
-    std::vector<uint64_t> inline_tmp;
-    size_t ring_off = 0;
-    if (batch == 1) { inline_tmp.assign(rw, 0); table = inline_tmp.data(); args.use_inline = 1; }
-    else { ring_off = ring_reserve(table_bytes); table = (uint64_t*)((char*)ring_host_ + ring_off); args.use_inline = 0; }
+    std::vector<uint64_t> table((size_t)batch * rw, 0);
     for (int b = 0; b < batch; ++b) {
-        uint64_t* r = table + (size_t)b * rw;
+        uint64_t* r = table.data() + (size_t)b * rw;
         const RowSpec& rs = rows[b];
         for (int k = 0; k < p->n_in; ++k) r[k] = (uint64_t)(uintptr_t)rs.in[k];
         for (int k = 0; k < p->n_out; ++k) r[p->n_in + k] = (uint64_t)(uintptr_t)rs.out[k];
@@ -566,13 +562,24 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         float* sc = (float*)(r + p->n_in + p->n_out + n_red);
         const float* src = rs.scalars ? rs.scalars : p->scalars.data();
         for (int k = 0; k < p->n_scal; ++k) sc[k] = src[k];
-        if (p->n_scal & 1) sc[p->n_scal] = 0.0f;
     }
-    if (batch == 1) std::memcpy(args.inline_row, table, rw * 8);
+    if (batch == 1) { args.use_inline = 1; std::memcpy(args.inline_row, table.data(), rw * 8); }
     else {
-        HostTimer t2(HostProfile::ROW_UPLOAD);
-        hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, table, table_bytes, hipMemcpyHostToDevice, stream_), "row table H2D");
-        dev_rows = (const uint64_t*)((char*)ring_dev_ + ring_off);
+        args.use_inline = 0;
+        // A loop that runs the same program over the same vectors (run_into: time stepping with fixed buffers, bench.py)
+        // re-creates the same table every time: if the copy uploaded last time is still in the ring, use it again and
+        // save the in-stream H2D copy (≈ 5-8 µs of stream time per launch).
+        if (p->last_dev_rows && p->last_ring_generation == ring_generation_ && p->last_table == table) dev_rows = p->last_dev_rows;
+        else {
+            HostTimer t2(HostProfile::ROW_UPLOAD);
+            const size_t ring_off = ring_reserve(table_bytes);          // may wrap (and bump the generation)
+            std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
+            hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "row table H2D");
+            dev_rows = (const uint64_t*)((char*)ring_dev_ + ring_off);
+            p->last_table.swap(table);
+            p->last_dev_rows = dev_rows;
+            p->last_ring_generation = ring_generation_;
+        }
     }
 
     void* partials = nullptr; size_t partials_cap = 0;

@@ -79,6 +79,10 @@ struct Program {
     std::vector<float> scalars;             // default scalar operands (explicit API)
     int refs = 1;
     // execution tier (jit.hpp): work done on the interpreter so far, and the specialised kernel once requested
+    // steady-state loops (run_into over the same vectors): the row table of the previous launch is still in the ring
+    std::vector<uint64_t> last_table;       // its bytes
+    const uint64_t* last_dev_rows = nullptr;
+    uint64_t last_ring_generation = 0;
     double interpreted_work = 0.0;          // elements x micro-ops
     std::shared_ptr<JitSlot> jit;
 };
@@ -165,6 +169,7 @@ private:
     // pinned staging for H2D/D2H and the row-table ring
     void*  stage_ = nullptr;  size_t stage_cap_ = 0;
     void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
+    uint64_t ring_generation_ = 1;          // bumped on every wrap: device copies of older tables may be overwritten
     void*  ensure_stage(size_t bytes);
     size_t ring_reserve(size_t bytes);
 
