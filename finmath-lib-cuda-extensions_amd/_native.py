@@ -27,7 +27,7 @@ SYMBOLS = [
     "fmhip_set_jit", "fmhip_jit_wait", "fmhip_jit_stats", "fmhip_program_tier", "fmhip_program_source",
     "fmhip_bm_generate", "fmhip_mersenne_increments", "fmhip_bm_generate_mersenne", "fmhip_inverse_normal_cdf",
     "fmhip_pool_clean", "fmhip_pool_purge", "fmhip_pool_stats",
-    "fmhip_profile_enable", "fmhip_profile_read",
+    "fmhip_profile_enable", "fmhip_profile_read", "fmhip_traffic_stats",
 ]
 
 OK = 0
@@ -108,6 +108,7 @@ def lib():
         "fmhip_jit_stats": [C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl), C.POINTER(i64)],
         "fmhip_program_tier": [i64, C.POINTER(i32), C.POINTER(i32)],
         "fmhip_program_source": [C.POINTER(ProgOp), i32, i32, C.POINTER(i32), i32, C.POINTER(i32), i32, C.c_char_p, i64, C.POINTER(i64)],
+        "fmhip_traffic_stats": [C.POINTER(i64), C.POINTER(i64)],
         "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],
     }
     for name, args in sig.items():

@@ -226,6 +226,12 @@ int fmhip_pool_clean(void) { return guarded([&] { Engine::get().pool_clean(); })
 int fmhip_pool_purge(void) { return guarded([&] { Engine::get().pool_purge(); }); }
 int fmhip_pool_stats(fmhip_pool_stats_t* out) { return guarded([&] { Engine::get().pool_stats(out); }); }
 
+int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches) {
+    return guarded([&] {
+        if (algorithmic_bytes) *algorithmic_bytes = Engine::get().algorithmic_bytes();
+        if (specialised_launches) *specialised_launches = Engine::get().jit_launches();
+    });
+}
 int fmhip_profile_enable(int enabled) { return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches) {
     return guarded([&] { Engine::get().profile_read(kernel_ms_total, n_launches); });

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <unordered_set>
 
 namespace fm {
@@ -607,7 +608,9 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
             p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
         HostTimer t3(HostProfile::LAUNCH_API);
+        bool used_jit = false;
         if (jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY) {
+            used_jit = true;
             const uint64_t* rows_arg = dev_rows; double* partials_arg = (double*)partials;
             void* params[] = { &args, &rows_arg, &partials_arg };
             hip_check(hipModuleLaunchKernel(batch == 1 ? p->jit->fn_inline : p->jit->fn_table, (unsigned)bpr, (unsigned)batch, 1, FM_BLOCK, 1, 1,
@@ -615,8 +618,10 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
             n_jit_launches_++;
         } else
             hip_check(launch_program(args, dev_rows, (double*)partials, (uint32_t)bpr, (uint32_t)batch, stream_), "launch fm_program_kernel");
-        if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 }); }
+        if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                          profile_tags_.push_back({ p->n_ops, p->n_in, p->n_out, n_red, batch, used_jit ? 1 : 0, n }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
+        algorithmic_bytes_ += 4 * n * (int64_t)(p->n_in + p->n_out) * batch;
         if (n_red > 0) {
             DevFinalizeArgs fa{ (const double*)partials, (double*)results, (uint32_t)bpr };
             hip_check(launch_finalize(fa, (uint32_t)(batch * n_red), stream_), "launch fm_finalize_kernel");
@@ -1072,7 +1077,7 @@ void Engine::pool_stats(fmhip_pool_stats_t* out) {
 
 void Engine::profile_enable(bool on) {
     require_init();
-    if (!on) { for (auto& p : profile_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } profile_events_.clear(); }
+    if (!on) { for (auto& p : profile_events_) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); } profile_events_.clear(); profile_tags_.clear(); }
     profiling_ = on;
 }
 
@@ -1080,12 +1085,33 @@ void Engine::profile_read(double* ms_total, int64_t* n) {
     require_init();
     hip_check(hipStreamSynchronize(stream_), "sync");
     double total = 0.0;
-    for (auto& p : profile_events_) {
+    // FMHIP_PROFILE_DUMP=1: per program shape (ops/in/out/red/rows/tier), launches, device time and algorithmic GB/s
+    const bool dump = std::getenv("FMHIP_PROFILE_DUMP") != nullptr;
+    struct Agg { long long launches = 0; double ms = 0.0, bytes = 0.0; };
+    std::map<std::string, Agg> agg;
+    for (size_t i = 0; i < profile_events_.size(); ++i) {
+        auto& p = profile_events_[i];
         float ms = 0.0f;
         hip_check(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime");
         total += ms;
         (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        if (dump && i < profile_tags_.size()) {
+            const ProfileTag& t = profile_tags_[i];
+            char key[128];
+            std::snprintf(key, sizeof key, "ops %3d in %2d out %d red %d rows %4d n %9lld %s", t.n_ops, t.n_in, t.n_out, t.n_red, t.batch, (long long)t.n, t.tier ? "specialised" : "interpreter");
+            Agg& a = agg[key];
+            a.launches++; a.ms += ms; a.bytes += 4.0 * (double)t.n * (t.n_in + t.n_out) * t.batch;
+        }
     }
+    if (dump) {
+        std::vector<std::pair<std::string, Agg>> v(agg.begin(), agg.end());
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.ms > b.second.ms; });
+        std::fprintf(stderr, "[fmhip profile] %zu launches, %.3f ms of kernel time\n", profile_events_.size(), total);
+        for (const auto& kv : v)
+            std::fprintf(stderr, "  %-72s %7lld launches %9.3f ms %8.1f us each %8.0f GB/s\n", kv.first.c_str(), kv.second.launches, kv.second.ms,
+                         kv.second.ms / kv.second.launches * 1e3, kv.second.ms > 0 ? kv.second.bytes / (kv.second.ms * 1e-3) / 1e9 : 0.0);
+    }
+    profile_tags_.clear();
     if (ms_total) *ms_total = total;
     if (n) *n = (int64_t)profile_events_.size();
     profile_events_.clear();

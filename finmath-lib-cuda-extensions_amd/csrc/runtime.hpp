@@ -132,6 +132,7 @@ public:
     void jit_wait() { jit_.wait_idle(); }
     JitStats jit_stats() { return jit_.stats(); }
     int64_t jit_launches() const { return n_jit_launches_; }
+    int64_t algorithmic_bytes() const { return algorithmic_bytes_; }
     Program* program(fmhip_program p);
     void program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
                      const double* shifts, fmhip_moments* moments, void* dev_moments);
@@ -161,10 +162,12 @@ private:
     std::unordered_set<Node*> pending_;                          // nodes without storage (lazy expressions)
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
-    int64_t n_launches_ = 0, n_ops_executed_ = 0, n_jit_launches_ = 0;
+    int64_t n_launches_ = 0, n_ops_executed_ = 0, n_jit_launches_ = 0, algorithmic_bytes_ = 0;
     uint64_t epoch_ = 0;
     bool profiling_ = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> profile_events_;
+    struct ProfileTag { int n_ops, n_in, n_out, n_red, batch, tier; int64_t n; };     // what each recorded launch was
+    std::vector<ProfileTag> profile_tags_;
 
     // pinned staging for H2D/D2H and the row-table ring
     void*  stage_ = nullptr;  size_t stage_cap_ = 0;

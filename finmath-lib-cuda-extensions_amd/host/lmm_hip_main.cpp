@@ -71,18 +71,30 @@ int main(int argc, char** argv) {
         }
 
         fmhip_pool_stats_t s0; check(fmhip_pool_stats(&s0));
+        int64_t bytes0 = 0; check(fmhip_traffic_stats(&bytes0, nullptr));
+        if (o.profile) check(fmhip_profile_enable(1));
         auto extra = [&] {
             fmhip_pool_stats_t s; check(fmhip_pool_stats(&s));
             char name[128] = { 0 }; int cus = 0; int64_t hbm = 0; fmhip_device_info(name, 128, &cus, &hbm);
             int64_t jc = 0, jf = 0, jp = 0, jd = 0; double js = 0.0; fmhip_jit_stats(&jc, &jf, &jp, &js, &jd);
+            int64_t bytes1 = 0, jl = 0; fmhip_traffic_stats(&bytes1, &jl);
+            std::string prof;
+            if (o.profile) {                             // device time of every program launch of the run
+                double ms = 0.0; int64_t nl = 0; fmhip_profile_read(&ms, &nl);
+                char pb[256];
+                std::snprintf(pb, sizeof pb, ", \"profiled_launches\": %lld, \"kernel_ms_total\": %.3f, \"achieved_GBps\": %.1f",
+                              (long long)nl, ms, ms > 0 ? (double)(bytes1 - bytes0) / (ms * 1e-3) / 1e9 : 0.0);
+                prof = pb;
+            }
             char buf[768];
             std::snprintf(buf, sizeof buf, ", \"kernel_launches\": %lld, \"path_ops\": %.6e, \"device_bytes_reserved\": %lld, \"device\": \"%s\", "
                           "\"world\": %d, \"rank\": %d, \"total_paths\": %lld, \"rccl_all_reduces\": %lld, "
-                          "\"specialised_kernels\": %lld, \"specialisations_from_disk_cache\": %lld, \"specialisations_pending\": %lld, \"specialisation_seconds\": %.3f",
+                          "\"specialised_kernels\": %lld, \"specialisations_from_disk_cache\": %lld, \"specialisations_pending\": %lld, \"specialisation_seconds\": %.3f, "
+                          "\"algorithmic_bytes\": %lld, \"specialised_launches\": %lld",
                           (long long)(s.n_kernel_launches - s0.n_kernel_launches), (double)(s.n_ops_executed - s0.n_ops_executed) * (double)o.paths,
                           (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives,
-                          (long long)jc, (long long)jd, (long long)jp, js);
-            return std::string(buf);
+                          (long long)jc, (long long)jd, (long long)jp, js, (long long)(bytes1 - bytes0), (long long)jl);
+            return std::string(buf) + prof;
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);
         else { lmm::Options quiet = o; quiet.verbose = false; std::FILE* devnull = std::freopen("/dev/null", "w", stdout); (void)devnull; lmm::runAndReport(quiet, be, "hip", extra); }

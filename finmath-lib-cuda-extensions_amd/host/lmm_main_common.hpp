@@ -11,7 +11,8 @@ namespace fmhost { namespace lmm {
 struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
-    int world = 1, rank = 0; std::string ncclIdFile;      // path sharding over GPUs: one process per GPU
+    int world = 1, rank = 0; std::string ncclIdFile;
+    bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU
 };
 inline Options parseOptions(int argc, char** argv) {
     Options o;
@@ -27,6 +28,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--world") o.world = std::atoi(next());
         else if (a == "--rank") o.rank = std::atoi(next());
         else if (a == "--nccl-id-file") o.ncclIdFile = next();
+        else if (a == "--profile") o.profile = true;
         else if (a == "--verbose") o.verbose = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); std::exit(2); }
     }

@@ -304,6 +304,9 @@ int fmhip_pool_stats(fmhip_pool_stats_t* out);
  * of their device durations (ms) and their count, and clears the record.  Used by bench.py for the live
  * roofline figure; adds two event records per launch, so leave it off in production. */
 int fmhip_profile_enable(int enabled);
+/* Algorithmic bytes of all program launches so far (4 B x N x (inputs read + outputs written) per batch row;
+ * reductions add nothing) and how many of those launches ran on the specialised tier. */
+int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches);
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);
 
 #ifdef __cplusplus
