@@ -111,6 +111,11 @@ def lmm_workload(args):
     if out.returncode != 0:
         raise RuntimeError(f"lmm_hip rank {rank} failed: {out.stderr}")
     wall = time.perf_counter() - t0
+    warm_seconds = None
+    if world == 1:                       # the same calibration again: specialised kernels now come from the code-object cache
+        out2 = subprocess.run(cmd, capture_output=True, text=True)
+        if out2.returncode == 0:
+            warm_seconds = json.loads(out2.stdout.strip().splitlines()[-1])["seconds"]
     if rank != 0:
         return
     if "--nccl-id-file" in cmd and os.path.exists(cmd[-1]):
@@ -126,7 +131,7 @@ def lmm_workload(args):
                        "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
                        "rms_deviation": r["rms_deviation"], "mean_deviation": r["mean_deviation"],
                        "acceptance": "abs(mean deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
-                       "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
+                       "seconds_with_warm_code_object_cache": warm_seconds, "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
                        "specialisations_pending_at_exit": r.get("specialisations_pending"),
                        "specialisation_seconds": r.get("specialisation_seconds"),
                        "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"], "process_wall_s": wall},

@@ -42,26 +42,37 @@ static size_t round_cap(size_t bytes) {
 void* Pool::alloc(size_t bytes, size_t* cap_out) {
     const size_t cap = round_cap(bytes);
     *cap_out = cap;
-    auto it = free_.find(cap);
-    if (it != free_.end() && !it->second.empty()) {
-        void* p = it->second.back();
-        it->second.pop_back();
+    std::vector<void*>& fl = free_[cap];
+    if (!fl.empty()) {
+        void* p = fl.back();
+        fl.pop_back();
         hits++; cached -= (int64_t)cap; in_use += (int64_t)cap;
         return p;
     }
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, cap);
+    // Miss.  Device allocations are expensive (≈ 100 µs each) and a Monte-Carlo state is thousands of equally sized vectors:
+    // allocate SLABS of 1, 2, 4 … 64 blocks of this size class (≤ 1 GiB per slab) and hand the rest to the free list.
+    size_t& grow = slab_blocks_[cap];
+    size_t blocks = grow ? std::min<size_t>(grow * 2, 64) : 1;
+    while (blocks > 1 && blocks * cap > (size_t(1) << 30)) blocks /= 2;
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, blocks * cap);
+    if (e != hipSuccess && blocks > 1) { (void)hipGetLastError(); blocks = 1; e = hipMalloc(&base, cap); }
     if (e != hipSuccess) {              // last resort of the reference pool (:340): drop every cached buffer, retry once
         (void)hipGetLastError();
         purge();
-        e = hipMalloc(&p, cap);
+        blocks = 1;
+        e = hipMalloc(&base, cap);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e));
     }
-    misses++; reserved += (int64_t)cap; in_use += (int64_t)cap;
-    return p;
+    grow = blocks;
+    slabs_.push_back({ base, cap, blocks });
+    std::vector<void*>& fl2 = free_[cap];
+    for (size_t i = blocks; i-- > 1;) { fl2.push_back((char*)base + i * cap); cached += (int64_t)cap; }
+    misses++; reserved += (int64_t)(blocks * cap); in_use += (int64_t)cap;
+    return base;
 }
 
 void Pool::release(void* p, size_t cap) {
@@ -69,12 +80,28 @@ void Pool::release(void* p, size_t cap) {
     in_use -= (int64_t)cap; cached += (int64_t)cap;
 }
 
+// Frees every slab whose blocks are ALL back in the free list (a slab with one live vector stays).
 void Pool::purge() {
-    for (auto& kv : free_) {
-        for (void* p : kv.second) { (void)hipFree(p); reserved -= (int64_t)kv.first; cached -= (int64_t)kv.first; }
-        kv.second.clear();
+    std::unordered_map<size_t, std::unordered_set<void*>> free_set;
+    for (auto& kv : free_) free_set[kv.first].insert(kv.second.begin(), kv.second.end());
+    std::vector<Slab> kept;
+    for (const Slab& sl : slabs_) {
+        std::unordered_set<void*>& fs = free_set[sl.cap];
+        bool all_free = true;
+        for (size_t i = 0; i < sl.blocks && all_free; ++i) all_free = fs.count((char*)sl.base + i * sl.cap) != 0;
+        if (!all_free) { kept.push_back(sl); continue; }
+        for (size_t i = 0; i < sl.blocks; ++i) fs.erase((char*)sl.base + i * sl.cap);
+        (void)hipFree(sl.base);
+        reserved -= (int64_t)(sl.blocks * sl.cap); cached -= (int64_t)(sl.blocks * sl.cap);
     }
-    free_.clear();
+    slabs_.swap(kept);
+    for (auto& kv : free_) { kv.second.assign(free_set[kv.first].begin(), free_set[kv.first].end()); }
+    for (auto it = free_.begin(); it != free_.end();) it = it->second.empty() ? free_.erase(it) : std::next(it);
+    for (auto it = slab_blocks_.begin(); it != slab_blocks_.end();) {       // size classes without slabs start small again
+        bool any = false;
+        for (const Slab& sl : slabs_) any |= sl.cap == it->first;
+        it = any ? std::next(it) : slab_blocks_.erase(it);
+    }
 }
 
 // ---------------------------------------------------------------- engine lifecycle
@@ -136,12 +163,8 @@ void Engine::shutdown() {
     jit_.stop();                        // joins the compiler thread, unloads the specialised kernels
     for (auto& kv : nodes_) {           // leak-safe teardown: free storage of every live vector
         Node* nd = kv.second;
-        if (nd->buf && --nd->buf->refs == 0) {
-            Buffer* b = nd->buf;
-            if (b->parent) { if (--b->parent->refs == 0) { (void)hipFree(b->parent->ptr); delete b->parent; } }
-            else (void)hipFree(b->ptr);
-            delete b;
-        }
+        if (nd->buf) buffer_unref(nd->buf);     // back to the pool (blocks belong to slabs); purge() below frees the slabs
+        delete nd;
     }
     nodes_.clear();
     pending_.clear();

@@ -42,7 +42,10 @@ public:
     void  purge();                                    // hipFree everything cached
     int64_t reserved = 0, in_use = 0, cached = 0, hits = 0, misses = 0;
 private:
+    struct Slab { void* base; size_t cap; size_t blocks; };
     std::unordered_map<size_t, std::vector<void*>> free_;
+    std::vector<Slab> slabs_;
+    std::unordered_map<size_t, size_t> slab_blocks_;       // blocks of the last slab per size class (geometric growth)
 };
 
 struct Buffer {                 // refcounted device storage; views keep their parent alive

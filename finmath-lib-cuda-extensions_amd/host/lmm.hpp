@@ -161,42 +161,64 @@ struct Backend {
     std::function<std::vector<double>(const std::vector<RV>&)> averages = [](const std::vector<RV>& v) {
         std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum)
+    int jacobianBatch = 1;                  // finite-difference bumps evaluated in lock-step (rows of the same launches)
 };
 
-inline Simulation simulate(const Market& m, const VolatilityModel& vol, const Backend& be, int lastTimeIndex) {
+// Simulates SEVERAL parameter sets in lock-step (same Brownian increments = common random numbers): the operations of
+// one chunk are recorded for every parameter set before the flush, so that a lazily fusing back end finds K independent
+// DAGs of identical structure and runs them as K rows of ONE launch (K times the bytes per launch: at 1 M paths a single
+// set's launches are only ~65 MB and launch-granularity-bound).  Each set's arithmetic is unchanged.
+inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be, int lastTimeIndex) {
     const auto& td = m.timeDiscretization;
     const int n = m.numberOfLibors();
     const double delta = m.dt;
-    Simulation sim;
-    sim.libor.resize((size_t)lastTimeIndex + 1);
-    sim.numeraire.resize((size_t)lastTimeIndex + 1);
-    sim.libor[0].resize((size_t)n);
-    for (int j = 0; j < n; ++j) sim.libor[0][(size_t)j] = be.factory->createRandomVariable(0.0, m.curve.forward(td.getTime(j), delta));
-    sim.numeraire[0] = be.factory->createRandomVariable(0.0, 1.0);
+    const size_t K = vols.size();
+    std::vector<Simulation> sims(K);
+    for (Simulation& sim : sims) {
+        sim.libor.resize((size_t)lastTimeIndex + 1);
+        sim.numeraire.resize((size_t)lastTimeIndex + 1);
+        sim.libor[0].resize((size_t)n);
+        for (int j = 0; j < n; ++j) sim.libor[0][(size_t)j] = be.factory->createRandomVariable(0.0, m.curve.forward(td.getTime(j), delta));
+        sim.numeraire[0] = be.factory->createRandomVariable(0.0, 1.0);
+    }
+    std::vector<RV> factorSum(K);                                                        // Σ_k λ_k δ/(1+δ L_k): running over components
     for (int i = 0; i < lastTimeIndex; ++i) {
         const double t = td.getTime(i), dt = td.getTimeStep(i);
         const RV dW = be.brownianMotion->getBrownianIncrement(i, 0);
-        auto& cur = sim.libor[(size_t)i];
-        auto& nxt = sim.libor[(size_t)i + 1];
-        nxt.resize((size_t)n);
-        for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = cur[(size_t)j];           // fixed LIBORs
-        RV factorSum;                                                                    // Σ_k λ_k δ/(1+δ L_k): running over components
-        int inChunk = 0;
-        for (int j = i + 1; j < n; ++j) {
-            const double lambda = vol.volatility(t, td.getTime(j));                      // one factor: loading = volatility
-            {   // temporaries die before the flush: a live handle would make them extra outputs of the fused launch
-                const RV& L = cur[(size_t)j];
-                const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
-                factorSum = factorSum ? factorSum->add(transform) : transform;
-                const RV drift = factorSum->mult(lambda);
-                nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);       // Euler step, normal state space
-            }
-            if (++inChunk == be.chunk) { be.flush(); inChunk = 0; }
+        for (size_t k = 0; k < K; ++k) {
+            auto& cur = sims[k].libor[(size_t)i];
+            auto& nxt = sims[k].libor[(size_t)i + 1];
+            nxt.resize((size_t)n);
+            for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = cur[(size_t)j];       // fixed LIBORs
+            factorSum[k] = nullptr;
         }
-        sim.numeraire[(size_t)i + 1] = sim.numeraire[(size_t)i]->accrue(cur[(size_t)i], delta);   // rolled-over bank account
+        for (int j0 = i + 1; j0 < n; j0 += be.chunk) {
+            const int j1 = std::min(n, j0 + be.chunk);
+            for (size_t k = 0; k < K; ++k) {
+                auto& cur = sims[k].libor[(size_t)i];
+                auto& nxt = sims[k].libor[(size_t)i + 1];
+                for (int j = j0; j < j1; ++j) {
+                    const double lambda = vols[k]->volatility(t, td.getTime(j));         // one factor: loading = volatility
+                    // temporaries die before the flush: a live handle would make them extra outputs of the fused launch
+                    const RV& L = cur[(size_t)j];
+                    const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
+                    factorSum[k] = factorSum[k] ? factorSum[k]->add(transform) : transform;
+                    const RV drift = factorSum[k]->mult(lambda);
+                    nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);   // Euler step, normal state space
+                }
+            }
+            if (j1 - j0 == be.chunk) be.flush();
+        }
+        for (size_t k = 0; k < K; ++k)
+            sims[k].numeraire[(size_t)i + 1] = sims[k].numeraire[(size_t)i]->accrue(sims[k].libor[(size_t)i][(size_t)i], delta);   // rolled-over bank account
+        for (size_t k = 0; k < K; ++k) factorSum[k] = nullptr;
         be.flush();
     }
-    return sim;
+    return sims;
+}
+
+inline Simulation simulate(const Market& m, const VolatilityModel& vol, const Backend& be, int lastTimeIndex) {
+    return std::move(simulateMany(m, { &vol }, be, lastTimeIndex)[0]);
 }
 
 // SwaptionSimple with ValueUnit VOLATILITYNORMAL: backward induction of the swap value at exercise, payoff floored at 0,
@@ -219,28 +241,39 @@ inline double bachelierAtmImpliedVolatility(double optionValue, double optionMat
 
 struct Valuation { std::vector<double> modelVolatility; double seconds_simulation = 0, seconds_valuation = 0; long long launches_simulation = 0, launches_valuation = 0; };
 
-inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Backend& be) {
+inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be) {
     using clk = std::chrono::steady_clock;
-    Valuation out;
+    const size_t K = vols.size();
+    std::vector<Valuation> out(K);
     int lastIndex = 0;
     for (const Swaption& s : m.swaptions) lastIndex = std::max(lastIndex, m.timeDiscretization.getTimeIndex(s.exercise));
     const auto t0 = clk::now();
     const long long l0 = be.launches();
-    const Simulation sim = simulate(m, vol, be, lastIndex);
+    const std::vector<Simulation> sims = simulateMany(m, vols, be, lastIndex);
     const auto t1 = clk::now();
     const long long l1 = be.launches();
-    std::vector<RV> values;
-    values.reserve(m.swaptions.size());
-    for (const Swaption& s : m.swaptions) { values.push_back(swaptionValue(m, sim, s)); }
+    std::vector<std::vector<RV>> values(K);
+    for (size_t k = 0; k < K; ++k) {
+        values[k].reserve(m.swaptions.size());
+        for (const Swaption& s : m.swaptions) values[k].push_back(swaptionValue(m, sims[k], s));
+    }
     be.flush();
-    const std::vector<double> optionValues = be.averages(values);
-    for (size_t k = 0; k < m.swaptions.size(); ++k)
-        out.modelVolatility.push_back(bachelierAtmImpliedVolatility(optionValues[k], m.swaptions[k].exercise, m.swaptions[k].annuity));
+    for (size_t k = 0; k < K; ++k) {
+        const std::vector<double> optionValues = be.averages(values[k]);
+        for (size_t q = 0; q < m.swaptions.size(); ++q)
+            out[k].modelVolatility.push_back(bachelierAtmImpliedVolatility(optionValues[q], m.swaptions[q].exercise, m.swaptions[q].annuity));
+    }
     const auto t2 = clk::now();
-    out.launches_simulation = l1 - l0; out.launches_valuation = be.launches() - l1;
-    out.seconds_simulation = std::chrono::duration<double>(t1 - t0).count();
-    out.seconds_valuation = std::chrono::duration<double>(t2 - t1).count();
+    for (size_t k = 0; k < K; ++k) {            // statistics: the batch's totals, split evenly
+        out[k].launches_simulation = (l1 - l0) / (long long)K; out[k].launches_valuation = (be.launches() - l1) / (long long)K;
+        out[k].seconds_simulation = std::chrono::duration<double>(t1 - t0).count() / (double)K;
+        out[k].seconds_valuation = std::chrono::duration<double>(t2 - t1).count() / (double)K;
+    }
     return out;
+}
+
+inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Backend& be) {
+    return std::move(evaluateMany(m, { &vol }, be)[0]);
 }
 
 // ------------------------------------------------------------------ Levenberg–Marquardt with finite differences (:314-340)
@@ -291,11 +324,25 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
     for (int it = 0; it < maxIterations; ++it) {
         // Jacobian by forward differences: one re-simulation per active parameter (common random numbers)
         std::vector<double> J((size_t)nr * np);
-        for (int a = 0; a < np; ++a) {
-            VolatilityModel v = vol;
-            v.parameter[(size_t)active[(size_t)a]] += parameterStep;
-            residuals(v, rTrial, nullptr);
-            for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (rTrial[(size_t)k] - r[(size_t)k]) / parameterStep;
+        for (int a0 = 0; a0 < np; a0 += std::max(1, be.jacobianBatch)) {
+            const int a1 = std::min(np, a0 + std::max(1, be.jacobianBatch));
+            std::vector<VolatilityModel> bumped((size_t)(a1 - a0), vol);
+            std::vector<const VolatilityModel*> ptrs;
+            for (int a = a0; a < a1; ++a) { bumped[(size_t)(a - a0)].parameter[(size_t)active[(size_t)a]] += parameterStep; ptrs.push_back(&bumped[(size_t)(a - a0)]); }
+            std::vector<Valuation> vals;
+            try { vals = evaluateMany(m, ptrs, be); }
+            catch (const std::exception& e) {           // K simultaneous states did not fit the device: one by one instead
+                if (ptrs.size() == 1 || std::string(e.what()).find("allocation") == std::string::npos) throw;
+                if (verbose) std::fprintf(stderr, "  batch of %zu bumps does not fit (%s): evaluating them one at a time\n", ptrs.size(), e.what());
+                be.flush();
+                vals.clear();
+                for (const VolatilityModel* p1 : ptrs) vals.push_back(evaluate(m, *p1, be));
+            }
+            for (int a = a0; a < a1; ++a) {
+                const Valuation& val = vals[(size_t)(a - a0)];
+                res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
+                for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility - r[(size_t)k]) / parameterStep;
+            }
         }
         std::vector<double> JtJ((size_t)np * np, 0.0), Jtr((size_t)np, 0.0);
         for (int a = 0; a < np; ++a) {

@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
         lmm::Backend be;
         be.factory = &factory; be.brownianMotion = &bm;
         be.flush = [] { check(fmhip_flush()); };
+        be.jacobianBatch = o.jacobianBatch > 0 ? o.jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
 

@@ -12,6 +12,7 @@ struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
     int world = 1, rank = 0; std::string ncclIdFile;
+    int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU
 };
 inline Options parseOptions(int argc, char** argv) {
@@ -29,6 +30,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--rank") o.rank = std::atoi(next());
         else if (a == "--nccl-id-file") o.ncclIdFile = next();
         else if (a == "--profile") o.profile = true;
+        else if (a == "--jacobian-batch") o.jacobianBatch = std::atoi(next());
         else if (a == "--verbose") o.verbose = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); std::exit(2); }
     }

@@ -68,3 +68,13 @@ def test_sharded_driver_path_with_rccl_world_of_one(tmp_path):
     assert dist["rccl_all_reduces"] >= 1 and dist["world"] == 1
     a, b = np.array(plain["model_volatility"]), np.array(dist["model_volatility"])
     assert np.max(np.abs(a - b) / a) <= 1e-12
+
+
+def test_lock_step_jacobian_batches_give_the_same_calibration():
+    """Finite-difference bumps simulated in lock-step (rows of the same launches) change the launch count, not one bit of
+    the result."""
+    one = run(LMM_HIP, "--paths", 3000, "--mode", "calibrate", "--max-iterations", 2, "--jacobian-batch", 1)
+    many = run(LMM_HIP, "--paths", 3000, "--mode", "calibrate", "--max-iterations", 2, "--jacobian-batch", 7)
+    assert one["parameters"] == many["parameters"] and one["rms_deviation"] == many["rms_deviation"]
+    assert one["evaluations"] == many["evaluations"]
+    assert many["kernel_launches"] < 0.5 * one["kernel_launches"]
