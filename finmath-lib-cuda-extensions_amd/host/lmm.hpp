@@ -168,7 +168,10 @@ struct Backend {
 // one chunk are recorded for every parameter set before the flush, so that a lazily fusing back end finds K independent
 // DAGs of identical structure and runs them as K rows of ONE launch (K times the bytes per launch: at 1 M paths a single
 // set's launches are only ~65 MB and launch-granularity-bound).  Each set's arithmetic is unchanged.
-inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be, int lastTimeIndex) {
+// `keep` (optional): time indices whose state a product will read; the state of every other past time step is released as
+// soon as the next step exists (one objective evaluation then holds ≈ 15 instead of 80 time steps of 80 vectors).
+inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be, int lastTimeIndex,
+                                            const std::vector<char>* keep = nullptr) {
     const auto& td = m.timeDiscretization;
     const int n = m.numberOfLibors();
     const double delta = m.dt;
@@ -213,6 +216,8 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
             sims[k].numeraire[(size_t)i + 1] = sims[k].numeraire[(size_t)i]->accrue(sims[k].libor[(size_t)i][(size_t)i], delta);   // rolled-over bank account
         for (size_t k = 0; k < K; ++k) factorSum[k] = nullptr;
         be.flush();
+        if (keep && !(*keep)[(size_t)i])
+            for (size_t k = 0; k < K; ++k) { sims[k].libor[(size_t)i].clear(); sims[k].libor[(size_t)i].shrink_to_fit(); }
     }
     return sims;
 }
@@ -249,7 +254,9 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<co
     for (const Swaption& s : m.swaptions) lastIndex = std::max(lastIndex, m.timeDiscretization.getTimeIndex(s.exercise));
     const auto t0 = clk::now();
     const long long l0 = be.launches();
-    const std::vector<Simulation> sims = simulateMany(m, vols, be, lastIndex);
+    std::vector<char> keep((size_t)lastIndex + 1, 0);                // states read by SwaptionSimple: the exercise dates
+    for (const Swaption& s : m.swaptions) keep[(size_t)m.timeDiscretization.getTimeIndex(s.exercise)] = 1;
+    const std::vector<Simulation> sims = simulateMany(m, vols, be, lastIndex, &keep);
     const auto t1 = clk::now();
     const long long l1 = be.launches();
     std::vector<std::vector<RV>> values(K);
