@@ -45,7 +45,14 @@ inline void runAndReport(const Options& o, const Backend& be, const char* backen
         VolatilityModel vol;
         Valuation v;
         double sim = 0, val = 0;
-        for (int k = 0; k < o.evaluations; ++k) { v = evaluate(m, vol, be); sim += v.seconds_simulation; val += v.seconds_valuation; }
+        // --jacobian-batch K (explicit): `evaluations` parameter sets are evaluated K at a time in lock-step, as the calibration does
+        const int K = std::max(1, o.jacobianBatch);
+        for (int k = 0; k < o.evaluations; k += K) {
+            const int kk = std::min(K, o.evaluations - k);
+            const std::vector<Valuation> vs = evaluateMany(m, std::vector<const VolatilityModel*>((size_t)kk, &vol), be);
+            for (const Valuation& x : vs) { sim += x.seconds_simulation; val += x.seconds_valuation; }
+            v = vs.back();
+        }
         std::printf("{\"backend\": \"%s\", \"mode\": \"evaluate\", \"paths\": %lld, \"swaptions\": %zu, \"evaluations\": %d, "
                     "\"seconds_simulation_per_evaluation\": %.6f, \"seconds_valuation_per_evaluation\": %.6f, \"launches_simulation\": %lld, \"launches_valuation\": %lld%s, \"model_volatility\": [",
                     backendName, (long long)o.paths, m.swaptions.size(), o.evaluations, sim / o.evaluations, val / o.evaluations, v.launches_simulation, v.launches_valuation, extraJson().c_str());
