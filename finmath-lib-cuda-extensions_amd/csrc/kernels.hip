@@ -1,6 +1,8 @@
 // kernels.hip — the hand-written gfx950 (CDNA4) kernels of the RandomVariable / BrownianMotion hot path.
 //
-//   fm_program_kernel   one launch = a whole chain of RandomVariable methods over `batch` independent
+//   fm_program_kernel   tier 0 of a compiled program (tier 1 = the per-program kernels jit.cpp generates from the same
+//                       building blocks, fm_kernel_parts.hpp / fm_device_math.hpp):
+//                       one launch = a whole chain of RandomVariable methods over `batch` independent
 //                       vector tuples (replaces the reference's one-launch-per-method scheme,
 //                       RandomVariableCuda.java:483-557 + the 27 kernels of RandomVariableCudaKernel.cu),
 //                       optionally ending in fused {Σ, Σ², min, max} reductions (replaces the
@@ -10,7 +12,9 @@
 //                       curandGenerateNormal, BrownianMotionCudaWithRandomVariableCuda.java:168-178).
 //   fm_fill_kernel      constant fill.
 //
-// All four are HBM-bandwidth bound; nothing here is a contraction, MFMA is not used.
+// Byte movers by construction: nothing here is a contraction, MFMA is not used.  Measured: method chains of
+// arithmetic ops stream at the HBM ceiling; chains with fp64-evaluated exp/log and the IEEE-only normal generator are
+// VALU-bound.
 // Design for CDNA4: 64-wide waves, 256-thread workgroups, one 128-bit access per lane per vector
 // (1 KiB per wave-instruction, fully coalesced), every input load of a tile issued before the first
 // use so ≥ n_in KiB per wave are in flight, virtual registers in VGPRs (s_set_gpr_idx — no scratch,
