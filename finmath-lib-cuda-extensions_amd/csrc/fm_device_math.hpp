@@ -20,19 +20,18 @@ namespace fm {
 // The reference's CUDA kernels use `a < b ? a : b` (RandomVariableCudaKernel.cu:2-21), which differs from
 // its own CPU twin for NaN and signed zeros; the twin (and finmath-lib's double class) is followed here.
 // Built on the hardware v_min_f32 / v_max_f32, which order -0 < +0 exactly like Java and return the other operand
-// when one is NaN; the NaN propagation is added with two selects (branch-free).
+// when one is NaN; the NaN propagation is added with one unordered compare + one select (the result is the canonical
+// quiet NaN: Java leaves the payload unspecified, parity treats NaN ≡ NaN).
 // (inline asm: the builtin min/max would first canonicalise both inputs with an extra v_max_f32 x,x each)
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float jmin(float a, float b) {
-    float r = hw_min(a, b);
-    r = (b != b) ? b : r;
-    return (a != a) ? a : r;
+    const float r = hw_min(a, b);
+    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;       // one v_cmp_u_f32 covers "a or b is NaN"
 }
 __device__ __forceinline__ float jmax(float a, float b) {
-    float r = hw_max(a, b);
-    r = (b != b) ? b : r;
-    return (a != a) ? a : r;
+    const float r = hw_max(a, b);
+    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;
 }
 // java.lang.Math.pow special cases that differ from C99 pow (see oracle/rv_float.c jpow).
 __device__ __forceinline__ double jpow(double x, double y) {
