@@ -60,3 +60,29 @@ def test_2pow26_paths_idempotence_and_closed_forms(gpu):
     assert z.sub(k).abs().getMax() == 0.0
     assert x.squared().sqrt().sub(3.0).abs().getMax() == 0.0
     gpu.purge()
+
+
+def test_maximum_vector_size(gpu):
+    """The largest vector the boundary accepts: 2^31 elements (the reference's kernels take `int n`)
+    = 8.6 GB per vector; 32-bit float4 indexing and the grid arithmetic at their limit, on both execution tiers.  Closed
+    forms: every element of filled(0.5).add(0.75).squared() is 1.5625, so Σ = n·1.5625 and Σ² = n·1.5625² exactly in fp64."""
+    n = 1 << 31
+    with pytest.raises(gpu.FmhipError) as e:
+        gpu.DeviceVector.filled(n + 1, 0.0)
+    assert e.value.code == -5
+    x = gpu.DeviceVector.filled(n, 0.5)
+    for tier in (gpu.JIT_OFF, gpu.JIT_SYNC):
+        prev = gpu.set_jit(tier)
+        try:
+            p = gpu.Program(1)
+            w = p.op("SQUARED", p.op("ADD_S", 0, s=0.75))
+            p.output(w); p.reduce(w); p.compile()
+            outs, m = p.run([[x]])
+        finally:
+            gpu.set_jit(prev)
+        assert m[0, 0, 0] == n * 1.5625 and m[0, 0, 1] == n * 1.5625 ** 2 and m[0, 0, 2] == 1.5625 and m[0, 0, 3] == 1.5625
+        tail = outs[0][0].v1s1("SUB_S", 1.5625).moments()           # every element, again through the eager path
+        assert tail.sum == 0.0 and tail.min == 0.0 and tail.max == 0.0
+        del outs
+    del x
+    gpu.purge()
