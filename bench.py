@@ -64,8 +64,10 @@ def synthetic_inputs(fm, batch, n, rank):
     return rows
 
 
-def cpu_baseline(target_seconds=12.0):
-    """Stream S on the CPU oracle, one 1M-path triple per pass, repeated for ~target_seconds."""
+def cpu_baseline(target_seconds=12.0, all_cores_seconds=6.0):
+    """Stream S on the CPU oracle, one 1M-path triple per pass, repeated for ~target_seconds (the reference's cost model:
+    single-threaded loops).  Additionally, for information, the same loop in one fresh process per host core over
+    independent triples (`all_cores`: what path-sharding over the CPU's cores would give)."""
     import oracle as o
     n = N_PATHS
     x = o.f_from_double(o.java_random_doubles(31415, n))
@@ -87,9 +89,23 @@ def cpu_baseline(target_seconds=12.0):
         dt = time.perf_counter() - t0
         if dt >= target_seconds or passes >= 2000:
             break
-    return {"value": N_OPS * n * passes / dt, "unit": "path-ops/s", "cores": 1, "kind": "port",
-            "sample": f"{passes} passes of stream S over one 1M-path (x,y,z) triple, {dt:.1f} s, "
-                      f"C restatement of RandomVariableFromFloatArray (one loop + one fresh array per op)"}
+    result = {"value": N_OPS * n * passes / dt, "unit": "path-ops/s", "cores": 1, "kind": "port",
+              "sample": f"{passes} passes of stream S over one 1M-path (x,y,z) triple, {dt:.1f} s, "
+                        f"C restatement of RandomVariableFromFloatArray (one loop + one fresh array per op)"}
+    if all_cores_seconds > 0:
+        import subprocess
+        cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(all_cores_seconds)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+        total = 0.0
+        for pr in procs:
+            out, _ = pr.communicate(timeout=all_cores_seconds * 6 + 60)
+            if pr.returncode == 0 and out.strip():
+                w = json.loads(out.strip().splitlines()[-1])
+                total += w["value"]
+        result["all_cores"] = {"value": total, "unit": "path-ops/s", "cores": cores,
+                               "sample": f"{cores} processes x ~{all_cores_seconds:.0f} s of the same single-threaded loop over independent triples"}
+    return result
 
 
 def lmm_workload(args):
@@ -173,7 +189,11 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="independent (x,y,z) triples per launch")
     ap.add_argument("--paths", type=int, default=N_PATHS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)      # internal: one process of the all-cores CPU baseline
     args = ap.parse_args()
+    if args.cpu_worker > 0:
+        print(json.dumps(cpu_baseline(args.cpu_worker, 0.0)), flush=True)
+        return
     if args.workload == "lmm":
         return lmm_workload(args)
 
