@@ -322,14 +322,14 @@ public:
         if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->mult(self());
         const double t = std::max(time_, rate->getFiltrationTime());
         if (rate->isDeterministic()) return mult(1.0 + rate->doubleValue() * p);
-        if (isDeterministic()) return rate->mult(p)->add(1.0)->mult(value_);
+        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->mult(value_); return of(t, vecOf(r), r->size()); }   // newTime kept (twin:1214-1219)
         return of(t, vec_->v2s1(FMHIP_OP_ACCRUE, *vecOf(rate), p), n_);
     }
     RV discount(const RV& rate, double p) const override {                          // :1604-1624
         if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->invert()->mult(self());
         const double t = std::max(time_, rate->getFiltrationTime());
         if (rate->isDeterministic()) return div(1.0 + rate->doubleValue() * p);
-        if (isDeterministic()) { if (value_ == 0) return self(); return rate->mult(p)->add(1.0)->vid(value_); }
+        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->vid(value_); return of(t, vecOf(r), r->size()); }    // twin:1242-1247 (no zero short-cut)
         return of(t, vec_->v2s1(FMHIP_OP_DISCOUNT, *vecOf(rate), p), n_);
     }
     RV choose(const RV& a, const RV& b) const override {                            // twin:1264-1285

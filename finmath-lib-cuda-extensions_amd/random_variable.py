@@ -14,7 +14,9 @@ maximum of the filtration times, then dispatch on which operands are determinist
 Deliberate deviations from RandomVariableCuda, each following the reference's own CPU twin
 (RandomVariableFromFloatArray.java, ``twin:line``) where the GPU class is broken or unimplemented
 (SURVEY.md Appendix A):
-  * add/sub/bus(RandomVariable) stochastic branch returns newTime (the GPU class drops it, :1410,:1434,:1459);
+  * add/sub/bus(RandomVariable) stochastic branch returns newTime (the GPU class drops it, :1410,:1434,:1459); so do
+    accrue/discount of a deterministic receiver with a stochastic rate (:1595-1596, :1615-1619; twin:1214-1219, :1242-1247),
+    and discount does not short-cut a zero receiver to a constant (the twin returns the vector 0/(1+r·Δ), NaNs included);
   * cap(RandomVariable) handles "argument deterministic, receiver stochastic" (null dereference at :1546-1555);
   * vid(RandomVariable) priority branch calls div (twin:1116-1119; the GPU class calls vid, :1513-1516);
   * choose, isNaN, sin, cos are implemented (GPU class returns null / throws; twin:1264,1441,927,942);
@@ -421,16 +423,16 @@ class RandomVariableHip:
         if rate.getTypePriority() > self.getTypePriority(): return rate.mult(period_length).add(1.0).mult(self)
         new_time = max(self.time, rate.getFiltrationTime())
         if rate.isDeterministic(): return self.mult(1.0 + rate.doubleValue() * period_length)
-        if self.isDeterministic(): return rate.mult(period_length).add(1.0).mult(self.value)
+        if self.isDeterministic():       # same rounding sequence as :1595-1596, but newTime kept as the twin does (twin:1214-1219)
+            return self._sto(rate.mult(period_length).add(1.0).mult(self.value).realizations, new_time)
         return self._sto(self.realizations.v2s1("ACCRUE", self._vec(rate), period_length), new_time)
 
     def discount(self, rate, period_length):                          # :1604-1624
         if rate.getTypePriority() > self.getTypePriority(): return rate.mult(period_length).add(1.0).invert().mult(self)
         new_time = max(self.time, rate.getFiltrationTime())
         if rate.isDeterministic(): return self.div(1.0 + rate.doubleValue() * period_length)
-        if self.isDeterministic():
-            if self.value == 0: return self
-            return rate.mult(period_length).add(1.0).vid(self.value)
+        if self.isDeterministic():       # twin:1242-1247 (the GPU class short-cuts value == 0 to `this` and drops newTime, :1615-1619)
+            return self._sto(rate.mult(period_length).add(1.0).vid(self.value).realizations, new_time)
         return self._sto(self.realizations.v2s1("DISCOUNT", self._vec(rate), period_length), new_time)
 
     def choose(self, value_if_trigger_non_negative, value_if_trigger_negative):        # twin:1264-1285
