@@ -145,7 +145,82 @@ __device__ __forceinline__ float log_fast(float a) {
 // budget (and with it the occupancy) of the whole interpreter kernel.
 __device__ __noinline__ float sin_f(float a) { return (float)sin((double)a); }
 __device__ __noinline__ float cos_f(float a) { return (float)cos((double)a); }
-__device__ __noinline__ float pow_f(float a, float s) { return (float)jpow((double)a, (double)s); }
+// ---- pow: `(float)Math.pow((double)x, (double)(float)exponent)` (twin :849).
+// Fast path for x > 0 finite and a finite exponent: 2^(y·log2 x) with log2 x carried as a double-double — the same mantissa
+// split, Newton reciprocal and atanh series as log_f, plus the division residual (s = s_hi + s_lo), a degree-6 minimax tail
+// (2^-57.6) and 2/ln2 as a double-double, so that y·log2 x is good to ≈ 2^-54 relative even at |y·log2 x| ≈ 150; then the
+// exp polynomial on the fraction.  ≈ 70 instructions instead of the ≈ 300 of the generic library pow; every other
+// argument class (x <= 0, ±inf, NaN, exponent ±inf / NaN) takes the library path with Java's special cases (jpow).
+__device__ __forceinline__ float pow_pos(float a, float yf) {
+    float m32 = __builtin_amdgcn_frexp_mantf(a);
+    int e = __builtin_amdgcn_frexp_expf(a);
+    const bool lo = m32 < 0.70710678f;
+    m32 = lo ? m32 + m32 : m32;
+    e = lo ? e - 1 : e;
+    const double m = (double)m32, f = m - 1.0, d = m + 1.0;
+    const double q0 = (double)__builtin_amdgcn_rcpf(m32 + 1.0f);
+    const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);
+    const double s_hi = f * q1;
+    const double s_lo = __builtin_fma(-s_hi, d, f) * q1;                  // division residual: s = s_hi + s_lo to ≈ 2^-88
+    const double z = s_hi * s_hi;
+    double g = 0x1.2b5b5fb2eac92p-4;                                      // (atanh(s)/s - 1)/z, tools/minimax_coefficients.py
+    g = fma_c(g, z, 0x1.39fe208c33457p-4);
+    g = fma_c(g, z, 0x1.7462b69705382p-4);
+    g = fma_c(g, z, 0x1.c71c62debf86bp-4);
+    g = fma_c(g, z, 0x1.2492492df6947p-3);
+    g = fma_c(g, z, 0x1.99999999952b2p-3);
+    g = fma_c(g, z, 0x1.5555555555558p-2);
+    double at_lo = __builtin_fma(s_hi * z, g, s_lo);                      // atanh(s) = s_hi + at_lo
+    at_lo = __builtin_fma(z, s_lo, at_lo);                                // first-order effect of s_lo on the s³ term
+    const double c_hi = 0x1.71547652b82fep+1, c_lo = 0x1.777d0ffda0d24p-55;   // 2/ln 2
+    const double p_hi = c_hi * s_hi;
+    const double p_lo = __builtin_fma(c_hi, s_hi, -p_hi) + __builtin_fma(c_hi, at_lo, c_lo * s_hi);
+    const double ed = (double)e;
+    const double l_hi = ed + p_hi;                                        // Fast2Sum: |ed| >= 1 > |p_hi|, or ed == 0
+    const double l_lo = ((ed - l_hi) + p_hi) + p_lo;
+    const double y = (double)yf;
+    double P_hi = y * l_hi;
+    const double P_lo = __builtin_fma(y, l_hi, -P_hi) + y * l_lo;
+    P_hi = __builtin_fmin(__builtin_fmax(P_hi, -1100.0), 1100.0);         // results saturate to 0 / +inf; keeps k an int
+    const double t = P_hi + 6755399441055744.0;
+    const double k = t - 6755399441055744.0;
+    const int ki = (int)(uint32_t)__double_as_longlong(t);
+    const double ff = (P_hi - k) + P_lo;
+    const double r = __builtin_fma(ff, 0x1.abc9e3b39803fp-56, ff * 0x1.62e42fefa39efp-1);   // ff · ln 2
+    double p = 0x1.286f24b3f714bp-22;                                     // e^r as in exp_f
+    p = fma_c(p, r, 0x1.72ad803971e4dp-19);
+    p = fma_c(p, r, 0x1.a019d81272de4p-16);
+    p = fma_c(p, r, 0x1.a019c3487562dp-13);
+    p = fma_c(p, r, 0x1.6c16c17016625p-10);
+    p = fma_c(p, r, 0x1.1111111710d7bp-7);
+    p = fma_c(p, r, 0x1.5555555555369p-5);
+    p = fma_c(p, r, 0x1.5555555554f90p-3);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, ki);
+}
+__device__ __noinline__ float pow_f(float a, float s) {
+    const double x = (double)a;
+    // Small integer exponents (wave-uniform test): the product / quotient of exact doubles is rounded ONCE, i.e. it is the
+    // correctly rounded power — including the exact ties (x² of a short mantissa) that no approximation can resolve.
+    if (s == 2.0f) return (float)(x * x);
+    if (s == 3.0f) return (float)((x * x) * x);
+    if (s == 4.0f) { const double t = x * x; return (float)(t * t); }
+    if (s == -1.0f) return (float)(1.0 / x);
+    if (s == -2.0f) return (float)(1.0 / (x * x));
+    // half-integer exponents: x^(k+1/2) = x^k·sqrt(x); the exact ties of these powers have an exact square root, so the product is exact
+    // (positive bases only: Math.pow(-inf, 1.5) = +inf and Math.pow(-0.0, 2.5) = +0.0 are the library's business)
+    if (s == 1.5f && a > 0.0f) return (float)(x * __builtin_sqrt(x));
+    if (s == 2.5f && a > 0.0f) return (float)((x * x) * __builtin_sqrt(x));
+    // +denormal | +normal base (0x180), finite exponent (everything but NaN 0x3 and ±inf 0x204)
+    if (__builtin_amdgcn_classf(a, 0x180) && __builtin_amdgcn_classf(s, 0x1f8)) {
+        const float r = pow_pos(a, s);
+        // results in the fp32 denormal range keep few bits, so exact ties are common there: library path
+        if (__builtin_fabsf(r) >= 1.17549435e-38f) return r;
+    }
+    return (float)jpow(x, (double)s);
+}
 
 // (float)Math.sqrt((double)a) == correctly rounded fp32 sqrt (double rounding is innocuous for sqrt, 53 >= 2*24+2).
 // __builtin_sqrtf lowers to the IEEE-correct expansion (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt);
