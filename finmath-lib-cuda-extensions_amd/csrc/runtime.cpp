@@ -894,15 +894,21 @@ void Engine::flush_all() {
 
 // ---------------------------------------------------------------- reductions
 
+// The stand-alone reduction is the empty program with one fused reduction of its input (compiled once).
+Program* Engine::reduce_program() {
+    static const char* key = "__reduce1";
+    auto it = program_cache_.find(key);
+    if (it != program_cache_.end()) return it->second;
+    Program* prog = compile({}, 1, {}, { 0 }, nullptr, true);
+    program_cache_[key] = prog;
+    return prog;
+}
+
 void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out) {
     require_init();
     Node* nd = node(h);
     if (!nd->buf) materialize({ nd });
-    static const char* key = "__reduce1";
-    Program* prog;
-    auto it = program_cache_.find(key);
-    if (it != program_cache_.end()) prog = it->second;
-    else { prog = compile({}, 1, {}, { 0 }, nullptr, true); program_cache_[key] = prog; }
+    Program* prog = reduce_program();
     std::vector<RowSpec> rows(1);
     rows[0].in.push_back(nd->buf->ptr);
     rows[0].scalars = nullptr;
@@ -922,11 +928,7 @@ void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, 
     for (Node* nd : nds) pending |= !nd->buf;
     if (pending) flush_all();                                   // one batched flush instead of one launch per vector
     for (Node* nd : nds) if (!nd->buf) materialize({ nd });
-    static const char* key = "__reduce1";
-    Program* prog;
-    auto it = program_cache_.find(key);
-    if (it != program_cache_.end()) prog = it->second;
-    else { prog = compile({}, 1, {}, { 0 }, nullptr, true); program_cache_[key] = prog; }
+    Program* prog = reduce_program();
     const int max_rows = 1024;
     for (int off = 0; off < count; off += max_rows) {
         const int m = std::min(max_rows, count - off);

@@ -193,6 +193,7 @@ private:
     // rows: per batch row, n_in input buffers + n_out output buffers (+ per-row scalars, shifts)
     struct RowSpec { std::vector<const float*> in; std::vector<float*> out; const float* scalars; const double* shifts; };
     void launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmhip_moments* host_moments, void* dev_moments);
+    Program* reduce_program();
     bool try_fused(const std::vector<Node*>& roots);
     struct Dag;
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
