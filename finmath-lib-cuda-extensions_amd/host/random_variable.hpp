@@ -194,6 +194,11 @@ public:
         : time_(time), value_(std::numeric_limits<double>::quiet_NaN()), vec_(DeviceVector::fromHost(values)), n_((int64_t)values.size()), priority_(typePriorityDefault) {}
 
     static RV of(double time, double value) { return std::make_shared<RandomVariableHip>(time, value); }
+    static RV restamp(const RV& rv, double time) {                   // same value, another filtration time
+        const auto* h = dynamic_cast<const RandomVariableHip*>(rv.get());
+        if (!h || h->time_ == time) return rv;
+        return h->isDeterministic() ? of(time, h->value_) : of(time, h->vec_, h->n_);
+    }
     static RV of(double time, DeviceVector::Ptr v, int64_t n) { return std::make_shared<RandomVariableHip>(time, std::move(v), n); }
 
     double getFiltrationTime() const override { return time_; }
@@ -299,7 +304,7 @@ public:
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, rv->doubleValue() / value_);
         if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_DIV_S, value_), rv->size());
-        if (rv->isDeterministic()) return vid(rv->doubleValue());
+        if (rv->isDeterministic()) return restamp(vid(rv->doubleValue()), t);      // value as :1528, time as the twin (twin:1135-1140)
         return of(t, vecOf(rv)->v2s0(FMHIP_OP_DIV, *vec_), n_);                   // flipped arguments, :1531
     }
     RV cap(const RV& rv) const override {
@@ -339,6 +344,9 @@ public:
         const DeviceVector::Ptr vb = b->isDeterministic() ? DeviceVector::filled(n_, b->doubleValue()) : vecOf(b);
         return of(t, vec_->v3s0(FMHIP_OP_CHOOSE, *va, *vb), n_);
     }
+    // :1686-1695 compose add/sub(div); the filtration time is the maximum of all three, as in the twin (twin:1395-1438)
+    RV addRatio(const RV& num, const RV& den) const override { return restamp(add(num->div(den)), std::max(std::max(time_, num->getFiltrationTime()), den->getFiltrationTime())); }
+    RV subRatio(const RV& num, const RV& den) const override { return restamp(sub(num->div(den)), std::max(std::max(time_, num->getFiltrationTime()), den->getFiltrationTime())); }
     RV addProduct(const RV& f1, double f2) const override {                         // :1638-1656
         if (f1->getTypePriority() > priority_) return f1->mult(f2)->add(self());
         const double t = std::max(time_, f1->getFiltrationTime());

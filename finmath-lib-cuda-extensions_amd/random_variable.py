@@ -17,6 +17,10 @@ Deliberate deviations from RandomVariableCuda, each following the reference's ow
   * add/sub/bus(RandomVariable) stochastic branch returns newTime (the GPU class drops it, :1410,:1434,:1459); so do
     accrue/discount of a deterministic receiver with a stochastic rate (:1595-1596, :1615-1619; twin:1214-1219, :1242-1247),
     and discount does not short-cut a zero receiver to a constant (the twin returns the vector 0/(1+r·Δ), NaNs included);
+    addRatio/subRatio carry the maximum of all three filtration times (twin:1395-1438; add(div(·)) drops a constant denominator's);
+    vid(RandomVariable) with a constant argument takes the twin's newTime; its VALUE follows the GPU class (constant narrowed
+    to fp32 like every scalar operand, :1528 — the twin divides the double constant, twin:1138; different only for constants
+    that are not fp32 values);
   * cap(RandomVariable) handles "argument deterministic, receiver stochastic" (null dereference at :1546-1555);
   * vid(RandomVariable) priority branch calls div (twin:1116-1119; the GPU class calls vid, :1513-1516);
   * choose, isNaN, sin, cos are implemented (GPU class returns null / throws; twin:1264,1441,927,942);
@@ -400,7 +404,8 @@ class RandomVariableHip:
         if self.isDeterministic() and rv.isDeterministic():
             return self._det(_f64(np.divide, rv.doubleValue(), self.value), new_time)
         if self.isDeterministic(): return self._sto(self._vec(rv).v1s1("DIV_S", self.value), new_time)
-        if rv.isDeterministic(): return self.vid(rv.doubleValue())
+        if rv.isDeterministic():        # value as :1528 (scalar narrowed like every scalar operand), time as the twin (twin:1135-1140)
+            return self._restamp(self.vid(rv.doubleValue()), new_time)
         return self._sto(self._vec(rv).v2s0("DIV", self.realizations), new_time)       # flipped arguments, :1531
 
     def _cap_rv(self, rv):
@@ -475,11 +480,18 @@ class RandomVariableHip:
             result = result.addProduct(f1, f2)
         return result
 
-    def addRatio(self, numerator, denominator):                       # :1686-1689
-        return self.add(numerator.div(denominator))
+    def _restamp(self, rv, time):
+        """`rv` with filtration time `time` (same value / same device vector)."""
+        if not isinstance(rv, RandomVariableHip) or rv.time == time: return rv
+        return RandomVariableHip(time, rv.value if rv.isDeterministic() else rv.realizations, rv.type_priority)
+
+    def addRatio(self, numerator, denominator):                       # :1686-1689 composes add(div); the filtration time is the
+        new_time = max(self.time, numerator.getFiltrationTime(), denominator.getFiltrationTime())   # twin's (twin:1395-1438)
+        return self._restamp(self.add(numerator.div(denominator)), new_time)
 
     def subRatio(self, numerator, denominator):                       # :1692-1695
-        return self.sub(numerator.div(denominator))
+        new_time = max(self.time, numerator.getFiltrationTime(), denominator.getFiltrationTime())
+        return self._restamp(self.sub(numerator.div(denominator)), new_time)
 
     def apply(self, *args):
         raise NotImplementedError("UnsupportedOperationException: apply(lambda) cannot run on the device (:1146-1169)")

@@ -57,6 +57,14 @@ public:
     RV log() const override     { return unary(FMHIP_OP_LOG, std::log(value_)); }
     RV invert() const override  { return unary(FMHIP_OP_INVERT, 1.0 / value_); }
     RV abs() const override     { return unary(FMHIP_OP_ABS, std::fabs(value_)); }
+    // RandomVariableFromFloatArray.java:1395-1438: maximum of all three filtration times
+    RV addRatio(const RV& num, const RV& den) const override { return restamp(add(num->div(den)), std::max(std::max(time_, num->getFiltrationTime()), den->getFiltrationTime())); }
+    RV subRatio(const RV& num, const RV& den) const override { return restamp(sub(num->div(den)), std::max(std::max(time_, num->getFiltrationTime()), den->getFiltrationTime())); }
+    static RV restamp(const RV& rv, double time) {
+        const auto* c = dynamic_cast<const RandomVariableFromFloatArray*>(rv.get());
+        if (!c || c->time_ == time) return rv;
+        return c->a_ ? of(time, c->a_) : of(time, c->value_);
+    }
     RV isNaN() const override   { return unary(FMHIP_OP_ISNAN, value_ != value_ ? 1.0 : 0.0); }
     RV sin() const override     { return unary(FMHIP_OP_SIN, std::sin(value_)); }
     RV cos() const override     { return unary(FMHIP_OP_COS, std::cos(value_)); }
@@ -97,6 +105,12 @@ public:
         const double t = std::max(time_, rv->getFiltrationTime());
         if (!a_ && rv->isDeterministic()) return of(t, rv->doubleValue() / value_);
         if (!a_) return of(t, v1s1(FMHIP_OP_DIV_S, arr(rv, 0), value_));
+        if (rv->isDeterministic()) {             // :1138 (float)(randomVariable.get(i) / realizations[i]): the DOUBLE constant is divided
+            auto out = std::make_shared<std::vector<float>>(a_->size());
+            const double v = rv->doubleValue();
+            for (size_t i = 0; i < a_->size(); ++i) (*out)[i] = (float)(v / (double)(*a_)[i]);
+            return of(t, out);
+        }
         return of(t, v2s0(FMHIP_OP_DIV, arr(rv, size()), a_));
     }
     RV cap(const RV& rv) const override { return binary(rv, [&] { return rv->cap(self()); }, jmin(value_, det(rv)), FMHIP_OP_CAP, FMHIP_OP_CAP_S, false); }        // :1145

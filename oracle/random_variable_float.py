@@ -218,7 +218,7 @@ class RandomVariableFromFloatArray:
     def _div_rv(self, rv):      # :1082-1112 det receiver: (float)v / b[i]
         return self._binary(rv, lambda r: r.vid(self), _jdiv, "DIV", "VID_S",
                             scalar_shortcut=lambda s: self.div(s))
-    def _vid_rv(self, rv):      # :1115-1142 b[i] / a[i]   (stochastic branch divides in double, then narrows: same bits)
+    def _vid_rv(self, rv):      # :1115-1142 b[i] / a[i]
         if rv.getTypePriority() > self.getTypePriority(): return rv.div(self)
         new_time = max(self.time, rv.getFiltrationTime())
         if self.isDeterministic() and rv.isDeterministic():
@@ -226,7 +226,14 @@ class RandomVariableFromFloatArray:
         n = max(self.size(), rv.size())
         if self.isDeterministic():
             return RandomVariableFromFloatArray(new_time, f_v1s1("DIV_S", rv._f(n), self.value))
-        return RandomVariableFromFloatArray(new_time, f_v2s0("DIV", rv._f(n), self.realizations))
+        if rv.isDeterministic():
+            # :1138 `(float)(randomVariable.get(i) / realizations[i])`: get(i) of a constant is its DOUBLE value — the quotient
+            # is formed in double and narrowed once (differs from the fp32 quotient only for constants that are not fp32 values;
+            # RandomVariableCuda narrows the constant first, :1528, and so does the HIP mirror)
+            with np.errstate(all="ignore"):
+                q = np.float64(rv.get(0)) / self.realizations.astype(np.float64)
+            return RandomVariableFromFloatArray(new_time, q.astype(np.float32))
+        return RandomVariableFromFloatArray(new_time, f_v2s0("DIV", rv._f(n), self.realizations))   # double quotient of two fp32 values: same bits
     def _cap_rv(self, rv):      # :1145-1171
         return self._binary(rv, lambda r: r.cap(self), _jmin, "CAP", "CAP_S")
     def _floor_rv(self, rv):    # :1174-1200

@@ -10,6 +10,7 @@ import pytest
 from conftest import assert_bits_equal
 
 pytestmark = pytest.mark.gpu
+SCALE = int(__import__("os").environ.get("FMHIP_FUZZ_SCALE", "1"))      # one-off deep runs: FMHIP_FUZZ_SCALE=25
 
 UNARY = ["squared", "sqrt", "invert", "abs", "isNaN"]
 SCALAR = ["cap", "floor", "add", "sub", "bus", "mult", "div", "vid"]
@@ -29,7 +30,15 @@ def step(rng, vals):
         return f"{m}({a}, {s})", lambda v: getattr(v[a], m)(s)
     if kind == 2:
         m, a, b = BINARY[rng.integers(len(BINARY))], pick(), pick()
-        return f"{m}({a}, {b})", lambda v: getattr(v[a], m)(v[b])
+
+        def binary(v):
+            x, y = v[a], v[b]
+            if m == "vid" and y.isDeterministic() and not x.isDeterministic() and float(np.float32(y.doubleValue())) != y.doubleValue():
+                # the one branch where the reference's two classes differ in VALUE: the twin divides the double constant
+                # (twin:1138), RandomVariableCuda narrows it first (:1528) — compare on an fp32-representable constant
+                return x.vid(float(np.float32(y.doubleValue())))
+            return getattr(x, m)(y)
+        return f"{m}({a}, {b})", binary
     if kind == 3:
         m, a, b, s = ["accrue", "discount"][rng.integers(2)], pick(), pick(), float(SCALARS[rng.integers(len(SCALARS))])
         return f"{m}({a}, {b}, {s})", lambda v: getattr(v[a], m)(v[b], s)
@@ -44,7 +53,7 @@ def step(rng, vals):
 
 
 @pytest.mark.parametrize("fusion", [False, True])
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(20 * SCALE))
 def test_random_method_chains(gpu, oracle, seed, fusion):
     rng = np.random.default_rng(77000 + seed)
     n = int(rng.choice([1, 2, 513, 4099]))

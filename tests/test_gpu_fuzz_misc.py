@@ -9,9 +9,10 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+SCALE = int(__import__("os").environ.get("FMHIP_FUZZ_SCALE", "1"))      # one-off deep runs: FMHIP_FUZZ_SCALE=25
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * SCALE))
 def test_random_brownian_motion_configurations(gpu, oracle, seed):
     rng = np.random.default_rng(31000 + seed)
     steps, factors = int(rng.integers(1, 6)), int(rng.integers(1, 5))
@@ -40,7 +41,7 @@ def special_vector(oracle, rng, n):
     return x
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_random_reductions(gpu, oracle, seed):
     rng = np.random.default_rng(52000 + seed)
     n = int(rng.choice([1, 2, 3, 63, 64, 65, 1023, 2047, 2048, 2049, 8191, 8192, 8193, 65537, 300001]))

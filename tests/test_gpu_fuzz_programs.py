@@ -15,6 +15,7 @@ import pytest
 from conftest import assert_bits_equal
 
 pytestmark = pytest.mark.gpu
+SCALE = int(__import__("os").environ.get("FMHIP_FUZZ_SCALE", "1"))      # one-off deep runs: FMHIP_FUZZ_SCALE=25
 
 EXACT = [("SQUARED", 1, 0), ("SQRT", 1, 0), ("INVERT", 1, 0), ("ABS", 1, 0), ("ISNAN", 1, 0),
          ("CAP_S", 1, 1), ("FLOOR_S", 1, 1), ("ADD_S", 1, 1), ("SUB_S", 1, 1), ("BUS_S", 1, 1), ("MULT_S", 1, 1), ("DIV_S", 1, 1), ("VID_S", 1, 1),
@@ -90,7 +91,7 @@ def make_rows(oracle, rng, n_in, n, batch):
     return rows
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SCALE))
 def test_random_exact_programs(gpu, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     n_in = int(rng.integers(1, 7))
@@ -113,7 +114,7 @@ def test_random_exact_programs(gpu, oracle, seed):
             assert_bits_equal(o1[b][k], want[vid], f"oracle seed {seed} out {vid}")
 
 
-@pytest.mark.parametrize("seed", range(15))
+@pytest.mark.parametrize("seed", range(15 * SCALE))
 def test_random_programs_with_exp_log_tiers_identical(gpu, oracle, seed):
     rng = np.random.default_rng(5000 + seed)
     n_in = int(rng.integers(1, 5))
@@ -147,7 +148,7 @@ class _RV:
         return vals
 
 
-@pytest.mark.parametrize("seed", range(25))
+@pytest.mark.parametrize("seed", range(25 * SCALE))
 def test_random_lazy_chains_match_oracle(gpu, oracle, seed):
     """The lazy front-end with arbitrary DAGs (including ones far beyond one launch: splitting, escaping intermediates)."""
     rng = np.random.default_rng(9000 + seed)
