@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <random>
 #include <string>
 #include <vector>
 #include "../../finmath-lib-cuda-extensions_amd/host/random_variable.hpp"
@@ -78,7 +79,7 @@ int main() {
         { "mult_s", [](const RV& x, const RV&) { return x->mult(3.1415); }, false },
         { "div_xx", [](const RV& x, const RV&) { return x->div(x->add(1.0)); }, false }, { "div_yx", [](const RV& x, const RV& y) { return y->div(x); }, false },
         { "div_xy", [](const RV& x, const RV& y) { return x->div(y); }, false }, { "div_s", [](const RV& x, const RV&) { return x->div(3.1415); }, false },
-        { "vid_xy", [](const RV& x, const RV& y) { return x->vid(y); }, false }, { "vid_yx", [](const RV& x, const RV& y) { return y->vid(x); }, false },
+        { "vid_xy", [](const RV& x, const RV& y) { return x->vid(y->cap(0.75)->floor(0.75)); }, false }   /* fp32-valued constant: DESIGN.md §2, vid(constant) */, { "vid_yx", [](const RV& x, const RV& y) { return y->vid(x); }, false },
         { "vid_s", [](const RV& x, const RV&) { return x->vid(2.0); }, false }, { "bus_s", [](const RV& x, const RV&) { return x->bus(2.0); }, false },
         { "exp", [](const RV& x, const RV&) { return x->exp(); }, true }, { "log", [](const RV& x, const RV&) { return x->log(); }, true },
         { "pow", [](const RV& x, const RV&) { return x->pow(1.5); }, true },
@@ -129,6 +130,51 @@ int main() {
         const std::vector<double> av = getAverages({ xh, xh->squared(), hip.createRandomVariable(1.5) });
         EXPECT(av[0] == xh->getAverage() && av[1] == xh->squared()->getAverage() && av[2] == 1.5, "getAverages");
     }
+    // differential fuzzing of the dispatch logic: random method chains over constants and stochastic variables with different
+    // filtration times, the HIP mirror against the CPU twin class (same idea as tests/test_gpu_fuzz_mirror.py, C++ flavour)
+    for (int fusion = 0; fusion <= 1; ++fusion) {
+        check(fmhip_set_fusion(fusion, nullptr));
+        for (unsigned seed = 0; seed < 60; ++seed) {
+            std::mt19937 rng(9000 + seed);
+            auto pickInt = [&](int n) { return (int)(rng() % (unsigned)n); };
+            const int len = std::vector<int>{ 1, 2, 513, 4099 }[(size_t)pickInt(4)];
+            std::vector<double> xa((size_t)len), xb((size_t)len);
+            orc_java_random_doubles(700 + seed, len, xa.data()); orc_java_random_doubles(900 + seed, len, xb.data());
+            for (int i = 0; i < len; ++i) { xa[(size_t)i] = xa[(size_t)i] * 2.0 - 0.7; xb[(size_t)i] = xb[(size_t)i] * 2.0 - 0.7; }
+            std::vector<RV> h = { hip.createRandomVariable(1.0, xa), hip.createRandomVariable(2.5, xb), hip.createRandomVariable(0.5, 0.75), hip.createRandomVariable(3.0, -2.0) };
+            std::vector<RV> c = { cpu.createRandomVariable(1.0, xa), cpu.createRandomVariable(2.5, xb), cpu.createRandomVariable(0.5, 0.75), cpu.createRandomVariable(3.0, -2.0) };
+            const double scalars[] = { 0.5, 2.0, -1.5, 1.0 / 3.0, 0.0, 3.0 };
+            const int steps = 5 + pickInt(30);
+            bool ok = true;
+            std::string what;
+            for (int k = 0; k < steps && ok; ++k) {
+                const int kind = pickInt(7), a = pickInt((int)h.size()), b = pickInt((int)h.size()), d = pickInt((int)h.size()), m = pickInt(8);
+                const double sc = scalars[pickInt(6)];
+                auto apply = [&](const std::vector<RV>& v) -> RV {
+                    const RV& x = v[(size_t)a]; const RV& y = v[(size_t)b]; const RV& z = v[(size_t)d];
+                    switch (kind) {
+                    case 0: switch (m % 5) { case 0: return x->squared(); case 1: return x->sqrt(); case 2: return x->invert(); case 3: return x->abs(); default: return x->isNaN(); }
+                    case 1: switch (m) { case 0: return x->cap(sc); case 1: return x->floor(sc); case 2: return x->add(sc); case 3: return x->sub(sc); case 4: return x->bus(sc); case 5: return x->mult(sc); case 6: return x->div(sc); default: return x->vid(sc); }
+                    case 2: switch (m) { case 0: return x->cap(y); case 1: return x->floor(y); case 2: return x->add(y); case 3: return x->sub(y); case 4: return x->bus(y); case 5: return x->mult(y); case 6: return x->div(y);
+                            default:    // vid with a constant that is not an fp32 value: the one value-level branch where the classes differ
+                                if (y->isDeterministic() && !x->isDeterministic() && (double)(float)y->doubleValue() != y->doubleValue()) return x->vid((double)(float)y->doubleValue());
+                                return x->vid(y); }
+                    case 3: return (m & 1) ? x->accrue(y, sc) : x->discount(y, sc);
+                    case 4: return x->addProduct(y, sc);
+                    case 5: switch (m % 3) { case 0: return x->addProduct(y, z); case 1: return x->addRatio(y, z); default: return x->subRatio(y, z); }
+                    default: return x->choose(y, z);
+                    }
+                };
+                const RV rh = apply(h), rc = apply(c);
+                what = "kind " + std::to_string(kind) + " m " + std::to_string(m) + " (" + std::to_string(a) + "," + std::to_string(b) + "," + std::to_string(d) + ")";
+                ok = rh->isDeterministic() == rc->isDeterministic() && rh->getFiltrationTime() == rc->getFiltrationTime()
+                     && sameBits(rh->getRealizations(), rc->getRealizations(), false);
+                h.push_back(rh); c.push_back(rc);
+            }
+            if (!ok) { std::printf("FAIL fuzz seed %u fusion %d at %s\n", seed, fusion, what.c_str()); ++failures; }
+        }
+    }
+    check(fmhip_set_fusion(0, nullptr));
     // host-side cold paths (sort on the host, both back ends through the same interface code)
     {
         const RV xh = hip.createRandomVariable(0.0, stream), xc = cpu.createRandomVariable(0.0, stream);
