@@ -182,7 +182,8 @@ int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
     return guarded([&] {
         need(n_launches, "n_launches");
         Engine::get().require_init();
-        *n_launches = 1 + (Engine::get().program(p)->n_red > 0 ? 1 : 0);
+        (void)Engine::get().program(p);          // validates the handle
+        *n_launches = 1;                         // fused reductions are finished inside the same launch
     });
 }
 int fmhip_program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs,

@@ -1,8 +1,8 @@
 // fm_kernel_parts.hpp — device building blocks shared by the interpreter (kernels.hip) and by the specialised kernels the
 // JIT tier generates (jit.cpp → hiprtc): global-address-space vector pointers, wave64 DPP reduction, the per-pass
 // {Σ, Σ², min, max} accumulation and the workgroup combine.  Sharing them is what makes the two tiers produce
-// BIT-IDENTICAL results (same per-lane accumulation order, same wave/LDS combine, same partial layout for
-// fm_finalize_kernel), so a program may switch tier between two launches without any observable difference.
+// BIT-IDENTICAL results (same per-lane accumulation order, same wave/LDS combine, same final combine of the partials),
+// so a program may switch tier between two launches without any observable difference.
 #pragma once
 #include "fm_program.h"
 #include "fm_device_math.hpp"
@@ -108,16 +108,38 @@ __device__ __forceinline__ void red_finish(const double shift, const double acc_
     if (shift == 0.0) nan_mask |= __ballot(acc_sq != acc_sq);
 }
 
+// fp64 min/max with java.lang.Math semantics for the final combine of the per-workgroup partials
+__device__ __forceinline__ double jmin_d(double a, double b) {
+    if (a != a) return a;
+    if (a == 0.0 && b == 0.0 && (__double_as_longlong(b) < 0)) return b;
+    return (a <= b) ? a : b;
+}
+__device__ __forceinline__ double jmax_d(double a, double b) {
+    if (a != a) return a;
+    if (a == 0.0 && b == 0.0 && (__double_as_longlong(a) < 0)) return b;
+    return (a >= b) ? a : b;
+}
+
+// Device-coherent accesses for the hand-off between workgroups (possibly on different XCDs, whose L2s are not coherent
+// with each other): `sc1` stores / loads go through to memory, no cache-wide write-back or invalidate is needed.
+__device__ __forceinline__ void store_coherent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup and reduction:
-// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.
+// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  The LAST workgroup of a row to arrive (device-scope counter) then sums
+// the row's partials in a FIXED order (thread t takes workgroups t, t+256, …, then an LDS tree) and writes the final
+// moments: deterministic, no float atomics, and no second launch.
 template <int NRED>
 __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], const double (&acc_sq)[NRED],
                                               const float (&acc_min)[NRED], const float (&acc_max)[NRED],
                                               const unsigned long long (&nan_mask)[NRED],
-                                              double* __restrict__ partials, const uint32_t row)
+                                              double* __restrict__ partials, const uint32_t row,
+                                              double* __restrict__ results, uint32_t* __restrict__ counters)
 {
     __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
     __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
+    __shared__ double sh[4][FM_BLOCK];
+    __shared__ uint32_t last_flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
@@ -138,10 +160,45 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
                 s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
                 mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
             }
-            double* __restrict__ out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
-            out[0] = s1; out[1] = s2; out[2] = (double)mn; out[3] = (double)mx;
+            double* out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
+            store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
         }
+        // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t arrived = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (arrived == gridDim.x - 1) ? 1u : 0u;
     }
+    __syncthreads();
+    if (last_flag == 0u) return;                                             // workgroup-uniform
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+        const double* p = partials + ((size_t)row * NRED + r) * gridDim.x * 4;
+        double s1 = 0.0, s2 = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += FM_BLOCK) {
+            s1 += load_coherent(p + b * 4 + 0); s2 += load_coherent(p + b * 4 + 1);
+            mn = jmin_d(mn, load_coherent(p + b * 4 + 2)); mx = jmax_d(mx, load_coherent(p + b * 4 + 3));
+        }
+        sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = mn; sh[3][threadIdx.x] = mx;
+        __syncthreads();
+        for (int stride = FM_BLOCK / 2; stride > 0; stride >>= 1) {
+            if ((int)threadIdx.x < stride) {
+                sh[0][threadIdx.x] += sh[0][threadIdx.x + stride];
+                sh[1][threadIdx.x] += sh[1][threadIdx.x + stride];
+                sh[2][threadIdx.x] = jmin_d(sh[2][threadIdx.x], sh[2][threadIdx.x + stride]);
+                sh[3][threadIdx.x] = jmax_d(sh[3][threadIdx.x], sh[3][threadIdx.x + stride]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            double* o = results + ((size_t)row * NRED + r) * 4;
+            // NaN results are canonicalised: which NaN (sign, payload) an fp64 add of two NaNs returns depends on the operand
+            // order the compiler picked, and the two execution tiers must agree bit for bit
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const double v = sh[k][0]; o[k] = (v != v) ? __builtin_nan("") : v; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(counters + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 } // namespace fm

@@ -82,16 +82,12 @@ struct DevProgramArgs {
     uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; batch==1 → row block inline
     uint32_t variant, pad0_;             // kernel variant (FM_VARIANT_*)
     int64_t  n;                          // elements per vector
+    double*   results;                   // [batch][n_red][4] final {Σ, Σ², min, max} (written by the last workgroup of a row)
+    uint32_t* counters;                  // [batch] arrival counters of the fused final combine, zero between launches
     uint32_t out_reg[FM_MAX_OUT];        // 32-bit so that they are fetched with scalar loads (gfx9 has no s_load_u8)
     uint32_t red_reg[FM_MAX_RED];
     DevOp    ops[FM_MAX_OPS + 2];            // two slack entries: the kernel prefetches ops[pc+1], ops[pc+2]
     uint64_t inline_row[FM_ROW_WORDS_MAX];
-};
-
-struct DevFinalizeArgs {
-    const double* partials;   // [batch*n_red][n_blocks][4]
-    double*       out;        // [batch*n_red][4]
-    uint32_t      n_blocks;
 };
 
 } // namespace fm

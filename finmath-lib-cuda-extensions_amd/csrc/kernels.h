@@ -19,7 +19,6 @@ struct DevBmArgs {
 
 hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double* partials,
                           uint32_t blocks_per_row, uint32_t batch, hipStream_t st);
-hipError_t launch_finalize(const DevFinalizeArgs& a, uint32_t n_results, hipStream_t st);
 hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st);
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st);
 

@@ -7,7 +7,6 @@
 //                       RandomVariableCuda.java:483-557 + the 27 kernels of RandomVariableCudaKernel.cu),
 //                       optionally ending in fused {Σ, Σ², min, max} reductions (replaces the
 //                       D2H-and-host-loop reductions, RandomVariableCuda.java:830-901).
-//   fm_finalize_kernel  deterministic combine of the per-workgroup reduction partials.
 //   fm_bm_kernel        counter-based Philox4x32-10 + Box–Muller normal increments (replaces
 //                       curandGenerateNormal, BrownianMotionCudaWithRandomVariableCuda.java:168-178).
 //   fm_fill_kernel      constant fill.
@@ -201,48 +200,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     for (int r = 0; r < NRED; ++r) red_finish(reinterpret_cast<const double*>(rowp)[n_in + n_out + r], acc_sq[r], nan_mask[r]);
 
     // ---- workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup
-    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row);
-}
-
-// Deterministic second stage: one workgroup per (row, reduction) sums the block partials in a fixed order.
-__device__ __forceinline__ double jmin_d(double a, double b) {
-    if (a != a) return a;
-    if (a == 0.0 && b == 0.0 && (__double_as_longlong(b) < 0)) return b;
-    return (a <= b) ? a : b;
-}
-__device__ __forceinline__ double jmax_d(double a, double b) {
-    if (a != a) return a;
-    if (a == 0.0 && b == 0.0 && (__double_as_longlong(a) < 0)) return b;
-    return (a >= b) ? a : b;
-}
-
-__global__ void __launch_bounds__(FM_BLOCK) fm_finalize_kernel(const DevFinalizeArgs A)
-{
-    __shared__ double sh[4][FM_BLOCK];
-    const double* __restrict__ p = A.partials + (size_t)blockIdx.x * A.n_blocks * 4;
-    double s1 = 0.0, s2 = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
-    for (uint32_t b = threadIdx.x; b < A.n_blocks; b += FM_BLOCK) {
-        s1 += p[b * 4 + 0]; s2 += p[b * 4 + 1];
-        mn = jmin_d(mn, p[b * 4 + 2]); mx = jmax_d(mx, p[b * 4 + 3]);
-    }
-    sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = mn; sh[3][threadIdx.x] = mx;
-    __syncthreads();
-    for (int stride = FM_BLOCK / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + stride];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + stride];
-            sh[2][threadIdx.x] = jmin_d(sh[2][threadIdx.x], sh[2][threadIdx.x + stride]);
-            sh[3][threadIdx.x] = jmax_d(sh[3][threadIdx.x], sh[3][threadIdx.x + stride]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        double* __restrict__ o = A.out + (size_t)blockIdx.x * 4;
-        // NaN results are canonicalised: which NaN (sign, payload) an fp64 add of two NaNs returns depends on the operand
-        // order the compiler picked, and the two execution tiers must agree bit for bit
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const double v = sh[k][0]; o[k] = (v != v) ? __builtin_nan("") : v; }
-    }
+    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row, A.results, A.counters);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,12 +357,6 @@ hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double*
     case 2:  return launch_program_nred<2>(a, rows, partials, grid, st);
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_finalize(const DevFinalizeArgs& a, uint32_t n_results, hipStream_t st)
-{
-    hipLaunchKernelGGL(fm_finalize_kernel, dim3(n_results), dim3(FM_BLOCK), 0, st, a);
-    return hipGetLastError();
 }
 
 hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st)

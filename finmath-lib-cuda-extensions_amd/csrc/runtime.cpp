@@ -142,6 +142,9 @@ void Engine::init(int device_index) {
     ring_cap_ = size_t(4) << 20;
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
+    hip_check(hipMalloc((void**)&counters_dev_, 65536 * sizeof(uint32_t)), "hipMalloc(counters)");
+    hip_check(hipMemsetAsync(counters_dev_, 0, 65536 * sizeof(uint32_t), stream_), "hipMemset(counters)");
+    hip_check(hipStreamSynchronize(stream_), "init sync");
     ring_off_ = 0;
     device_ = device_index;
     if (const char* e = std::getenv("FMHIP_JIT")) {
@@ -177,6 +180,8 @@ void Engine::shutdown() {
     if (stage_) (void)hipHostFree(stage_);
     if (ring_host_) (void)hipHostFree(ring_host_);
     if (ring_dev_) (void)hipFree(ring_dev_);
+    if (counters_dev_) (void)hipFree(counters_dev_);
+    counters_dev_ = nullptr;
     stage_ = ring_host_ = ring_dev_ = nullptr; stage_cap_ = ring_cap_ = ring_off_ = 0;
     (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
@@ -613,6 +618,8 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         if (dev_moments) results = dev_moments;
         else { try { results = pool_.alloc((size_t)batch * n_red * 32, &results_cap); } catch (...) { pool_.release(partials, partials_cap); throw; } }
     }
+    args.results = (double*)results;
+    args.counters = counters_dev_;
     auto cleanup = [&]() {
         if (partials) pool_.release(partials, partials_cap);
         if (results && !dev_moments) pool_.release(results, results_cap);
@@ -645,10 +652,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
                           profile_tags_.push_back({ p->n_ops, p->n_in, p->n_out, n_red, batch, used_jit ? 1 : 0, n }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
         algorithmic_bytes_ += 4 * n * (int64_t)(p->n_in + p->n_out) * batch;
-        if (n_red > 0) {
-            DevFinalizeArgs fa{ (const double*)partials, (double*)results, (uint32_t)bpr };
-            hip_check(launch_finalize(fa, (uint32_t)(batch * n_red), stream_), "launch fm_finalize_kernel");
-            n_launches_++;
+        if (n_red > 0) {                     // the final combine ran inside the same launch (last workgroup of each row)
             if (host_moments) {
                 const size_t bytes = (size_t)batch * n_red * 32;
                 void* st = ensure_stage(bytes);

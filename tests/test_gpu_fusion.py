@@ -62,7 +62,7 @@ def test_stream_s_batched_equals_single(gpu, oracle):
     rows = [[gpu.DeviceVector.from_host(a) for a in inputs(oracle, n, k)] for k in range(B)]
     before = gpu.pool_stats().n_kernel_launches
     outs, mom = p.run(rows)
-    assert gpu.pool_stats().n_kernel_launches - before == 2      # program + finalize, for the whole batch
+    assert gpu.pool_stats().n_kernel_launches - before == 1      # program incl. the fused final combine, for the whole batch
     for k in range(B):
         single, m1 = p.run([rows[k]])
         assert_bits_equal(outs[k][0].to_float32(), single[0][0].to_float32(), f"row {k}")
