@@ -78,3 +78,42 @@ def test_random_method_chains(gpu, oracle, seed, fusion):
                     assert_bits_equal(np.asarray(h.getRealizations(), dtype=np.float32), np.asarray(c.getRealizations(), dtype=np.float32), f"value {k}")
     finally:
         gpu.set_fusion(prev)
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_random_aad_gradients_device_vs_twin(gpu, oracle, seed):
+    """The adjoint sweep over random expressions: AAD(RandomVariableHip) against AAD(CPU twin) — every gradient entry bit for
+    bit (the sweep is written in RandomVariable operations, so this also fuzzes the mirror's dispatch with the constants and
+    indicator variables the partial derivatives introduce)."""
+    rng = np.random.default_rng(88000 + seed)
+    n = int(rng.choice([2, 513, 4099]))
+    xs = [oracle.java_random_doubles(300 + seed * 3 + k, n) * 1.5 + 0.25 for k in range(2)]       # positive: sqrt / invert stay finite
+
+    def build(factory_inner, mk):
+        f = gpu.RandomVariableDifferentiableAADFactory(factory_inner)
+        leaves = [f.createRandomVariable(1.0, xs[0]), f.createRandomVariable(2.5, xs[1]), f.createRandomVariable(0.5, 0.75), f.createRandomVariable(3.0, 1.25)]
+        return f, leaves
+
+    _, hip = build(gpu.RandomVariableHipFactory(), None)
+    _, cpu = build(oracle.RandomVariableFloatFactory(), None)
+    hip_leaves, cpu_leaves = list(hip), list(cpu)
+    prev = gpu.set_fusion(bool(seed & 1))
+    try:
+        with np.errstate(all="ignore"):
+            r2 = np.random.default_rng(99000 + seed)
+            for k in range(int(r2.integers(3, 14))):
+                while True:
+                    what, fn = step(r2, hip)
+                    if not what.startswith(("isNaN", "choose")) and "vid(" not in what:      # isNaN has no derivative; choose(trigger) only selects
+                        break
+                hip.append(fn(hip)); cpu.append(fn(cpu))
+            gh, gc = hip[-1].getGradient(), cpu[-1].getGradient()
+            for lh, lc in zip(hip_leaves, cpu_leaves):
+                a, b = gh.get(lh.getID()), gc.get(lc.getID())
+                assert (a is None) == (b is None)
+                if a is None:
+                    continue
+                av, bv = np.asarray(a.getRealizations(), dtype=np.float32), np.asarray(b.getRealizations(), dtype=np.float32)
+                assert_bits_equal(np.broadcast_to(av, np.broadcast_shapes(av.shape, bv.shape)).copy(), np.broadcast_to(bv, np.broadcast_shapes(av.shape, bv.shape)).copy(), f"gradient seed {seed}")
+    finally:
+        gpu.set_fusion(prev)
