@@ -115,6 +115,10 @@ def lmm_workload(args):
     import subprocess
     lmm_hip = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
     lmm_cpu = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
+    if not os.path.exists(lmm_hip):          # build products of csrc/Makefile and oracle/Makefile
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "csrc")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(lmm_cpu):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     paths = args.paths                      # per GPU; configs[4] = 1M paths on each of 8 GPUs (path sharding, weak scaling)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     cmd = [lmm_hip, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)]

@@ -16,7 +16,16 @@ LMM_HIP = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip"
 LMM_CPU = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
 
 
+def ensure_built():
+    """The driver binaries are build products (csrc/Makefile, oracle/Makefile): build them if this tree has not been built."""
+    if not os.path.exists(LMM_HIP):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "csrc")], stdout=subprocess.DEVNULL)
+    if not os.path.exists(LMM_CPU):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+
+
 def run(binary, *args):
+    ensure_built()
     out = subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     return json.loads(out.stdout.strip().splitlines()[-1])
