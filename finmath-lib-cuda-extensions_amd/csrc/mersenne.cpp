@@ -5,8 +5,11 @@
 // (LIBORMarketModelCalibrationATMTest.java:283, MonteCarloBlackScholesModelTest.java:78-85): a CPU generator whose
 // increments reach the device through factory.createRandomVariable(time, double[]).  That class lives in finmath-lib
 // 5.1.3 (NOT vendored); what is restated here from published specifications:
-//   - MT19937 (Matsumoto & Nishimura) with the init_genrand seeding that org.apache.commons.math3.random.MersenneTwister
-//     applies to an int seed, and commons-math3's nextDouble() = ((next(26) << 26) | next(26)) · 2^-52;
+//   - MT19937 (Matsumoto & Nishimura) seeded the way org.apache.commons.math3.random.MersenneTwister(long) does it:
+//     finmath's wrapper net.finmath.randomnumbers.MersenneTwister takes a `long seed`, so the test's int seed is widened and
+//     commons-math3 runs init_by_array({(int)(seed >>> 32), (int)seed}) after init_genrand(19650218) [unverified against
+//     the jar: an `int` overload would use plain init_genrand(seed)], and commons-math3's
+//     nextDouble() = ((next(26) << 26) | next(26)) · 2^-52;
 //   - the inverse normal CDF by Wichura's algorithm AS 241 (PPND16), which finmath's NormalDistribution uses;
 //   - increment = inverseCDF(uniform) · sqrt(dt).
 // The draw order (path-major: for path, for time step, for factor) is [unverified: finmath-lib source not available];
@@ -20,9 +23,31 @@ namespace fm {
 
 struct MT19937 {
     uint32_t mt[624]; int mti;
-    explicit MT19937(uint32_t seed) {
+    void init_genrand(uint32_t seed) {
         mt[0] = seed;
         for (mti = 1; mti < 624; ++mti) mt[mti] = 1812433253u * (mt[mti - 1] ^ (mt[mti - 1] >> 30)) + (uint32_t)mti;
+    }
+    // commons-math3 MersenneTwister.setSeed(int[]) = the reference init_by_array of mt19937ar.c
+    void init_by_array(const uint32_t* key, int len) {
+        init_genrand(19650218u);
+        int i = 1, j = 0;
+        for (int k = (624 > len ? 624 : len); k != 0; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            ++i; ++j;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= len) j = 0;
+        }
+        for (int k = 623; k != 0; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            ++i;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+        mti = 624;
+    }
+    explicit MT19937(int64_t seed) {                            // MersenneTwister(long): setSeed(new int[]{ hi, lo })
+        const uint32_t key[2] = { (uint32_t)((uint64_t)seed >> 32), (uint32_t)((uint64_t)seed & 0xffffffffu) };
+        init_by_array(key, 2);
     }
     uint32_t next32() {
         if (mti >= 624) {
@@ -76,7 +101,7 @@ double inverse_normal_cdf(double p) {
 
 // out[(step*n_factors + factor)*n_paths + path], doubles (host).  No device involved.
 void mersenne_increments(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, double* out) {
-    MT19937 mt((uint32_t)seed);
+    MT19937 mt((int64_t)seed);                                  // the int seed of the finmath constructor, widened
     std::vector<double> sq((size_t)n_steps);
     for (int i = 0; i < n_steps; ++i) sq[(size_t)i] = std::sqrt(dt[i]);
     for (int64_t path = 0; path < n_paths; ++path)

@@ -1,5 +1,5 @@
 """CPU-only: the host-side Mersenne-Twister Brownian motion (csrc/mersenne.cpp) against published
-known answers — MT19937 reference outputs (numpy's MT19937 with the same init_genrand seeding), AS 241 against scipy's
+known answers — MT19937 reference outputs (numpy's MT19937 with the same init_by_array seeding), AS 241 against scipy's
 normal quantile — and the statistical bounds the reference asserts for Brownian increments (BrownianMotionTest.java:120-121)."""
 import math
 
@@ -18,18 +18,21 @@ def test_inverse_normal_cdf_as241(fm):
 
 
 def test_mt19937_stream_matches_reference_generator(fm):
-    """uniform = ((next32()>>6) << 26 | (next32()>>6)) * 2^-52 from MT19937 seeded with init_genrand(seed): reproduce with
-    numpy's bit generator (legacy integer seeding = init_genrand) and invert our increments back to uniforms."""
+    """uniform = ((next32()>>6) << 26 | (next32()>>6)) * 2^-52 from MT19937 seeded by init_by_array({hi, lo}) of the widened
+    seed (commons-math3 MersenneTwister(long)): reproduce with numpy's legacy array seeding (= init_by_array) and invert our
+    increments back to uniforms; positive and negative (sign-extended) seeds."""
     from scipy.stats import norm
-    seed, n_paths = 31415, 50
-    inc = fm.mersenne_increments(seed, [1.0], 1, n_paths)[0, 0]
-    raw = np.random.RandomState(seed)._bit_generator.random_raw(2 * n_paths).astype(np.uint64) if hasattr(np.random.RandomState(seed), "_bit_generator") else None
-    if raw is None:
-        import pytest; pytest.skip("numpy without RandomState._bit_generator")
-    u = (((raw[0::2] >> np.uint64(6)) << np.uint64(26)) | (raw[1::2] >> np.uint64(6))).astype(np.float64) * 2.0 ** -52
-    assert np.max(np.abs(norm.cdf(inc) - u)) < 1e-15
-    # first output of MT19937 with the canonical seed 5489 is 3499211612 (Matsumoto & Nishimura reference implementation)
+    for seed in (31415, -7, 1):
+        n_paths = 50
+        inc = fm.mersenne_increments(seed, [1.0], 1, n_paths)[0, 0]
+        wide = seed & 0xffffffffffffffff
+        rs = np.random.RandomState(np.array([wide >> 32, wide & 0xffffffff], dtype=np.uint32))
+        raw = rs._bit_generator.random_raw(2 * n_paths).astype(np.uint64)
+        u = (((raw[0::2] >> np.uint64(6)) << np.uint64(26)) | (raw[1::2] >> np.uint64(6))).astype(np.float64) * 2.0 ** -52
+        assert np.max(np.abs(norm.cdf(inc) - u)) < 1e-15
+    # published known answers of mt19937ar.c: init_genrand(5489) -> 3499211612; init_by_array({0x123,0x234,0x345,0x456}) -> 1067595299
     assert int(np.random.RandomState(5489)._bit_generator.random_raw(1)[0]) == 3499211612
+    assert int(np.random.RandomState(np.array([0x123, 0x234, 0x345, 0x456], dtype=np.uint32))._bit_generator.random_raw(1)[0]) == 1067595299
 
 
 def test_draw_order_and_scaling(fm):
