@@ -195,7 +195,10 @@ void Engine::device_info(char* name, int len, int* cus, int64_t* hbm) {
     require_init();
     hipDeviceProp_t prop;
     hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
-    if (name && len > 0) { std::strncpy(name, prop.name, (size_t)len - 1); name[len - 1] = 0; }
+    if (name && len > 0) {          // some boxes report an empty marketing name: fall back to the architecture string
+        std::strncpy(name, prop.name[0] ? prop.name : prop.gcnArchName, (size_t)len - 1);
+        name[len - 1] = 0;
+    }
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
 }
