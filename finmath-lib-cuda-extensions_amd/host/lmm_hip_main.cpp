@@ -21,9 +21,14 @@ int main(int argc, char** argv) {
         RandomVariableHipFactory factory;
         lmm::Market m;
         const int64_t pathOffset = o.pathOffset + (int64_t)o.rank * o.paths;
-        BrownianMotionHip bm(m.timeDiscretization, 1, o.paths, o.seed, pathOffset);
+        BrownianMotionHip philox(m.timeDiscretization, 1, o.paths, o.seed, pathOffset);
+        // --brownian mersenne: the generator the reference's test injects (…ATMTest.java:283), drawn on the host and uploaded
+        // through the factory; a sequential stream, so it cannot be sharded by path offset
+        BrownianMotionFromMersenneRandomNumbers mersenne(m.timeDiscretization, 1, o.paths, (int)o.seed, &factory);
+        if (o.brownian == "mersenne" && o.world > 1) throw std::runtime_error("--brownian mersenne is a sequential stream: not available with --world > 1");
         lmm::Backend be;
-        be.factory = &factory; be.brownianMotion = &bm;
+        be.factory = &factory;
+        be.brownianMotion = (o.brownian == "mersenne") ? static_cast<const BrownianMotion*>(&mersenne) : &philox;
         be.flush = [] { check(fmhip_flush()); };
         be.jacobianBatch = o.jacobianBatch > 0 ? o.jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/fmhip.h"
+#include "mersenne.hpp"
 
 namespace fmhost {
 
@@ -505,6 +506,45 @@ private:
     TimeDiscretization td_;
     int factors_;
     int64_t paths_, seed_, offset_;
+    mutable std::vector<RV> inc_;
+};
+
+// ------------------------------------------------------------------ BrownianMotionFromMersenneRandomNumbers
+// finmath-lib's CPU generator (net.finmath.montecarlo.BrownianMotionFromMersenneRandomNumbers, not vendored; host/mersenne.hpp)
+// behind the BrownianMotion interface: the increments are drawn on the host and handed to the injected factory, so every
+// back end sees the same numbers (…ATMTest.java:283 passes the device factory exactly like this).
+class BrownianMotionFromMersenneRandomNumbers final : public BrownianMotion {
+public:
+    BrownianMotionFromMersenneRandomNumbers(TimeDiscretization td, int numberOfFactors, int64_t numberOfPaths, int seed, const RandomVariableFactory* factory)
+        : td_(std::move(td)), factors_(numberOfFactors), paths_(numberOfPaths), seed_(seed), factory_(factory) {}
+    RV getBrownianIncrement(int timeIndex, int factor) const override {
+        if (inc_.empty()) generate();
+        return inc_.at((size_t)timeIndex * factors_ + factor);
+    }
+    const TimeDiscretization& getTimeDiscretization() const override { return td_; }
+    int getNumberOfFactors() const override { return factors_; }
+    int64_t getNumberOfPaths() const override { return paths_; }
+    int getSeed() const { return seed_; }
+    RV getRandomVariableForConstant(double value) const override { return factory_->createRandomVariable(value); }
+private:
+    void generate() const {
+        const int steps = td_.getNumberOfTimeSteps();
+        std::vector<double> dt((size_t)steps);
+        for (int i = 0; i < steps; ++i) dt[(size_t)i] = td_.getTimeStep(i);
+        std::vector<double> all((size_t)steps * factors_ * (size_t)paths_);
+        mersenneIncrements(seed_, steps, factors_, paths_, dt.data(), all.data());
+        inc_.reserve((size_t)steps * factors_);
+        for (int i = 0; i < steps; ++i)
+            for (int f = 0; f < factors_; ++f) {
+                const double* p = all.data() + ((size_t)i * factors_ + f) * (size_t)paths_;
+                inc_.push_back(factory_->createRandomVariable(td_.getTime(i + 1), std::vector<double>(p, p + paths_)));
+            }
+    }
+    TimeDiscretization td_;
+    int factors_;
+    int64_t paths_;
+    int seed_;
+    const RandomVariableFactory* factory_;
     mutable std::vector<RV> inc_;
 };
 

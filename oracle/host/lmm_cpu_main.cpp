@@ -8,9 +8,11 @@ int main(int argc, char** argv) {
     try {
         RandomVariableFloatFactory factory;
         lmm::Market m;
-        BrownianMotionCpu bm(m.timeDiscretization, 1, o.paths, o.seed, o.pathOffset);
+        BrownianMotionCpu philox(m.timeDiscretization, 1, o.paths, o.seed, o.pathOffset);
+        BrownianMotionFromMersenneRandomNumbers mersenne(m.timeDiscretization, 1, o.paths, (int)o.seed, &factory);
         lmm::Backend be;
-        be.factory = &factory; be.brownianMotion = &bm;
+        be.factory = &factory;
+        be.brownianMotion = (o.brownian == "mersenne") ? static_cast<const BrownianMotion*>(&mersenne) : &philox;
         lmm::runAndReport(o, be, "cpu-twin", [] { return std::string(", \"cores\": 1"); });
     } catch (const std::exception& e) { std::fprintf(stderr, "lmm_cpu: %s\n", e.what()); return 1; }
     return 0;

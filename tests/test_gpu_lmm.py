@@ -87,3 +87,15 @@ def test_lock_step_jacobian_batches_give_the_same_calibration():
     assert one["parameters"] == many["parameters"] and one["rms_deviation"] == many["rms_deviation"]
     assert one["evaluations"] == many["evaluations"]
     assert many["kernel_launches"] < 0.5 * one["kernel_launches"]
+
+
+def test_mersenne_brownian_motion_through_the_factory():
+    """--brownian mersenne: finmath's CPU generator (the one the reference's test injects, …ATMTest.java:283) creates its
+    increments through the back end's factory — the HIP engine and the CPU twin then see the very same numbers and the
+    objective evaluation agrees like with the device generator."""
+    cpu = run(LMM_CPU, "--paths", 4000, "--mode", "evaluate", "--brownian", "mersenne")
+    hip = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate", "--brownian", "mersenne")
+    philox = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate")
+    a, b, c = np.array(cpu["model_volatility"]), np.array(hip["model_volatility"]), np.array(philox["model_volatility"])
+    assert np.max(np.abs(a - b) / a) <= 1e-12
+    assert np.max(np.abs(b - c) / c) > 1e-6 and np.max(np.abs(b - c) / c) < 0.2       # another stream of random numbers, same model
