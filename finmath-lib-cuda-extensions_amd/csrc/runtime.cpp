@@ -670,7 +670,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
 
 // ---------------------------------------------------------------- lazy front-end
 
-static const int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is executed on its own accord
+static const int FUSION_MAX_WEIGHT = 1000;  // pending ops below one node before it is executed on its own accord (bounds host memory of a caller that never reads; larger components are cut into launches by run_big_group)
 
 fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
     HostTimer timer(HostProfile::CALL);
@@ -811,6 +811,146 @@ bool Engine::run_dags(std::vector<Dag>& dags) {
     return true;
 }
 
+// ---------------------------------------------------------------- components larger than one launch
+//
+// A connected component of pending work that does not fit one launch (12 inputs / 8 outputs / 15 live values / 128
+// micro-ops) is cut into consecutive SEGMENTS of its topological order.  Every prefix of a topological order is closed
+// under dependencies, so a segment only reads materialised vectors and outputs of earlier segments; its outputs are the
+// values somebody outside the segment still needs.  Each segment is the longest one that still fits (found once per
+// component SHAPE and cached); components of identical shape — e.g. the same Euler step of several parameter sets — are
+// cut identically and their segments run as rows of the same launches.
+
+struct Engine::BigDag {
+    std::vector<Node*> roots;
+    std::vector<Node*> order;       // all pending nodes of the component, operands before users
+    std::string sig;                // shape: per op {opcode, operand ids (16 bit), escapes?}
+};
+
+bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
+    big.roots = roots;
+    const uint64_t ep = ++epoch_;
+    std::vector<std::pair<Node*, int>> stack;
+    int n_leaves = 0;
+    std::vector<Node*> leaves;
+    auto visit = [&](Node* nd) { nd->mark = ep; nd->tmp_id = -1; nd->tmp_uses = 0; };
+    for (Node* root : roots) {
+        if (root->mark == ep) continue;
+        visit(root);
+        stack.push_back({ root, 0 });
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            Node* nd = top.first;
+            if (top.second < nd->n_in) {
+                Node* c = nd->in[top.second++];
+                if (c->buf) { if (c->mark != ep) { visit(c); c->tmp_id = --n_leaves; leaves.push_back(c); } }      // leaves: -1, -2, …
+                else { if (c->mark != ep) { visit(c); stack.push_back({ c, 0 }); } c->tmp_uses++; }
+            } else { big.order.push_back(nd); stack.pop_back(); }
+        }
+    }
+    if (big.order.size() > 60000) return false;
+    big.sig.clear();
+    big.sig.reserve(big.order.size() * 8 + 8);
+    big.sig.push_back((char)('0' + math_mode));
+    auto put16 = [&](int v) { big.sig.push_back((char)(v & 0xff)); big.sig.push_back((char)((v >> 8) & 0xff)); };
+    for (size_t i = 0; i < big.order.size(); ++i) {
+        Node* nd = big.order[i];
+        nd->tmp_id = (int)i;
+        big.sig.push_back((char)nd->opcode);
+        for (int k = 0; k < 3; ++k) put16(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0);
+        big.sig.push_back((nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) ? 'x' : '.');      // needed outside the component
+    }
+    return true;
+}
+
+// The launchable DAG of order[s, e): inputs in first-use order, outputs = values needed outside the segment.
+bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag) {
+    const uint64_t ep = ++epoch_, ep_leaf = ++epoch_;          // mark == ep: produced inside the segment; == ep_leaf: registered input
+    dag = Dag();
+    for (size_t i = s; i < e; ++i) { Node* nd = big.order[i]; nd->mark = ep; nd->tmp_uses = 0; }
+    for (size_t i = s; i < e; ++i) {
+        Node* nd = big.order[i];
+        for (int k = 0; k < nd->n_in; ++k) {
+            Node* c = nd->in[k];
+            if (c->mark == ep) { c->tmp_uses++; continue; }
+            if (c->mark == ep_leaf) continue;
+            if (!c->buf) return false;                          // reads a value that is neither materialised nor produced here: not a valid cut
+            c->mark = ep_leaf;
+            dag.leaves.push_back(c);
+            if ((int)dag.leaves.size() > FM_MAX_IN) return false;
+        }
+    }
+    if (e - s > (size_t)FM_MAX_OPS) return false;
+    const int n_in = (int)dag.leaves.size();
+    for (int k = 0; k < n_in; ++k) dag.leaves[(size_t)k]->tmp_id = k;
+    dag.sig.push_back((char)('0' + math_mode)); dag.sig.push_back((char)n_in);
+    for (size_t i = s; i < e; ++i) {
+        Node* nd = big.order[i];
+        nd->tmp_id = n_in + (int)(i - s);
+        SsaOp op{ nd->opcode, -1, -1, -1, nd->scalar };
+        int* slots[3] = { &op.a, &op.b, &op.c };
+        for (int k = 0; k < nd->n_in; ++k) *slots[k] = nd->in[k]->tmp_id;
+        dag.order.push_back(nd);
+        dag.ops.push_back(op);
+        if (op_info(nd->opcode).scalar) dag.scalars.push_back((float)nd->scalar);
+        dag.sig.push_back((char)nd->opcode); dag.sig.push_back((char)(op.a + 1)); dag.sig.push_back((char)(op.b + 1)); dag.sig.push_back((char)(op.c + 1));
+    }
+    if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
+    for (size_t i = s; i < e; ++i) {
+        Node* nd = big.order[i];
+        if (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) { dag.outs.push_back(nd); dag.out_ids.push_back(nd->tmp_id); }   // a consumer outside [s, e)
+    }
+    if (dag.outs.empty() || (int)dag.outs.size() > FM_MAX_OUT) return false;
+    dag.roots = dag.outs;
+    dag.sig.push_back((char)0xff);
+    for (int v : dag.out_ids) dag.sig.push_back((char)(v + 1));
+    return true;
+}
+
+void Engine::run_big_group(std::vector<BigDag>& group) {
+    BigDag& g0 = group[0];
+    const size_t n_ops = g0.order.size();
+    std::vector<uint32_t>* cuts = nullptr;
+    auto it = split_cache_.find(g0.sig);
+    if (it != split_cache_.end()) cuts = &it->second;
+    std::vector<uint32_t> fresh;
+    size_t s = 0, stage = 0;
+    while (s < n_ops) {
+        size_t e = 0;
+        if (cuts) e = (*cuts)[stage];
+        else {
+            // longest segment starting at s that fits one launch.  Inputs grow monotonically with the end; outputs and live
+            // values do not: collect every end that passes the cheap checks, then take the largest one that also compiles.
+            std::vector<size_t> cheap;
+            for (size_t cand = s + 1; cand <= n_ops && cand - s <= (size_t)FM_MAX_OPS; ++cand) {
+                Dag d;
+                if (segment_dag(g0, s, cand, d)) cheap.push_back(cand);
+                else if ((int)d.leaves.size() > FM_MAX_IN) break;
+            }
+            for (size_t k = cheap.size(); k-- > 0 && e == 0;) {
+                Dag d;
+                segment_dag(g0, s, cheap[k], d);
+                if (!program_cache_.count(d.sig)) {
+                    try { program_cache_[d.sig] = compile(d.ops, (int)d.leaves.size(), d.out_ids, {}, nullptr, false); }
+                    catch (const Error& err) { if (err.code == FMHIP_ERR_PROGRAM_LIMIT) continue; throw; }
+                }
+                e = cheap[k];
+            }
+            if (e == 0) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "an operation does not fit one launch");
+            fresh.push_back((uint32_t)e);
+        }
+        std::vector<Dag> dags(group.size());
+        for (size_t c = 0; c < group.size(); ++c)
+            if (!segment_dag(group[c], s, e, dags[c])) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "inconsistent segment of a split component");
+        const size_t max_batch = 1024;
+        for (size_t off = 0; off < dags.size(); off += max_batch) {
+            std::vector<Dag> part(std::make_move_iterator(dags.begin() + off), std::make_move_iterator(dags.begin() + std::min(dags.size(), off + max_batch)));
+            if (!run_dags(part)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "segment of a split component does not fit one launch");
+        }
+        s = e; ++stage;
+    }
+    if (!cuts) split_cache_[g0.sig] = fresh;
+}
+
 bool Engine::try_fused(const std::vector<Node*>& roots) {
     std::vector<Dag> dags(1);
     if (!build_dag(roots, dags[0])) return false;
@@ -821,14 +961,10 @@ void Engine::materialize(const std::vector<Node*>& targets) {
     for (Node* t : targets) {
         if (t->buf) continue;
         if (try_fused({ t })) continue;
-        // Too large for one launch: execute the operands' expressions first, then this node alone.
-        std::vector<Node*> ins;
-        for (int k = 0; k < t->n_in; ++k) if (!t->in[k]->buf) ins.push_back(t->in[k]);
-        if (ins.empty()) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "a single op does not fit one launch");
-        for (Node* in : ins) { in->refs_int++; }
-        try { materialize(ins); } catch (...) { for (Node* in : ins) in->refs_int--; throw; }
-        for (Node* in : ins) in->refs_int--;
-        if (!try_fused({ t })) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "expression does not fit one launch after splitting");
+        // Too large for one launch: cut the component into consecutive segments (run_big_group)
+        std::vector<BigDag> one(1);
+        if (!build_big({ t }, one[0])) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "expression too large");
+        run_big_group(one);
     }
 }
 
@@ -894,8 +1030,27 @@ void Engine::flush_all() {
                 if (!run_dags(part)) for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r);
             }
         }
-        // components that do not fit one launch: root by root (shared parts escape and are reused)
-        for (Node* r : leftovers) if (!r->buf) materialize({ r });
+        // components that do not fit one launch: cut into segments; components of identical shape share the cuts and the launches
+        if (!leftovers.empty()) {
+            std::unordered_map<Node*, int> comp_of;                      // root -> component key
+            for (int c : comp_order) for (Node* r : comps[c]) comp_of[r] = c;
+            std::unordered_set<int> big_comps;
+            std::vector<int> big_order;
+            for (Node* r : leftovers) { const int c = comp_of[r]; if (big_comps.insert(c).second) big_order.push_back(c); }
+            std::unordered_map<std::string, std::vector<BigDag>> big_groups;
+            std::vector<std::string> big_group_order;
+            for (int c : big_order) {
+                std::vector<Node*> roots;
+                for (Node* r : comps[c]) if (!r->buf) roots.push_back(r);
+                if (roots.empty()) continue;
+                BigDag b;
+                if (!build_big(roots, b)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "pending expression too large");
+                std::string key = b.sig; key.push_back('#'); key += std::to_string(roots[0]->n);
+                if (!big_groups.count(key)) big_group_order.push_back(key);
+                big_groups[key].push_back(std::move(b));
+            }
+            for (const std::string& key : big_group_order) run_big_group(big_groups[key]);
+        }
     }
 }
 

@@ -197,6 +197,11 @@ private:
     Program* reduce_program();
     bool try_fused(const std::vector<Node*>& roots);
     struct Dag;
+    struct BigDag;
+    bool build_big(const std::vector<Node*>& roots, BigDag& big);
+    bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
+    void run_big_group(std::vector<BigDag>& group);
+    std::unordered_map<std::string, std::vector<uint32_t>> split_cache_;      // component shape -> segment ends (partitioner)
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
     bool run_dags(std::vector<Dag>& dags);
 };

@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
         be.factory = &factory;
         be.brownianMotion = (o.brownian == "mersenne") ? static_cast<const BrownianMotion*>(&mersenne) : &philox;
         be.flush = [] { check(fmhip_flush()); };
+        if (o.chunk > 0) be.chunk = o.chunk;
         be.jacobianBatch = o.jacobianBatch > 0 ? o.jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         be.averages = [](const std::vector<RV>& v) { return getAverages(v); };

@@ -12,6 +12,7 @@ struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
     int world = 1, rank = 0; std::string ncclIdFile;
+    int chunk = 0;                                         // LIBOR components per fused launch; 0 = back end default
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     std::string brownian = "philox";                        // philox (counter-based, on the device) | mersenne (finmath's CPU generator through the factory)
     bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU
@@ -33,6 +34,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--profile") o.profile = true;
         else if (a == "--brownian") o.brownian = next();
         else if (a == "--jacobian-batch") o.jacobianBatch = std::atoi(next());
+        else if (a == "--chunk") o.chunk = std::atoi(next());
         else if (a == "--verbose") o.verbose = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); std::exit(2); }
     }
