@@ -114,6 +114,7 @@ void Engine::require_init() const {
     if (bound_device != device_) { hip_check(hipSetDevice(device_), "hipSetDevice"); bound_device = device_; }
 }
 
+void fusion_max_weight_override(int v);      // FMHIP_FUSION_MAX_WEIGHT (experiments)
 HostProfile g_host_profile;
 void HostProfile::report() const {
     static const char* names[N_SLOTS] = { "call (record one method)", "release", "flush_all (total)", "  build_dag", "  run_dags (total)", "    launch (total)",
@@ -155,6 +156,7 @@ void Engine::init(int device_index) {
     }
     jit_.start(device_index);
     g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr;
+    if (const char* e = std::getenv("FMHIP_FUSION_MAX_WEIGHT")) { const int v = std::atoi(e); if (v > 0) fusion_max_weight_override(v); }
     initialized_ = true;
 }
 
@@ -670,7 +672,12 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
 
 // ---------------------------------------------------------------- lazy front-end
 
-static const int FUSION_MAX_WEIGHT = 1000;  // pending ops below one node before it is executed on its own accord (bounds host memory of a caller that never reads; larger components are cut into launches by run_big_group)
+static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is executed on its own accord.  Measured on the LMM
+                                       // calibration (same box, FMHIP_FUSION_MAX_WEIGHT=40 vs 1000): 6.3 s vs 6.8-7.6 s although the
+                                       // larger value needs 3x fewer launches — executing early overlaps device work with the
+                                       // recording of the next methods, and that path is host-bound
+
+void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
 
 fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
     HostTimer timer(HostProfile::CALL);
