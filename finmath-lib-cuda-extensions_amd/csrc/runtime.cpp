@@ -173,6 +173,8 @@ void Engine::shutdown() {
     }
     nodes_.clear();
     pending_.clear();
+    for (Node* nd : node_pool_) delete nd;
+    node_pool_.clear();
     for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
     programs_.clear();
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
@@ -246,7 +248,9 @@ void Engine::buffer_unref(Buffer* b) {
 }
 
 Node* Engine::new_node(int64_t n) {
-    Node* nd = new Node();
+    Node* nd;
+    if (!node_pool_.empty()) { nd = node_pool_.back(); node_pool_.pop_back(); *nd = Node(); }      // recycled: no malloc on the hot path
+    else nd = new Node();
     nd->id = next_id_++;
     nd->n = n;
     nd->refs_ext = 1;
@@ -275,7 +279,7 @@ void Engine::node_maybe_free(Node* nd) {
     if (nd->refs_ext > 0 || nd->refs_int > 0) return;
     if (nd->buf) buffer_unref(nd->buf);
     else { pending_.erase(nd); drop_expression(nd); }
-    delete nd;
+    if (node_pool_.size() < 65536) node_pool_.push_back(nd); else delete nd;
 }
 
 void Engine::retain(fmhip_vec h) { require_init(); node(h)->refs_ext++; }

@@ -163,6 +163,7 @@ private:
     int64_t next_id_ = 1;
     std::unordered_map<int64_t, Node*> nodes_;
     std::unordered_set<Node*> pending_;                          // nodes without storage (lazy expressions)
+    std::vector<Node*> node_pool_;                               // recycled Node objects
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
     int64_t n_launches_ = 0, n_ops_executed_ = 0, n_jit_launches_ = 0, algorithmic_bytes_ = 0;

@@ -63,7 +63,7 @@ int main(int argc, char** argv) {
                 for (const RV& x : v) {
                     auto p = dynamic_cast<const RandomVariableHip*>(x.get());
                     if (!p || p->isDeterministic()) throw std::runtime_error("sharded expectation of a non-device value");
-                    h.push_back(p->deviceVector()->handle());
+                    h.push_back(p->deviceVector().handle());
                 }
                 void* dev = nullptr; check(fmhip_vec_device_ptr(sums, &dev));
                 check(fmhip_reduce_moments_batch_device(h.data(), (int)h.size(), nullptr, dev));

@@ -158,25 +158,32 @@ struct FmhipError : std::runtime_error {
 };
 inline void check(int status) { if (status != FMHIP_OK) throw FmhipError(status, fmhip_last_error()); }
 
+// Move-only owner of one handle, held BY VALUE inside a RandomVariableHip (no heap object of its own: a Monte-Carlo
+// driver creates tens of thousands of random variables per objective evaluation and is bound by host time).  Sharing a
+// vector between two random variables goes through the engine's own reference count (fmhip_vec_retain).
 class DeviceVector {
 public:
+    DeviceVector() = default;
     explicit DeviceVector(fmhip_vec h) : h_(h) {}
     ~DeviceVector() { if (h_) fmhip_vec_release(h_); }
+    DeviceVector(DeviceVector&& o) noexcept : h_(o.h_) { o.h_ = 0; }
+    DeviceVector& operator=(DeviceVector&& o) noexcept { if (this != &o) { if (h_) fmhip_vec_release(h_); h_ = o.h_; o.h_ = 0; } return *this; }
     DeviceVector(const DeviceVector&) = delete;
     DeviceVector& operator=(const DeviceVector&) = delete;
     fmhip_vec handle() const { return h_; }
-    using Ptr = std::shared_ptr<const DeviceVector>;
-    static Ptr fromHost(const std::vector<double>& v) { fmhip_vec h = 0; check(fmhip_vec_create_from_double(v.data(), (int64_t)v.size(), &h)); return std::make_shared<DeviceVector>(h); }
-    static Ptr filled(int64_t n, double value) { fmhip_vec h = 0; check(fmhip_vec_create_filled(n, value, &h)); return std::make_shared<DeviceVector>(h); }
-    // the five launch helpers of the reference (callFunctionv1s0 … v3s0, :483-537)
-    Ptr v1s0(int op) const { fmhip_vec o = 0; check(fmhip_call_v1s0(op, h_, &o)); return std::make_shared<DeviceVector>(o); }
-    Ptr v1s1(int op, double s) const { fmhip_vec o = 0; check(fmhip_call_v1s1(op, h_, s, &o)); return std::make_shared<DeviceVector>(o); }
-    Ptr v2s0(int op, const DeviceVector& b) const { fmhip_vec o = 0; check(fmhip_call_v2s0(op, h_, b.h_, &o)); return std::make_shared<DeviceVector>(o); }
-    Ptr v2s1(int op, const DeviceVector& b, double s) const { fmhip_vec o = 0; check(fmhip_call_v2s1(op, h_, b.h_, s, &o)); return std::make_shared<DeviceVector>(o); }
-    Ptr v3s0(int op, const DeviceVector& b, const DeviceVector& c) const { fmhip_vec o = 0; check(fmhip_call_v3s0(op, h_, b.h_, c.h_, &o)); return std::make_shared<DeviceVector>(o); }
+    bool valid() const { return h_ != 0; }
+    DeviceVector share() const { if (!h_) return DeviceVector(); check(fmhip_vec_retain(h_)); return DeviceVector(h_); }
+    static DeviceVector fromHost(const std::vector<double>& v) { fmhip_vec h = 0; check(fmhip_vec_create_from_double(v.data(), (int64_t)v.size(), &h)); return DeviceVector(h); }
+    static DeviceVector filled(int64_t n, double value) { fmhip_vec h = 0; check(fmhip_vec_create_filled(n, value, &h)); return DeviceVector(h); }
+    // the five launch helpers of the reference (callFunctionv1s0 … v3s0, :483-537), on raw handles
+    static DeviceVector v1s0(int op, fmhip_vec a) { fmhip_vec o = 0; check(fmhip_call_v1s0(op, a, &o)); return DeviceVector(o); }
+    static DeviceVector v1s1(int op, fmhip_vec a, double s) { fmhip_vec o = 0; check(fmhip_call_v1s1(op, a, s, &o)); return DeviceVector(o); }
+    static DeviceVector v2s0(int op, fmhip_vec a, fmhip_vec b) { fmhip_vec o = 0; check(fmhip_call_v2s0(op, a, b, &o)); return DeviceVector(o); }
+    static DeviceVector v2s1(int op, fmhip_vec a, fmhip_vec b, double s) { fmhip_vec o = 0; check(fmhip_call_v2s1(op, a, b, s, &o)); return DeviceVector(o); }
+    static DeviceVector v3s0(int op, fmhip_vec a, fmhip_vec b, fmhip_vec c) { fmhip_vec o = 0; check(fmhip_call_v3s0(op, a, b, c, &o)); return DeviceVector(o); }
     fmhip_moments moments(double shift = 0.0) const { fmhip_moments m; check(fmhip_reduce_moments(h_, shift, &m)); return m; }
 private:
-    fmhip_vec h_;
+    fmhip_vec h_ = 0;
 };
 
 // ------------------------------------------------------------------ RandomVariableHip
@@ -188,7 +195,7 @@ public:
     RandomVariableHip(double time, double value, int typePriority = typePriorityDefault)
         : time_(time), value_(value), n_(1), priority_(typePriority) {}
     // device vector (RandomVariableCuda.of, :618-646)
-    RandomVariableHip(double time, DeviceVector::Ptr realizations, int64_t n, int typePriority = typePriorityDefault)
+    RandomVariableHip(double time, DeviceVector&& realizations, int64_t n, int typePriority = typePriorityDefault)
         : time_(time), value_(std::numeric_limits<double>::quiet_NaN()), vec_(std::move(realizations)), n_(n), priority_(typePriority) {}
     // host values, narrowed to fp32 and uploaded (:696-723)
     RandomVariableHip(double time, const std::vector<double>& values)
@@ -198,13 +205,13 @@ public:
     static RV restamp(const RV& rv, double time) {                   // same value, another filtration time
         const auto* h = dynamic_cast<const RandomVariableHip*>(rv.get());
         if (!h || h->time_ == time) return rv;
-        return h->isDeterministic() ? of(time, h->value_) : of(time, h->vec_, h->n_);
+        return h->isDeterministic() ? of(time, h->value_) : of(time, h->vec_.share(), h->n_);
     }
-    static RV of(double time, DeviceVector::Ptr v, int64_t n) { return std::make_shared<RandomVariableHip>(time, std::move(v), n); }
+    static RV of(double time, DeviceVector&& v, int64_t n) { return std::make_shared<RandomVariableHip>(time, std::move(v), n); }
 
     double getFiltrationTime() const override { return time_; }
     int getTypePriority() const override { return priority_; }
-    bool isDeterministic() const override { return !vec_; }
+    bool isDeterministic() const override { return !vec_.valid(); }
     int64_t size() const override { return isDeterministic() ? 1 : n_; }
     double doubleValue() const override {
         if (isDeterministic()) return value_;
@@ -213,25 +220,25 @@ public:
     std::vector<double> getRealizations() const override {
         if (isDeterministic()) return { value_ };
         std::vector<double> out((size_t)n_);
-        check(fmhip_vec_read_double(vec_->handle(), out.data(), n_));
+        check(fmhip_vec_read_double(vec_.handle(), out.data(), n_));
         return out;
     }
-    const DeviceVector::Ptr& deviceVector() const { return vec_; }
+    const DeviceVector& deviceVector() const { return vec_; }
 
     // ---- reductions on the device (replaces :830-901)
     double getAverage() const override {
         if (isDeterministic()) return value_;
         if (n_ == 0) return std::nan("");
-        return vec_->moments().sum / (double)n_;
+        return vec_.moments().sum / (double)n_;
     }
     double getVariance() const override {                          // twin two-pass Σ(x-mean)²/n (twin:360-382)
         if (isDeterministic() || n_ == 1) return 0.0;
         if (n_ == 0) return std::nan("");
         const double mean = getAverage();
-        return vec_->moments(mean).sumsq / (double)n_;
+        return vec_.moments(mean).sumsq / (double)n_;
     }
-    double getMin() const override { return isDeterministic() ? value_ : vec_->moments().min; }
-    double getMax() const override { return isDeterministic() ? value_ : vec_->moments().max; }
+    double getMin() const override { return isDeterministic() ? value_ : vec_.moments().min; }
+    double getMax() const override { return isDeterministic() ? value_ : vec_.moments().max; }
 
     // ---- scalar operand / unary (:1172-1352)
     RV cap(double v) const override   { return scalar(FMHIP_OP_CAP_S, v, jmin(value_, v)); }
@@ -264,86 +271,86 @@ public:
         if (rv->getTypePriority() > priority_) return rv->add(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, value_ + rv->doubleValue());
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_ADD_S, value_), rv->size());
-        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_ADD_S, rv->doubleValue()), n_);
-        return of(t, vec_->v2s0(FMHIP_OP_ADD, *vecOf(rv)), n_);
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_ADD_S, vecOf(rv).h, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_ADD_S, vec_.handle(), rv->doubleValue()), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_ADD, vec_.handle(), vecOf(rv).h), n_);
     }
     RV sub(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->bus(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, value_ - rv->doubleValue());
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_BUS_S, value_), rv->size());
-        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_SUB_S, rv->doubleValue()), n_);
-        return of(t, vec_->v2s0(FMHIP_OP_SUB, *vecOf(rv)), n_);
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_BUS_S, vecOf(rv).h, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_SUB_S, vec_.handle(), rv->doubleValue()), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_SUB, vec_.handle(), vecOf(rv).h), n_);
     }
     RV bus(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->sub(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, -value_ + rv->doubleValue());
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_SUB_S, value_), rv->size());
-        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_BUS_S, rv->doubleValue()), n_);
-        return of(t, vecOf(rv)->v2s0(FMHIP_OP_SUB, *vec_), n_);                   // flipped arguments, :1458
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_SUB_S, vecOf(rv).h, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_BUS_S, vec_.handle(), rv->doubleValue()), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_SUB, vecOf(rv).h, vec_.handle()), n_);                   // flipped arguments, :1458
     }
     RV mult(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->mult(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, value_ * rv->doubleValue());
         if (rv->isDeterministic()) return mult(rv->doubleValue());
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_MULT_S, value_), rv->size());
-        return of(t, vec_->v2s0(FMHIP_OP_MULT, *vecOf(rv)), n_);
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_MULT_S, vecOf(rv).h, value_), rv->size());
+        return of(t, DeviceVector::v2s0(FMHIP_OP_MULT, vec_.handle(), vecOf(rv).h), n_);
     }
     RV div(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->vid(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, value_ / rv->doubleValue());
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_VID_S, value_), rv->size());
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_VID_S, vecOf(rv).h, value_), rv->size());
         if (rv->isDeterministic()) return div(rv->doubleValue());
-        return of(t, vec_->v2s0(FMHIP_OP_DIV, *vecOf(rv)), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_DIV, vec_.handle(), vecOf(rv).h), n_);
     }
     RV vid(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->div(self());             // twin:1116-1119
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, rv->doubleValue() / value_);
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_DIV_S, value_), rv->size());
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_DIV_S, vecOf(rv).h, value_), rv->size());
         if (rv->isDeterministic()) return restamp(vid(rv->doubleValue()), t);      // value as :1528, time as the twin (twin:1135-1140)
-        return of(t, vecOf(rv)->v2s0(FMHIP_OP_DIV, *vec_), n_);                   // flipped arguments, :1531
+        return of(t, DeviceVector::v2s0(FMHIP_OP_DIV, vecOf(rv).h, vec_.handle()), n_);                   // flipped arguments, :1531
     }
     RV cap(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->cap(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, jmin(value_, rv->doubleValue()));
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_CAP_S, value_), rv->size());
-        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_CAP_S, rv->doubleValue()), n_);
-        return of(t, vec_->v2s0(FMHIP_OP_CAP, *vecOf(rv)), n_);
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_CAP_S, vecOf(rv).h, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_CAP_S, vec_.handle(), rv->doubleValue()), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_CAP, vec_.handle(), vecOf(rv).h), n_);
     }
     RV floor(const RV& rv) const override {
         if (rv->getTypePriority() > priority_) return rv->floor(self());
         const double t = std::max(time_, rv->getFiltrationTime());
         if (isDeterministic() && rv->isDeterministic()) return of(t, jmax(value_, rv->doubleValue()));
-        if (isDeterministic()) return of(t, vecOf(rv)->v1s1(FMHIP_OP_FLOOR_S, value_), rv->size());
-        if (rv->isDeterministic()) return of(t, vec_->v1s1(FMHIP_OP_FLOOR_S, rv->doubleValue()), n_);
-        return of(t, vec_->v2s0(FMHIP_OP_FLOOR, *vecOf(rv)), n_);
+        if (isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_FLOOR_S, vecOf(rv).h, value_), rv->size());
+        if (rv->isDeterministic()) return of(t, DeviceVector::v1s1(FMHIP_OP_FLOOR_S, vec_.handle(), rv->doubleValue()), n_);
+        return of(t, DeviceVector::v2s0(FMHIP_OP_FLOOR, vec_.handle(), vecOf(rv).h), n_);
     }
     RV accrue(const RV& rate, double p) const override {                            // :1583-1601
         if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->mult(self());
         const double t = std::max(time_, rate->getFiltrationTime());
         if (rate->isDeterministic()) return mult(1.0 + rate->doubleValue() * p);
-        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->mult(value_); return of(t, vecOf(r), r->size()); }   // newTime kept (twin:1214-1219)
-        return of(t, vec_->v2s1(FMHIP_OP_ACCRUE, *vecOf(rate), p), n_);
+        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->mult(value_); return of(t, ownedVec(r), r->size()); }   // newTime kept (twin:1214-1219)
+        return of(t, DeviceVector::v2s1(FMHIP_OP_ACCRUE, vec_.handle(), vecOf(rate).h, p), n_);
     }
     RV discount(const RV& rate, double p) const override {                          // :1604-1624
         if (rate->getTypePriority() > priority_) return rate->mult(p)->add(1.0)->invert()->mult(self());
         const double t = std::max(time_, rate->getFiltrationTime());
         if (rate->isDeterministic()) return div(1.0 + rate->doubleValue() * p);
-        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->vid(value_); return of(t, vecOf(r), r->size()); }    // twin:1242-1247 (no zero short-cut)
-        return of(t, vec_->v2s1(FMHIP_OP_DISCOUNT, *vecOf(rate), p), n_);
+        if (isDeterministic()) { const RV r = rate->mult(p)->add(1.0)->vid(value_); return of(t, ownedVec(r), r->size()); }    // twin:1242-1247 (no zero short-cut)
+        return of(t, DeviceVector::v2s1(FMHIP_OP_DISCOUNT, vec_.handle(), vecOf(rate).h, p), n_);
     }
     RV choose(const RV& a, const RV& b) const override {                            // twin:1264-1285
         const double t = std::max(std::max(time_, a->getFiltrationTime()), b->getFiltrationTime());
         if (isDeterministic()) return value_ >= 0 ? a : b;
-        const DeviceVector::Ptr va = a->isDeterministic() ? DeviceVector::filled(n_, a->doubleValue()) : vecOf(a);
-        const DeviceVector::Ptr vb = b->isDeterministic() ? DeviceVector::filled(n_, b->doubleValue()) : vecOf(b);
-        return of(t, vec_->v3s0(FMHIP_OP_CHOOSE, *va, *vb), n_);
+        const DeviceVector va = a->isDeterministic() ? DeviceVector::filled(n_, a->doubleValue()) : ownedVec(a);
+        const DeviceVector vb = b->isDeterministic() ? DeviceVector::filled(n_, b->doubleValue()) : ownedVec(b);
+        return of(t, DeviceVector::v3s0(FMHIP_OP_CHOOSE, vec_.handle(), va.handle(), vb.handle()), n_);
     }
     // :1686-1695 compose add/sub(div); the filtration time is the maximum of all three, as in the twin (twin:1395-1438)
     RV addRatio(const RV& num, const RV& den) const override { return restamp(add(num->div(den)), std::max(std::max(time_, num->getFiltrationTime()), den->getFiltrationTime())); }
@@ -352,7 +359,7 @@ public:
         if (f1->getTypePriority() > priority_) return f1->mult(f2)->add(self());
         const double t = std::max(time_, f1->getFiltrationTime());
         if (f1->isDeterministic()) return add(f1->doubleValue() * f2);
-        if (!isDeterministic()) return of(t, vec_->v2s1(FMHIP_OP_ADDPRODUCT_VS, *vecOf(f1), f2), n_);
+        if (!isDeterministic()) return of(t, DeviceVector::v2s1(FMHIP_OP_ADDPRODUCT_VS, vec_.handle(), vecOf(f1).h, f2), n_);
         return add(f1->mult(f2));
     }
     RV addProduct(const RV& f1, const RV& f2) const override {                      // :1658-1683
@@ -362,27 +369,34 @@ public:
         if (f1->isDeterministic() && f2->isDeterministic()) return add(f1->doubleValue() * f2->doubleValue());
         if (f2->isDeterministic()) return addProduct(f1, f2->doubleValue());
         if (f1->isDeterministic()) return addProduct(f2, f1->doubleValue());
-        if (!isDeterministic()) return of(t, vec_->v3s0(FMHIP_OP_ADDPRODUCT, *vecOf(f1), *vecOf(f2)), n_);
+        if (!isDeterministic()) return of(t, DeviceVector::v3s0(FMHIP_OP_ADDPRODUCT, vec_.handle(), vecOf(f1).h, vecOf(f2).h), n_);
         return add(f1->mult(f2));
     }
 
 private:
     // getRandomVariableCuda(rv).realizations (:759-766): foreign types are uploaded through getRealizations()
-    static DeviceVector::Ptr vecOf(const RV& rv) {
-        if (auto h = dynamic_cast<const RandomVariableHip*>(rv.get())) return h->vec_;
+    static DeviceVector ownedVec(const RV& rv) {                 // an owning reference (shared through the engine's count) or an upload
+        if (auto h = dynamic_cast<const RandomVariableHip*>(rv.get())) return h->vec_.share();
         return DeviceVector::fromHost(rv->getRealizations());
+    }
+    struct VecRef { fmhip_vec h; DeviceVector uploaded; };       // a borrowed handle, or an upload that lives as long as the reference
+    static VecRef vecOf(const RV& rv) {
+        if (auto h = dynamic_cast<const RandomVariableHip*>(rv.get())) return { h->vec_.handle(), DeviceVector() };
+        DeviceVector up = DeviceVector::fromHost(rv->getRealizations());
+        const fmhip_vec handle = up.handle();
+        return { handle, std::move(up) };
     }
     RV scalar(int op, double s, double detResult) const {
         if (isDeterministic()) return of(time_, detResult);
-        return of(time_, vec_->v1s1(op, s), n_);
+        return of(time_, DeviceVector::v1s1(op, vec_.handle(), s), n_);
     }
     RV unary(int op, double detResult) const {
         if (isDeterministic()) return of(time_, detResult);
-        return of(time_, vec_->v1s0(op), n_);
+        return of(time_, DeviceVector::v1s0(op, vec_.handle()), n_);
     }
     double time_;
     double value_;
-    DeviceVector::Ptr vec_;
+    DeviceVector vec_;
     int64_t n_;
     int priority_;
 };
@@ -451,7 +465,7 @@ inline std::vector<double> getAverages(const std::vector<RV>& values) {
     int64_t n = -1; bool uniform = true;
     for (size_t k = 0; k < values.size(); ++k) {
         auto h = dynamic_cast<const RandomVariableHip*>(values[k].get());
-        if (h && !h->isDeterministic() && h->size() > 0) { if (n < 0) n = h->size(); uniform &= (h->size() == n); handles.push_back(h->deviceVector()->handle()); where.push_back(k); }
+        if (h && !h->isDeterministic() && h->size() > 0) { if (n < 0) n = h->size(); uniform &= (h->size() == n); handles.push_back(h->deviceVector().handle()); where.push_back(k); }
         else out[k] = values[k]->getAverage();
     }
     if (!handles.empty() && uniform) {
@@ -501,7 +515,7 @@ private:
         inc_.reserve(h.size());
         for (int i = 0; i < steps; ++i)
             for (int f = 0; f < factors_; ++f)
-                inc_.push_back(RandomVariableHip::of(td_.getTime(i + 1), std::make_shared<DeviceVector>(h[(size_t)i * factors_ + f]), paths_));
+                inc_.push_back(RandomVariableHip::of(td_.getTime(i + 1), DeviceVector(h[(size_t)i * factors_ + f]), paths_));
     }
     TimeDiscretization td_;
     int factors_;
