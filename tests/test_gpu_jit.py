@@ -225,3 +225,29 @@ def test_persistent_code_object_cache(tmp_path):
     assert runs[1]["stats"]["compiled"] == 1 and runs[1]["stats"]["disk_cache_hits"] == 1
     assert runs[0]["sum"] == runs[1]["sum"] and runs[0]["bits"] == runs[1]["bits"]
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".co")]) == 1
+
+
+def test_traffic_statistics_count_algorithmic_bytes(gpu, oracle):
+    """fmhip_traffic_stats: 4 B x N x (inputs + outputs) x rows per program launch, reductions add nothing."""
+    import ctypes as C
+    n = 12345
+    x, y, _ = inputs(oracle, n, seed=51)
+    def stats():
+        b, j = C.c_int64(0), C.c_int64(0)
+        gpu._native.check(gpu.lib().fmhip_traffic_stats(C.byref(b), C.byref(j)))
+        return b.value, j.value
+    prev = gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        p = gpu.Program(2)
+        w = p.op("ADDPRODUCT_VS", p.op("EXP", 0), 1, s=0.5)
+        p.output(w); p.reduce(w); p.compile()
+        rows = [[dv(gpu, x), dv(gpu, y)] for _ in range(3)]
+        b0, j0 = stats()
+        p.run(rows)
+        b1, j1 = stats()
+        assert b1 - b0 == 4 * n * (2 + 1) * 3 and j1 - j0 == 1
+        dv(gpu, x).moments()                        # stand-alone reduction: 4 B per element read, nothing written
+        b2, _ = stats()
+        assert b2 - b1 == 4 * n
+    finally:
+        gpu.set_jit(prev)
