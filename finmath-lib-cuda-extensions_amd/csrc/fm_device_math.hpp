@@ -85,11 +85,12 @@ __device__ __forceinline__ float exp_f(float a) {
 }
 
 // ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).
-// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) with an fp32 reciprocal seed and ONE Newton step (relative
-// error 2^-44: no fp64 division);  log m = 2s·(1 + z·g(z)), z = s² <= 0.0295, g of degree 5 (2^-50).
+// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) with an fp32 reciprocal seed, ONE Newton step (2^-44) and the
+// division residual folded back in (2^-88: no fp64 division);  log m = 2s·(1 + z·g(z)), z = s² <= 0.0295, g of degree 5 (2^-50).
 // Zero, negative, infinite and NaN arguments take the hardware v_log_f32 of the mantissa, which has exactly the IEEE
 // special values needed (-inf, NaN, +inf, NaN): one class test + one select instead of four compare/select pairs.
-// Verified over all 2^32 inputs: 3 results differ from `(float)log((double)x)` by one ulp (the 2^-44 of the reciprocal).
+// Verified over all 2^32 inputs: identical to `(float)log((double)x)` of the C library everywhere (without the division
+// residual below, 3 inputs were off by one ulp: the 2^-44 of the Newton reciprocal).
 __device__ __forceinline__ float log_f(float a) {
     // mantissa/exponent split and the centring on [sqrt(1/2), sqrt(2)) in fp32 (denormals are honoured by v_frexp_*_f32,
     // every step is exact), then everything else in fp64
@@ -104,7 +105,8 @@ __device__ __forceinline__ float log_f(float a) {
     const double d = m + 1.0;                                       // exact (m carries <= 24 significant bits)
     const double q0 = (double)__builtin_amdgcn_rcpf(m32 + 1.0f);    // ≈ 1/d, 2^-22 (a seed: the fp32 sum need not be exact)
     const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);   // Newton: 2^-44
-    const double s = f * q1;
+    const double s0 = f * q1;
+    const double s = __builtin_fma(__builtin_fma(-s0, d, f), q1, s0);         // + the division residual: s = f/d to ≈ 2^-88
     const double z = s * s;
     // log m = 2s·(1 + z·g(z)): g = near-minimax polynomial of degree 5 on [0, 0.02945] (tools/minimax_coefficients.py;
     // relative error of log m 2^-50.4, well under the 2^-44 of the Newton reciprocal) instead of 1/3 + z/5 + … + z^7/17
