@@ -5,34 +5,32 @@
 // (each elementary operation rounds to fp32 once: this file is compiled with -ffp-contract=off, the
 // counterpart of the reference's `nvcc -fmad false`, JCudaUtils.java:69-70), and exp/log/pow/sin/cos are
 // evaluated in fp64 and narrowed ONCE — the twin computes `(float)Math.exp(realizations[i])` (:905).  The fp64
-// intermediate is accurate to ≈2^-44…2^-47, so the narrowed result differs from the twin's only when the exact value
-// lies within that distance (relative) of an fp32 rounding boundary: ≈1e-6 of the elements, and then by one fp32 ulp.
+// intermediates of exp, log, sqrt, sin, cos are accurate enough that the narrowed result equals the twin's for every one
+// of the 2^32 fp32 arguments (benchmarks/exhaustive_unary.py, profiles/round01_exhaustive_parity.json); pow with a
+// generic exponent differs in a few dozen arguments per exponent, by one fp32 ulp.
 #pragma once
 #ifndef __HIPCC_RTC__           // the JIT tier compiles this header with hiprtc, which brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #endif
 #include "fm_program.h"
+#include "fm_log_table.hpp"
 
 namespace fm {
 
 // java.lang.Math.min/max(float,float): NaN-propagating, -0.0f < +0.0f (RandomVariableFromFloatArray.java:759,774).
 // The reference's CUDA kernels use `a < b ? a : b` (RandomVariableCudaKernel.cu:2-21), which differs from
 // its own CPU twin for NaN and signed zeros; the twin (and finmath-lib's double class) is followed here.
-// Built on the hardware v_min_f32 / v_max_f32, which order -0 < +0 exactly like Java and return the other operand
-// when one is NaN; the NaN propagation is added with one unordered compare + one select (the result is the canonical
-// quiet NaN: Java leaves the payload unspecified, parity treats NaN ≡ NaN).
-// (inline asm: the builtin min/max would first canonicalise both inputs with an extra v_max_f32 x,x each)
+// gfx950 has exactly this operation: v_minimum3_f32 / v_maximum3_f32 are the IEEE 754-2019 minimum / maximum (any NaN
+// operand gives NaN, -0 < +0) — ONE instruction.  (The older v_min_f32 / v_max_f32 return the other operand when one is
+// NaN; with them Java's semantics cost an unordered compare and a select on top.)  Java leaves the NaN payload
+// unspecified, parity treats NaN ≡ NaN.
+__device__ __forceinline__ float jmin(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__device__ __forceinline__ float jmax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+// minNum / maxNum flavour (returns the other operand when one is NaN) for the reduction accumulators, whose NaN is read
+// off Σx² (fm_kernel_parts.hpp).  (inline asm: the builtin would first canonicalise both inputs with a v_max_f32 x,x each)
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float jmin(float a, float b) {
-    const float r = hw_min(a, b);
-    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;       // one v_cmp_u_f32 covers "a or b is NaN"
-}
-__device__ __forceinline__ float jmax(float a, float b) {
-    const float r = hw_max(a, b);
-    return __builtin_isunordered(a, b) ? __builtin_nanf("") : r;
-}
 // java.lang.Math.pow special cases that differ from C99 pow (see oracle/rv_float.c jpow).
 __device__ __forceinline__ double jpow(double x, double y) {
     if (y == 0.0) return 1.0;
@@ -58,8 +56,10 @@ __device__ __forceinline__ double fma_c(double p, double r, double c) {
 }
 
 __device__ __forceinline__ float exp_f(float a) {
-    // clamp in fp32 (one v_med3_f32): ±inf and huge arguments give 0 / +inf anyway, and k stays a small integer
-    const double x = (double)__builtin_amdgcn_fmed3f(a, -110.0f, 90.0f);
+    // clamp in fp32: ±inf and huge arguments give 0 / +inf anyway, and k stays a small integer.  With the NaN-propagating
+    // minimum / maximum a NaN argument runs through the whole evaluation (two instructions; v_med3_f32 drops the NaN and
+    // needs a compare and a select afterwards).
+    const double x = (double)jmax(jmin(a, 90.0f), -110.0f);
     // k = round(x·log2 e) by the 1.5·2^52 trick: after the addition the integer sits in the low mantissa bits (two's
     // complement), so the int for ldexp is the low dword of t — no v_rndne_f64 / v_cvt_i32_f64.
     const double t = __builtin_fma(x, 1.4426950408889634, 6755399441055744.0);
@@ -80,50 +80,62 @@ __device__ __forceinline__ float exp_f(float a) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    const float res = (float)__builtin_ldexp(p, ki);
-    return (a != a) ? a : res;
+    return (float)__builtin_ldexp(p, ki);           // NaN: t, k, r, p are NaN, ldexp and the conversion keep it
 }
 
-// ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).
-// x = 2^e·m, m in [sqrt(1/2), sqrt(2));  s = (m-1)/(m+1) with an fp32 reciprocal seed, ONE Newton step (2^-44) and the
-// division residual folded back in (2^-88: no fp64 division);  log m = 2s·(1 + z·g(z)), z = s² <= 0.0295, g of degree 5 (2^-50).
+// ---- log: fp64 evaluation for an fp32 argument, narrowed once (twin :920).  Table-driven, no division:
+// x = 2^e·m, m in [1/2, 1) (v_frexp_*_f32: denormals honoured);  c = m rounded to 8 mantissa bits (a grid of 257 points,
+// c = 1 included);  r = (m - c)/c: the difference is exact in fp32, 1/c comes from the table, |r| <= 2^-9;
+// log x = (e·LN2_HI + log_hi(c)) + (e·LN2_LO + log_lo(c) + log1p(r)),  log1p(r) = r + r²·Q(r), Q of degree 3.
+// The first bracket is exact (log_hi is a multiple of 2^-40), so the result carries ONE rounding at its own magnitude.
+// The centring of the argument on 1 is folded into the table (entries below sqrt(1/2) hold log(2c) - ln2, fm_log_table.hpp):
+// x just above 1 (m just above 1/2, e = 1) cancels exactly, x just below 1 has c = 1, log_hi = log_lo = 0, r exact.
+// 25 instruction slots (the division-based form this replaces: 38 — frexp, centring, reciprocal seed, Newton step,
+// division residual, degree-5 atanh series).  The table sits in LDS (8 KB, log_table_init() at kernel start): one
+// ds_read_b128 + one ds_read_b64 per element.
 // Zero, negative, infinite and NaN arguments take the hardware v_log_f32 of the mantissa, which has exactly the IEEE
 // special values needed (-inf, NaN, +inf, NaN): one class test + one select instead of four compare/select pairs.
-// Verified over all 2^32 inputs: identical to `(float)log((double)x)` of the C library everywhere (without the division
-// residual below, 3 inputs were off by one ulp: the 2^-44 of the Newton reciprocal).
+// Verified over all 2^32 inputs: identical to `(float)log((double)x)` of the C library everywhere (on the device:
+// benchmarks/exhaustive_unary.py; the same operation sequence on the CPU: tools/check_log_table.cpp).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+__shared__ double fm_log_lds[FM_LOG_TABLE_ENTRIES * 4];
+
+// Workgroup-wide copy of the table into LDS; every kernel that may evaluate log_f calls it once before its first pass.
+__device__ __forceinline__ void log_table_init() {
+    const f64x2* __restrict__ src = reinterpret_cast<const f64x2*>(FM_LOG_TABLE);
+    f64x2* dst = reinterpret_cast<f64x2*>(fm_log_lds);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)FM_LOG_TABLE_ENTRIES * 2u; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
 __device__ __forceinline__ float log_f(float a) {
-    // mantissa/exponent split and the centring on [sqrt(1/2), sqrt(2)) in fp32 (denormals are honoured by v_frexp_*_f32,
-    // every step is exact), then everything else in fp64
-    float m32 = __builtin_amdgcn_frexp_mantf(a);                    // [0.5, 1), sign of a; ±0, ±inf, NaN pass through
-    int e = __builtin_amdgcn_frexp_expf(a);
+    const float m32 = __builtin_amdgcn_frexp_mantf(a);             // [0.5, 1), sign of a; ±0, ±inf, NaN pass through
+    const int e = __builtin_amdgcn_frexp_expf(a);
     const float lg = __builtin_amdgcn_logf(m32);                    // used only for the special cases below
-    const bool lo = m32 < 0.70710678f;
-    m32 = lo ? m32 + m32 : m32;
-    e = lo ? e - 1 : e;
-    const double m = (double)m32;
-    const double f = m - 1.0;                                       // exact
-    const double d = m + 1.0;                                       // exact (m carries <= 24 significant bits)
-    const double q0 = (double)__builtin_amdgcn_rcpf(m32 + 1.0f);    // ≈ 1/d, 2^-22 (a seed: the fp32 sum need not be exact)
-    const double q1 = __builtin_fma(__builtin_fma(-d, q0, 1.0), q0, q0);   // Newton: 2^-44
-    const double s0 = f * q1;
-    const double s = __builtin_fma(__builtin_fma(-s0, d, f), q1, s0);         // + the division residual: s = f/d to ≈ 2^-88
-    const double z = s * s;
-    // log m = 2s·(1 + z·g(z)): g = near-minimax polynomial of degree 5 on [0, 0.02945] (tools/minimax_coefficients.py;
-    // relative error of log m 2^-50.4, well under the 2^-44 of the Newton reciprocal) instead of 1/3 + z/5 + … + z^7/17
-    double p = 0x1.546d249f36cb2p-4;
-    p = fma_c(p, z, 0x1.7382a9fa2e7aep-4);
-    p = fma_c(p, z, 0x1.c71fcdfe2f300p-4);
-    p = fma_c(p, z, 0x1.249246299fc8ep-3);
-    p = fma_c(p, z, 0x1.9999999b878d7p-3);
-    p = fma_c(p, z, 0x1.55555555553b7p-2);
-    const double s2 = s + s;
-    const double lm = __builtin_fma(s2, p * z, s2);
+    const uint32_t cb = (__float_as_uint(m32) + 0x4000u) & 0xffff8000u;     // nearest grid point: 8 mantissa bits, may be 1.0
+    // byte offset of the 32-byte entry = index·32, index = bits 15…23 of cb (0 … 255: exponent of [0.5,1); 256: c = 1.0).
+    // Special arguments (discarded below) may index past the table: LDS reads have no side effects.
+    // (inline asm: the compiler expands the bit-field extract of a constant field into a shift and a mask)
+    uint32_t offset;
+    asm("v_bfe_u32 %0, %1, 10, 14" : "=v"(offset) : "v"(cb));     // bits 10…14 of cb are zero
+    const char* entry = reinterpret_cast<const char*>(fm_log_lds) + offset;
+    const f64x2 t = *reinterpret_cast<const f64x2*>(entry);         // { 1/c, log_hi }
+    const double log_lo = *reinterpret_cast<const double*>(entry + 16);
+    const double r = (double)(m32 - __uint_as_float(cb)) * t.x;     // fp32 difference exact (both multiples of 2^-24, |·| <= 2^-10)
+    const double r2 = r * r;
+    double q = FM_LOG1P_Q3;
+    q = fma_c(q, r, FM_LOG1P_Q2);
+    q = fma_c(q, r, FM_LOG1P_Q1);
+    q = fma_c(q, r, FM_LOG1P_Q0);
+    const double lp = __builtin_fma(r2, q, r);                      // log1p(r)
     const double ed = (double)e;
-    const double r = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+    const double hi = __builtin_fma(ed, 6.93147180369123816490e-01, t.y);   // exact
+    const double lo = __builtin_fma(ed, 1.90821492927058770002e-10, log_lo);
+    const double res = hi + (lo + lp);
     // class mask: sNaN|qNaN|-inf|-normal|-denormal|-0|+0|+inf = everything except +denormal (0x080) and +normal (0x100).
     // For those arguments log2 of the MANTISSA (negative → NaN, ±0 → -inf, +inf → +inf, NaN → NaN) is exactly the IEEE result.
     const bool special = __builtin_amdgcn_classf(a, 0x27f);
-    return special ? lg : (float)r;
+    return special ? lg : (float)res;
 }
 
 // ---- FAST math mode (fmhip_set_math_mode(FMHIP_MATH_FAST)): exp and log on the hardware transcendental unit
@@ -151,8 +163,9 @@ __device__ __forceinline__ float log_fast(float a) {
 __device__ __noinline__ float sin_f(float a) { return (float)sin((double)a); }
 __device__ __noinline__ float cos_f(float a) { return (float)cos((double)a); }
 // ---- pow: `(float)Math.pow((double)x, (double)(float)exponent)` (twin :849).
-// Fast path for x > 0 finite and a finite exponent: 2^(y·log2 x) with log2 x carried as a double-double — the same mantissa
-// split, Newton reciprocal and atanh series as log_f, plus the division residual (s = s_hi + s_lo), a degree-6 minimax tail
+// Fast path for x > 0 finite and a finite exponent: 2^(y·log2 x) with log2 x carried as a double-double — mantissa centred on
+// [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1) from an fp32 reciprocal seed, one Newton step and the division residual
+// (s = s_hi + s_lo to 2^-88), log m = 2·atanh(s) with a degree-6 minimax tail
 // (2^-57.6) and 2/ln2 as a double-double, so that y·log2 x is good to ≈ 2^-54 relative even at |y·log2 x| ≈ 150; then the
 // exp polynomial on the fraction.  ≈ 70 instructions instead of the ≈ 300 of the generic library pow; every other
 // argument class (x <= 0, ±inf, NaN, exponent ±inf / NaN) takes the library path with Java's special cases (jpow).

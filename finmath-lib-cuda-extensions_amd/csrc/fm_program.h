@@ -76,11 +76,13 @@ static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsig
 //   then n_scal floats (padded to a multiple of 2)
 constexpr int FM_ROW_WORDS_MAX = FM_MAX_IN + FM_MAX_OUT + FM_MAX_RED + FM_MAX_SCAL / 2;   // 54 x 8 B
 
+constexpr uint32_t FM_ARGS_LOG_TABLE = 1u;      // the program evaluates log_f: the kernel copies the log table into LDS first
+
 struct DevProgramArgs {
     uint32_t n_ops, n_in, n_out, n_red;
     uint32_t n_scal, row_words;          // row stride in 8-byte words
     uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; batch==1 → row block inline
-    uint32_t variant, pad0_;             // kernel variant (FM_VARIANT_*)
+    uint32_t variant, flags;             // kernel variant (FM_VARIANT_*); FM_ARGS_* bits
     int64_t  n;                          // elements per vector
     double*   results;                   // [batch][n_red][4] final {Σ, Σ², min, max} (written by the last workgroup of a row)
     uint32_t* counters;                  // [batch] arrival counters of the fused final combine, zero between launches

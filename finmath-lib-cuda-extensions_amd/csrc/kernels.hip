@@ -73,6 +73,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     const uint32_t n_in = A.n_in, n_out = A.n_out, n_ops = A.n_ops;
     const int64_t n = A.n;
     const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + n_in + n_out + A.n_red);
+    if (A.flags & FM_ARGS_LOG_TABLE) log_table_init();          // wave- and workgroup-uniform
 
     double acc_sum[NRED > 0 ? NRED : 1], acc_sq[NRED > 0 ? NRED : 1];
     float  acc_min[NRED > 0 ? NRED : 1], acc_max[NRED > 0 ? NRED : 1];

@@ -523,6 +523,7 @@ Program* Engine::compile_variant(const std::vector<SsaOp>& ops, int n_in, const 
         unsigned slot = 0;
         uint32_t uop = uv.uop;
         if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
+        if (uop == U_LOG) p->proto.flags |= FM_ARGS_LOG_TABLE;
         if (op_info(ops[i].opcode).scalar) {
             if ((int)scal.size() >= FM_MAX_SCAL) { delete p; throw Error(FMHIP_ERR_PROGRAM_LIMIT, "too many scalar operands for one launch"); }
             slot = (unsigned)scal.size();
