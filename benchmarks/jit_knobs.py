@@ -1,0 +1,81 @@
+"""Shape of the specialised kernel (csrc/jit.cpp: jit_shape) measured on the bench program, stream S over 64 x 1M paths:
+elements per lane and pass (FMHIP_JIT_ELEMS), interleaved elements of an exp / log body (FMHIP_JIT_GROUP), occupancy
+hint for the register allocator (FMHIP_JIT_WAVES), software prefetch of the next pass (FMHIP_JIT_PREFETCH).
+One fresh process per configuration (the knobs are read when the kernel source is generated); all on one box, in sequence.
+
+    python benchmarks/jit_knobs.py [--json out.json] [--configs "8,4,0,0;4,4,0,0;..."]        (elems,group,waves,prefetch[,elements per workgroup])
+"""
+import importlib, json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+DEFAULT = "8,4,0,0;8,4,5,0;8,1,0,0;4,4,0,0;4,2,0,0;8,4,0,1;4,4,0,1;8,4,5,1;8,4,0,0"
+
+
+def child():
+    import torch
+    fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+    fm.init(0)
+    fm.set_jit(fm.JIT_SYNC)
+    n, B = 1_000_000, 64
+    bm = fm.BrownianMotionHip(fm.TimeDiscretization(0.0, B, 1.0), 3, n, 31415)
+    rows = []
+    for b in range(B):
+        g = [bm.getBrownianIncrement(b, f) for f in range(3)]
+        rows.append([g[0].mult(0.25).add(0.5).cap(1.0).floor(0.0).realizations, g[1].mult(0.25).add(1.0).cap(1.5).floor(0.5).realizations,
+                     g[2].mult(0.25).add(1.0).cap(1.5).floor(0.5).realizations])
+    del bm
+    outs = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
+    sys.path.insert(0, ROOT)
+    import bench
+    if os.environ.get("KNOB_NO_REDUCE"):            # the same stream without the fused reductions (output vector only)
+        p = fm.Program(3)
+        x, y, z = 0, 1, 2
+        t = p.op("SUB", p.op("MULT", p.op("DIV_S", p.op("ADD_S", x, s=4.0), s=2.0), y), z)
+        u = p.op("SQRT", p.op("ABS", p.op("LOG", p.op("EXP", t))))
+        v = p.op("ADDPRODUCT", p.op("FLOOR_S", p.op("CAP_S", u, s=1.5), s=0.25), y, z)
+        p.output(p.op("CHOOSE", t, v, x))
+        p.compile()
+    else:
+        p = bench.build_stream_s(fm)
+    partial = torch.zeros(B * 4, dtype=torch.float64, device="cuda:0")
+
+    def run(k):
+        for _ in range(k):
+            p.run_into(rows, outs, want_moments=False, device_moments=partial.data_ptr())
+
+    run(30); fm.synchronize()
+    best, vals = 1e9, []
+    for _ in range(4):
+        fm.profile_enable(True); run(100); ms, k = fm.profile_read(); fm.profile_enable(False)
+        vals.append(ms / k * 1e3)
+    print(json.dumps({"tier": p.tier(), "us": [round(v, 1) for v in vals], "moments": partial[:4].tolist()}), flush=True)
+
+
+def main():
+    if "--child" in sys.argv:
+        return child()
+    configs = DEFAULT
+    if "--configs" in sys.argv:
+        configs = sys.argv[sys.argv.index("--configs") + 1]
+    out = []
+    for c in configs.split(";"):
+        e, g, w, pf, *rest = c.split(",")
+        env = dict(os.environ, FMHIP_JIT_ELEMS=e, FMHIP_JIT_GROUP=g, FMHIP_JIT_WAVES=w, FMHIP_JIT_PREFETCH=pf)
+        if rest: env["FMHIP_ELEMS_PER_BLOCK"] = rest[0]
+        if len(rest) > 1 and rest[1] == "noreduce": env["KNOB_NO_REDUCE"] = "1"
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        rec = {"elems": int(e), "group": int(g), "waves": int(w), "prefetch": int(pf), "elems_per_block": int(rest[0]) if rest else 8192, "reduce": not (len(rest) > 1 and rest[1] == "noreduce")}
+        if line: rec.update(json.loads(line[-1]))
+        else: rec["error"] = (r.stderr or r.stdout)[-400:]
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

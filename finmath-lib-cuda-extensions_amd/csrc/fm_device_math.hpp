@@ -100,12 +100,30 @@ __device__ __forceinline__ float exp_f(float a) {
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 __shared__ double fm_log_lds[FM_LOG_TABLE_ENTRIES * 4];
 
-// Workgroup-wide copy of the table into LDS; every kernel that may evaluate log_f calls it once before its first pass.
-__device__ __forceinline__ void log_table_init() {
+// Workgroup-wide copy of the table into LDS; every kernel that may evaluate log_f does it once before its first pass.
+// In two halves, so that a kernel can put the loads of its first pass between them (one memory round trip instead of two).
+constexpr int FM_LOG_TABLE_CHUNKS = (FM_LOG_TABLE_ENTRIES * 2 + FM_BLOCK - 1) / FM_BLOCK;      // 16-byte pieces per thread
+__device__ __forceinline__ void log_table_issue(f64x2 (&v)[FM_LOG_TABLE_CHUNKS]) {
     const f64x2* __restrict__ src = reinterpret_cast<const f64x2*>(FM_LOG_TABLE);
+#pragma unroll
+    for (int k = 0; k < FM_LOG_TABLE_CHUNKS; ++k) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * FM_BLOCK;
+        v[k] = src[i < (uint32_t)FM_LOG_TABLE_ENTRIES * 2u ? i : 0u];
+    }
+}
+__device__ __forceinline__ void log_table_commit(const f64x2 (&v)[FM_LOG_TABLE_CHUNKS]) {
     f64x2* dst = reinterpret_cast<f64x2*>(fm_log_lds);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)FM_LOG_TABLE_ENTRIES * 2u; i += blockDim.x) dst[i] = src[i];
+#pragma unroll
+    for (int k = 0; k < FM_LOG_TABLE_CHUNKS; ++k) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * FM_BLOCK;
+        if (i < (uint32_t)FM_LOG_TABLE_ENTRIES * 2u) dst[i] = v[k];
+    }
     __syncthreads();
+}
+__device__ __forceinline__ void log_table_init() {
+    f64x2 v[FM_LOG_TABLE_CHUNKS];
+    log_table_issue(v);
+    log_table_commit(v);
 }
 
 __device__ __forceinline__ float log_f(float a) {

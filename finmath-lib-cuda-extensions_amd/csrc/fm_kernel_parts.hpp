@@ -165,7 +165,7 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
         }
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = __hip_atomic_fetch_add(counters + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(counters + (size_t)row * FM_COUNTER_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_flag = (arrived == gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
@@ -198,7 +198,7 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) __hip_atomic_store(counters + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (threadIdx.x == 0) __hip_atomic_store(counters + (size_t)row * FM_COUNTER_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 } // namespace fm

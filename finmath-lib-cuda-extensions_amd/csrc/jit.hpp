@@ -31,11 +31,17 @@ struct JitSlot {
     hipModule_t module = nullptr;
     hipFunction_t fn_inline = nullptr, fn_table = nullptr;      // row block in the kernarg segment / in the row table
     int vgprs = 0;
+    int elems = 0;                                              // elements per lane and pass of this kernel (the host tiles the launch with it)
     bool from_disk = false;                                     // code object came from the persistent cache
     double compile_seconds = 0.0;
 };
 
 struct JitStats { int64_t compiled = 0, failed = 0, pending = 0, disk_hits = 0; double seconds = 0.0; };
+
+// Shape of a specialised kernel: elements per lane and pass, how many elements of an exp / log body are interleaved,
+// an occupancy hint for the register allocator, software prefetch of the next pass.
+struct JitShape { int elems = 8, group = 4, waves = 0; bool prefetch = true; };
+JitShape jit_shape(const DevProgramArgs& proto);
 
 // Source text of the specialised kernel pair of a program (deterministic: it doubles as the cache key).
 std::string jit_generate_source(const DevProgramArgs& proto);

@@ -143,8 +143,8 @@ void Engine::init(int device_index) {
     ring_cap_ = size_t(4) << 20;
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
-    hip_check(hipMalloc((void**)&counters_dev_, 65536 * sizeof(uint32_t)), "hipMalloc(counters)");
-    hip_check(hipMemsetAsync(counters_dev_, 0, 65536 * sizeof(uint32_t), stream_), "hipMemset(counters)");
+    hip_check(hipMalloc((void**)&counters_dev_, (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE * sizeof(uint32_t)), "hipMalloc(counters)");
+    hip_check(hipMemsetAsync(counters_dev_, 0, (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
     ring_off_ = 0;
     device_ = device_index;
@@ -577,13 +577,28 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         return;
     }
     DevProgramArgs args = p->proto;
-    const int64_t elems_per_pass = (int64_t)FM_BLOCK * FM_VARIANT_ELEMS[args.variant];
+    // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
+    // (≈10 ms of device time: a compilation costs ≈0.2 s of one background host core); explicit programs at creation.
+    if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
+        p->interpreted_work += (double)n * batch * p->n_ops;
+        if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
+    } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
+        p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
+    const bool use_jit = jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY;
+    // the specialised kernel may process a different number of elements per lane and pass than the interpreter variant
+    const int64_t elems_per_pass = (int64_t)FM_BLOCK * (use_jit ? p->jit->elems : FM_VARIANT_ELEMS[args.variant]);
     const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
     if (tiles > int64_t(0x7fffffff)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "vector too long");
-    // One pass per workgroup: measured fastest for pure streaming on MI355X (5.8 TB/s vs 5.0 TB/s with a 2048-workgroup
-    // grid-stride loop).  With fused reductions a workgroup covers several passes so that the wave/LDS combine and
-    // the partial write are amortised (≈8192 elements per workgroup).
-    int64_t passes_per_block = (n_red > 0) ? std::max<int64_t>(1, 8192 / elems_per_pass) : 1;
+    // Passes per workgroup.  A workgroup has a fixed cost (launch, log-table copy, for reductions the wave/LDS combine, the
+    // partial write and the arrival counter) and, run back to back, kernels pay one workgroup lifetime of ramp-up and
+    // tail: measured on the bench program (64 rows x 1M paths, benchmarks/jit_knobs.py) 2048 / 4096 / 8192 / 16384
+    // elements per workgroup = 223 / 199 / 193 / 199 µs with fused reductions (181 / 179 / 177 / 186 µs without; there one
+    // pass per workgroup is kept: on the LMM op stream, whose launches have 8 rows, 8192 gained 2 % and lost it again
+    // together with the prefetch below).  With reductions the span must not depend on the batch: it fixes the order in
+    // which a row's partial sums are added, and a value must not depend on how many other rows shared its launch.
+    static const int64_t ELEMS_PER_BLOCK_ENV = [] { const char* e = std::getenv("FMHIP_ELEMS_PER_BLOCK"); const long long v = e ? std::atoll(e) : 0; return v >= 1024 ? (int64_t)v : (int64_t)0; }();
+    const int64_t elems_per_block = ELEMS_PER_BLOCK_ENV ? ELEMS_PER_BLOCK_ENV : (n_red > 0 ? 8192 : 0);      // the variable: for benchmarks/jit_knobs.py
+    const int64_t passes_per_block = std::max<int64_t>(1, elems_per_block / elems_per_pass);
     int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
     bpr = std::min<int64_t>(std::max<int64_t>(bpr, 1), 65536);
     args.n = n;
@@ -640,17 +655,9 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
             hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate");
             hip_check(hipEventRecord(ev0, stream_), "hipEventRecord");
         }
-        // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
-        // (≈10 ms of device time: a compilation costs ≈0.2 s of one background host core); explicit programs at creation.
-        if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
-            p->interpreted_work += (double)n * batch * p->n_ops;
-            if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
-        } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
-            p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
         HostTimer t3(HostProfile::LAUNCH_API);
-        bool used_jit = false;
-        if (jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY) {
-            used_jit = true;
+        const bool used_jit = use_jit;
+        if (use_jit) {
             const uint64_t* rows_arg = dev_rows; double* partials_arg = (double*)partials;
             void* params[] = { &args, &rows_arg, &partials_arg };
             hip_check(hipModuleLaunchKernel(batch == 1 ? p->jit->fn_inline : p->jit->fn_table, (unsigned)bpr, (unsigned)batch, 1, FM_BLOCK, 1, 1,
