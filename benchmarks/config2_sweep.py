@@ -1,7 +1,7 @@
 """BASELINE.json configs[1] / SURVEY.md §8(d) config 2, parts (A) and (C): every opcode ALONE and the reductions alone, on
 both execution tiers, as device time and algorithmic GB/s (4 B x N x (inputs + outputs); a stand-alone reduction 4 B/path).
 
-    python benchmarks/config2_sweep.py [--json out.json]
+    python benchmarks/config2_sweep.py [--json out.json] [--ops LOG,CAP_S,moments]
 
 Two shapes: 64 independent tuples of N = 1 000 000 per launch (working set 0.5-1 GB >> the 256 MB Infinity Cache, i.e. the
 HBM-labelled figure) and one tuple of N = 2^26."""
@@ -41,12 +41,14 @@ def timed(p, rows, outs, reps):
 
 def main():
     results = []
+    only = set(sys.argv[sys.argv.index("--ops") + 1].split(",")) if "--ops" in sys.argv else None
     for n, B, reps in ((1_000_000, 64, 6), (1 << 26, 1, 6)):
         rows = inputs(n, B)
         outs = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
         for tname, tier in (("interpreter", fm.JIT_OFF), ("specialised", fm.JIT_SYNC)):
             fm.set_jit(tier)
             for name, nvec, has_s in OPS:
+                if only is not None and name not in only: continue
                 p = fm.Program(nvec)
                 w = p.op(name, *range(nvec), s=1.25) if has_s else p.op(name, *range(nvec))
                 p.output(w); p.compile()
@@ -54,6 +56,7 @@ def main():
                 gb = 4.0 * (nvec + 1) * n * B / us / 1e3
                 results.append({"part": "A", "op": name, "n": n, "batch": B, "tier": tname, "us": us, "GBps": gb})
                 print(f"A  {name:14s} N={n:9d} x{B:3d} {tname:12s} {us:9.1f} us {gb:8.0f} GB/s", flush=True)
+            if only is not None and "moments" not in only: continue
             p = fm.Program(1); p.reduce(0); p.compile()
             us = timed(p, [r[:1] for r in rows], [[] for _ in range(B)], reps)
             gb = 4.0 * n * B / us / 1e3

@@ -134,7 +134,7 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
                                               const float (&acc_min)[NRED], const float (&acc_max)[NRED],
                                               const unsigned long long (&nan_mask)[NRED],
                                               double* __restrict__ partials, const uint32_t row,
-                                              double* __restrict__ results, uint32_t* __restrict__ counters)
+                                              double* __restrict__ results, uint32_t* __restrict__ counter)      // counter: this row's arrival counter
 {
     __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
     __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
@@ -165,8 +165,26 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
         }
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = __hip_atomic_fetch_add(counters + (size_t)row * FM_COUNTER_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (arrived == gridDim.x - 1) ? 1u : 0u;
+        // Arrival counting.  Device-scope atomics execute at the memory side, ≈ 11-13 ns apiece on one address: a row of
+        // thousands of workgroups (one vector of 2^26 paths: 8192) would queue there for longer than the kernel runs
+        // (measured: 128 µs instead of 45).  Rows with many workgroups therefore count in up to 7 groups (workgroup b
+        // belongs to group b mod G), the last arrival of each group moves a second-level counter, and the last of those
+        // is the last workgroup of the row.  The queue is per cache line, not per address (7 group counters 32 B apart:
+        // still 72 µs), so every group counter lives in a plane of its own: counter + plane·FM_COUNTER_PLANE.
+        const uint32_t G = gridDim.x >= 512u ? (gridDim.x >= 1792u ? 7u : gridDim.x >> 8) : 1u;
+        const uint32_t g = blockIdx.x % G;
+        const uint32_t members = (gridDim.x - g + G - 1u) / G;
+        uint32_t last = 0u;
+        const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == members - 1u) {
+            __hip_atomic_store(counter + (size_t)g * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            if (G == 1u) last = 1u;
+            else {
+                const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (groups_done == G - 1u) { __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1u; }
+            }
+        }
+        last_flag = last;
     }
     __syncthreads();
     if (last_flag == 0u) return;                                             // workgroup-uniform
@@ -174,9 +192,21 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
     for (int r = 0; r < NRED; ++r) {
         const double* p = partials + ((size_t)row * NRED + r) * gridDim.x * 4;
         double s1 = 0.0, s2 = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
-        for (uint32_t b = threadIdx.x; b < gridDim.x; b += FM_BLOCK) {
-            s1 += load_coherent(p + b * 4 + 0); s2 += load_coherent(p + b * 4 + 1);
-            mn = jmin_d(mn, load_coherent(p + b * 4 + 2)); mx = jmax_d(mx, load_coherent(p + b * 4 + 3));
+        // Thread t adds the partials of workgroups t, t+256, … in that order.  The loads of 8 of them are issued before
+        // the first is used: left one at a time (the compiler keeps coherent loads in program order and waits for each
+        // before the dependent add), a row of 8192 workgroups cost 32 memory round trips here — ≈ 40 µs of a 45 µs kernel.
+        for (uint32_t b0 = threadIdx.x; b0 < gridDim.x; b0 += FM_BLOCK * 8u) {
+            double v[8][4];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t b = b0 + u * FM_BLOCK;
+                const double* q = p + (size_t)(b < gridDim.x ? b : b0) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = load_coherent(q + k);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; ++u)
+                if (b0 + u * FM_BLOCK < gridDim.x) { s1 += v[u][0]; s2 += v[u][1]; mn = jmin_d(mn, v[u][2]); mx = jmax_d(mx, v[u][3]); }
         }
         sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = mn; sh[3][threadIdx.x] = mx;
         __syncthreads();
@@ -198,7 +228,6 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) __hip_atomic_store(counters + (size_t)row * FM_COUNTER_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 } // namespace fm

@@ -76,11 +76,14 @@ static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsig
 //   then n_scal floats (padded to a multiple of 2)
 constexpr int FM_ROW_WORDS_MAX = FM_MAX_IN + FM_MAX_OUT + FM_MAX_RED + FM_MAX_SCAL / 2;   // 54 x 8 B
 
-// Arrival counters of the fused final combine: one per row, 256 bytes apart.  Device-scope atomics are executed at the memory
-// side; packed into one or two cache lines the counters of all rows of a launch serialise there (measured: ≈ 5 ns per
-// workgroup of the whole grid, +9 µs on the 190 µs bench launch and +180 µs with 4x as many workgroups).
+// Arrival counters of the fused final combine: 8 planes (up to 7 group counters + one second-level counter per row:
+// fm_kernel_parts.hpp block_combine) of one 256-byte block per row — 128 MB of the 288 GB.  Device-scope atomics are executed at the memory side, ≈ 11-13 ns apiece
+// on one address; packed into one or two cache lines the counters of all rows of a launch serialise there (measured on 64
+// rows x 123 workgroups: stand-alone reduction 95 µs packed, 44 µs apart; the bench launch with 4x the workgroups 363 → 223 µs).
 constexpr uint32_t FM_COUNTER_STRIDE = 64;      // in uint32_t
 constexpr uint32_t FM_MAX_ROWS = 65536;
+constexpr uint32_t FM_COUNTER_PLANES = 8;
+constexpr size_t   FM_COUNTER_PLANE = (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE;      // in uint32_t
 
 constexpr uint32_t FM_ARGS_LOG_TABLE = 1u;      // the program evaluates log_f: the kernel copies the log table into LDS first
 

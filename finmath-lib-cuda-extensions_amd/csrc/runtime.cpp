@@ -143,8 +143,8 @@ void Engine::init(int device_index) {
     ring_cap_ = size_t(4) << 20;
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
-    hip_check(hipMalloc((void**)&counters_dev_, (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE * sizeof(uint32_t)), "hipMalloc(counters)");
-    hip_check(hipMemsetAsync(counters_dev_, 0, (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE * sizeof(uint32_t), stream_), "hipMemset(counters)");
+    hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
+    hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
     ring_off_ = 0;
     device_ = device_index;
@@ -597,8 +597,13 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     // together with the prefetch below).  With reductions the span must not depend on the batch: it fixes the order in
     // which a row's partial sums are added, and a value must not depend on how many other rows shared its launch.
     static const int64_t ELEMS_PER_BLOCK_ENV = [] { const char* e = std::getenv("FMHIP_ELEMS_PER_BLOCK"); const long long v = e ? std::atoll(e) : 0; return v >= 1024 ? (int64_t)v : (int64_t)0; }();
-    const int64_t elems_per_block = ELEMS_PER_BLOCK_ENV ? ELEMS_PER_BLOCK_ENV : (n_red > 0 ? 8192 : 0);      // the variable: for benchmarks/jit_knobs.py
-    const int64_t passes_per_block = std::max<int64_t>(1, elems_per_block / elems_per_pass);
+    // A program that evaluates log copies the 8 KB log table into LDS once per workgroup: one pass (2048 elements, 8 KB per
+    // vector) per workgroup would double its L2 traffic (`log` alone: 88 → 95 µs), so it also gets ≈ 8192 elements per
+    // workgroup — unless the launch is too small to fill the chip that way.
+    const bool log_table = (args.flags & FM_ARGS_LOG_TABLE) != 0;
+    const int64_t elems_per_block = ELEMS_PER_BLOCK_ENV ? ELEMS_PER_BLOCK_ENV : ((n_red > 0 || log_table) ? 8192 : 0);      // the variable: for benchmarks/jit_knobs.py
+    int64_t passes_per_block = std::max<int64_t>(1, elems_per_block / elems_per_pass);
+    if (n_red == 0) while (passes_per_block > 1 && ((tiles + passes_per_block - 1) / passes_per_block) * batch < 4096) passes_per_block /= 2;
     int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
     bpr = std::min<int64_t>(std::max<int64_t>(bpr, 1), 65536);
     args.n = n;

@@ -83,10 +83,15 @@ def test_weighted_and_quantiles(gpu, oracle):
     assert len(anchors) == 6 and len(hist) == 6
 
 
-def test_large_vector_closed_form(gpu):
-    """Full-size property check (no oracle pass needed): 2^24+3 elements, values k mod 7 → exact sums."""
-    n = (1 << 24) + 3
+@pytest.mark.parametrize("n", [(1 << 24) + 3, 4_194_304, 4_194_305, 5_000_003, 9_000_001, 12_000_001, 14_680_064, 14_680_065])
+def test_large_vector_closed_form(gpu, n):
+    """Full-size property check (no oracle pass needed): values k mod 7 → exact sums.  The sizes cover every layout of the
+    arrival counting of the fused final combine (fm_kernel_parts.hpp block_combine: 1 group below 512 workgroups of
+    8192 elements, 2…6 groups up to 1791, 7 above) and its boundaries; run twice, the counters must be back at zero."""
     x = (np.arange(n, dtype=np.int64) % 7).astype(np.float32)
-    m = dv(gpu, x).moments()
+    x[n // 3] = -2.0
     xs = x.astype(np.float64)
-    assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == 0.0 and m.max == 6.0
+    v = dv(gpu, x)
+    for _ in range(2):
+        m = v.moments()
+        assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == -2.0 and m.max == 6.0

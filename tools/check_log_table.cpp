@@ -32,11 +32,14 @@ static float log_table(float a) {
     return (float)(hi + (lo + lp));
 }
 
+#ifndef CHECK_STRIDE
+#define CHECK_STRIDE 1          // every positive finite argument; a larger odd stride for a quick sample (tests/test_log_table_cpu.py)
+#endif
+
 int main(void) {
     long long diffs = 0;
-    double worst = 0;
 #pragma omp parallel for reduction(+ : diffs) schedule(static, 1 << 20)
-    for (int64_t u = 1; u < 0x7f800000ll; ++u) {
+    for (int64_t u = 1; u < 0x7f800000ll; u += CHECK_STRIDE) {
         const float x = u2f((uint32_t)u);
         const float ref = (float)log((double)x);
         const float got = log_table(x);
@@ -45,7 +48,6 @@ int main(void) {
             if (diffs < 20) printf("x = %a: table %a, libm %a\n", x, got, ref);
         }
     }
-    printf("positive finite fp32 arguments: %lld differences\n", diffs);
-    (void)worst;
+    printf("positive finite fp32 arguments (stride %d): %lld differences\n", CHECK_STRIDE, diffs);
     return diffs != 0;
 }
