@@ -72,6 +72,14 @@ def set_fusion(enabled: bool) -> bool:
     return bool(prev.value)
 
 
+def fusion_hold(hold: bool) -> bool:
+    """While held, pending chains run only when a value is needed or at flush() — many independent chains of identical
+    structure recorded under a hold are batched as rows of the same launches (include/fmhip.h: fmhip_fusion_hold)."""
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_fusion_hold(1 if hold else 0, _C.byref(prev)))
+    return bool(prev.value)
+
+
 MATH_EXACT, MATH_FAST = 0, 1
 
 

@@ -103,6 +103,14 @@ int fmhip_set_fusion(int enabled, int* previous) {
         e.fusion = enabled != 0;
     });
 }
+int fmhip_fusion_hold(int hold, int* previous) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        e.require_init();
+        if (previous) *previous = e.fusion_hold ? 1 : 0;
+        e.fusion_hold = hold != 0;
+    });
+}
 int fmhip_set_math_mode(int mode, int* previous) {
     return guarded([&] {
         Engine& e = Engine::get();

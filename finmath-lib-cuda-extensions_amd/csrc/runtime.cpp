@@ -714,7 +714,7 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
     nd->weight = w;
     pending_.insert(nd);
-    if (!fusion || w > FUSION_MAX_WEIGHT) {
+    if (!fusion || (w > FUSION_MAX_WEIGHT && !fusion_hold)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
     }

@@ -118,6 +118,7 @@ public:
     // ops
     fmhip_vec call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar);
     bool fusion = false;
+    bool fusion_hold = false;               // fmhip_fusion_hold: no execution on the engine's own accord
     int math_mode = FMHIP_MATH_EXACT;
     void flush_all();
     void materialize(const std::vector<Node*>& targets);

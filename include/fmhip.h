@@ -184,6 +184,12 @@ int fmhip_set_fusion(int enabled, int* previous);
 /* Execute every pending node that is still referenced by a live handle (identical programs over
  * different vectors are batched into one launch). */
 int fmhip_flush(void);
+/* While held (hold != 0), a pending chain is never executed on the engine's own accord (normally it is once ≈ 40 methods
+ * have accumulated below one handle, so that the device starts early); it runs when a value is needed or at fmhip_flush.
+ * For callers that record many independent chains of identical structure — all products of a valuation, all bumped
+ * parameter sets of a Jacobian — and want them batched as rows of the same launches.  Releasing the hold executes nothing
+ * by itself.  Returns the previous setting through *previous (may be NULL). */
+int fmhip_fusion_hold(int hold, int* previous);
 
 /* Arithmetic mode of exp and log (everything else is identical in both modes):
  *   FMHIP_MATH_EXACT (default): evaluated in fp64 and narrowed once — bit-identical to the reference's CPU twin

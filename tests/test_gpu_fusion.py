@@ -141,6 +141,51 @@ def test_flush_batches_identical_programs(gpu, oracle):
         assert (got[k] == want).all(), k
 
 
+def test_fusion_hold_batches_long_chains(gpu, oracle):
+    """fmhip_fusion_hold: chains longer than the engine's own execution threshold (≈ 40 pending methods) are normally
+    launched one by one as each crosses it; recorded under a hold they stay pending and the flush batches the identical
+    chains as rows — far fewer launches, the same bits."""
+    n, B, L = 4099, 24, 60
+    f = gpu.RandomVariableHipFactory()
+    xs = [oracle.java_random_doubles(77 + k, n) for k in range(B)]
+
+    def record(rvs):
+        out = []
+        for k, rv in enumerate(rvs):
+            v = rv
+            for i in range(L):
+                v = v.mult(1.0 + 1e-3 * (k + 1)).add(1e-4 * i).cap(5.0) if i % 3 else v.squared().sqrt().add(0.5)
+            out.append(v)
+        return out
+
+    gpu.set_fusion(True)
+    try:
+        rvs = [f.createRandomVariable(0.0, x) for x in xs]
+        gpu.flush()
+        before = gpu.pool_stats().n_kernel_launches
+        res_plain = record(rvs)
+        gpu.flush()
+        launches_plain = gpu.pool_stats().n_kernel_launches - before
+        assert gpu.fusion_hold(True) is False
+        before = gpu.pool_stats().n_kernel_launches
+        res_held = record(rvs)
+        assert gpu.pool_stats().n_kernel_launches == before            # nothing ran on the engine's own accord
+        assert gpu.fusion_hold(False) is True
+        assert gpu.pool_stats().n_kernel_launches == before            # releasing the hold executes nothing by itself
+        gpu.flush()
+        launches_held = gpu.pool_stats().n_kernel_launches - before
+        got_plain = [r.getRealizations() for r in res_plain]
+        got_held = [r.getRealizations() for r in res_held]
+    finally:
+        gpu.fusion_hold(False)
+        gpu.set_fusion(False)
+    assert launches_plain >= B and launches_held <= 8, (launches_plain, launches_held)
+    of = oracle.RandomVariableFloatFactory()
+    want = [r.getRealizations() for r in record([of.createRandomVariable(0.0, x) for x in xs])]
+    for k in range(B):
+        assert (got_plain[k] == want[k]).all() and (got_held[k] == want[k]).all(), k
+
+
 def test_long_chain_is_split_not_refused(gpu, oracle):
     """More pending ops / inputs than one launch holds: executed in several launches, same bits."""
     n = 2053
