@@ -6,8 +6,8 @@
 // counterpart of the reference's `nvcc -fmad false`, JCudaUtils.java:69-70), and exp/log/pow/sin/cos are
 // evaluated in fp64 and narrowed ONCE — the twin computes `(float)Math.exp(realizations[i])` (:905).  The fp64
 // intermediates of exp, log, sqrt, sin, cos are accurate enough that the narrowed result equals the twin's for every one
-// of the 2^32 fp32 arguments (benchmarks/exhaustive_unary.py, profiles/round01_exhaustive_parity.json); pow with a
-// generic exponent differs in a few dozen arguments per exponent, by one fp32 ulp.
+// of the 2^32 fp32 arguments (benchmarks/exhaustive_unary.py, profiles/round01_exhaustive_parity.json), and so does pow
+// for each of the 29 exponents tried.
 #pragma once
 #ifndef __HIPCC_RTC__           // the JIT tier compiles this header with hiprtc, which brings its own runtime declarations
 #include <hip/hip_runtime.h>
@@ -223,14 +223,18 @@ __device__ __forceinline__ float pow_pos(float a, float yf) {
     const int ki = (int)(uint32_t)__double_as_longlong(t);
     const double ff = (P_hi - k) + P_lo;
     const double r = __builtin_fma(ff, 0x1.abc9e3b39803fp-56, ff * 0x1.62e42fefa39efp-1);   // ff · ln 2
-    double p = 0x1.286f24b3f714bp-22;                                     // e^r as in exp_f
-    p = fma_c(p, r, 0x1.72ad803971e4dp-19);
-    p = fma_c(p, r, 0x1.a019d81272de4p-16);
-    p = fma_c(p, r, 0x1.a019c3487562dp-13);
-    p = fma_c(p, r, 0x1.6c16c17016625p-10);
-    p = fma_c(p, r, 0x1.1111111710d7bp-7);
-    p = fma_c(p, r, 0x1.5555555555369p-5);
-    p = fma_c(p, r, 0x1.5555555554f90p-3);
+    // e^r as in exp_f, but with a tail of degree 9 (2^-59.8 instead of 2^-48.6: tools/minimax_coefficients.py): exp_f only
+    // has to separate the 2^29 arguments whose result is not trivially 0, 1 or inf; pow sees 2^31 bases per exponent
+    double p = 0x1.1f6701e62eb6ap-29;
+    p = fma_c(p, r, 0x1.af38e5e7b1a55p-26);
+    p = fma_c(p, r, 0x1.27e4e1e60c4eep-22);
+    p = fma_c(p, r, 0x1.71de0d950eaadp-19);
+    p = fma_c(p, r, 0x1.a01a01a47ebf9p-16);
+    p = fma_c(p, r, 0x1.a01a01a7caa3bp-13);
+    p = fma_c(p, r, 0x1.6c16c16c167ddp-10);
+    p = fma_c(p, r, 0x1.11111111109abp-7);
+    p = fma_c(p, r, 0x1.5555555555555p-5);
+    p = fma_c(p, r, 0x1.5555555555556p-3);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -249,11 +253,25 @@ __device__ __noinline__ float pow_f(float a, float s) {
     // (positive bases only: Math.pow(-inf, 1.5) = +inf and Math.pow(-0.0, 2.5) = +0.0 are the library's business)
     if (s == 1.5f && a > 0.0f) return (float)(x * __builtin_sqrt(x));
     if (s == 2.5f && a > 0.0f) return (float)((x * x) * __builtin_sqrt(x));
-    // +denormal | +normal base (0x180), finite exponent (everything but NaN 0x3 and ±inf 0x204)
-    if (__builtin_amdgcn_classf(a, 0x180) && __builtin_amdgcn_classf(s, 0x1f8)) {
-        const float r = pow_pos(a, s);
-        // results in the fp32 denormal range keep few bits, so exact ties are common there: library path
+    // +denormal | +normal base (0x180) with a finite exponent (everything but NaN 0x3 and ±inf 0x204); -normal | -denormal
+    // base (0x018) with an INTEGER exponent (wave-uniform test): ±|x|^y on the same path, sign by the parity of y (every
+    // float >= 2^24 is an even integer).  The library's power is good to a fraction of an fp64 ulp but not exact, which is
+    // what an exact tie needs: (-1.375)^7 = -19487171/2^21 lies exactly between two floats.
+    const bool s_finite = __builtin_amdgcn_classf(s, 0x1f8);
+    const bool s_integer = s_finite && __builtin_truncf(s) == s;
+    const bool negative_base = __builtin_amdgcn_classf(a, 0x018) && s_integer;
+    if ((__builtin_amdgcn_classf(a, 0x180) && s_finite) || negative_base) {
+        float r = pow_pos(__builtin_fabsf(a), s);
+        if (negative_base && __builtin_fabsf(s) < 16777216.0f && (((int)s) & 1) != 0) r = -r;
         if (__builtin_fabsf(r) >= 1.17549435e-38f) return r;
+        // Results in the fp32 denormal range keep few bits, so exact ties are common there.  For a small positive integer
+        // exponent the square-and-multiply product of doubles is EXACT whenever the power is short enough to be a tie
+        // (x = 27·2^-30: x^5 = 14348907·2^-150), and the conversion then rounds it once; everything else: library path.
+        if (s_integer && s > 0.0f && s <= 64.0f) {
+            double acc = 1.0, base = x;
+            for (int n = (int)s; n != 0; n >>= 1) { if (n & 1) acc *= base; base *= base; }
+            return (float)acc;
+        }
     }
     return (float)jpow(x, (double)s);
 }
