@@ -75,6 +75,7 @@ static inline uint32_t fm_pack_op(unsigned code, unsigned r1, unsigned r2, unsig
 //   [.., +n_red)                   double        reduction shifts
 //   then n_scal floats (padded to a multiple of 2)
 constexpr int FM_ROW_WORDS_MAX = FM_MAX_IN + FM_MAX_OUT + FM_MAX_RED + FM_MAX_SCAL / 2;   // 54 x 8 B
+constexpr int FM_INLINE_WORDS = 368;    // row blocks carried in the kernel arguments (the argument segment is limited to 4 KB)
 
 // Arrival counters of the fused final combine: 8 planes (up to 7 group counters + one second-level counter per row:
 // fm_kernel_parts.hpp block_combine) of one 256-byte block per row — 128 MB of the 288 GB.  Device-scope atomics are executed at the memory side, ≈ 11-13 ns apiece
@@ -90,7 +91,7 @@ constexpr uint32_t FM_ARGS_LOG_TABLE = 1u;      // the program evaluates log_f: 
 struct DevProgramArgs {
     uint32_t n_ops, n_in, n_out, n_red;
     uint32_t n_scal, row_words;          // row stride in 8-byte words
-    uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; batch==1 → row block inline
+    uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; use_inline: the row blocks of the whole batch are in inline_row
     uint32_t variant, flags;             // kernel variant (FM_VARIANT_*); FM_ARGS_* bits
     int64_t  n;                          // elements per vector
     double*   results;                   // [batch][n_red][4] final {Σ, Σ², min, max} (written by the last workgroup of a row)
@@ -98,7 +99,10 @@ struct DevProgramArgs {
     uint32_t out_reg[FM_MAX_OUT];        // 32-bit so that they are fetched with scalar loads (gfx9 has no s_load_u8)
     uint32_t red_reg[FM_MAX_RED];
     DevOp    ops[FM_MAX_OPS + 2];            // two slack entries: the kernel prefetches ops[pc+1], ops[pc+2]
-    uint64_t inline_row[FM_ROW_WORDS_MAX];
+    uint64_t inline_row[FM_INLINE_WORDS];    // [batch][row_words] when batch·row_words fits: no table upload (an in-stream copy kernel, ≈ 5 µs) for that launch
 };
+
+static_assert(sizeof(DevProgramArgs) <= 4096, "kernel arguments are limited to 4 KB");
+static_assert(FM_INLINE_WORDS >= FM_ROW_WORDS_MAX, "one row always fits");
 
 } // namespace fm

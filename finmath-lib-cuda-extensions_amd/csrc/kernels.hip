@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 {
     constexpr int T = E / FM_VEC;                   // float4 per lane per pass
     const uint32_t row = blockIdx.y;
-    // Row block: wave-uniform, read with SCALAR loads — kernarg segment when INLINE_ROW, else the row table, which
+    // Row block: wave-uniform, read with SCALAR loads — kernarg segment when INLINE_ROW (small batches), else the row table, which
     // must be a `const __restrict__` kernel parameter of its own: fetched through a pointer stored inside the
     // argument struct the compiler cannot prove it read-only and falls back to vector loads + v_readfirstlane.
-    const uint64_t* __restrict__ rowp = INLINE_ROW ? A.inline_row : (rows + (size_t)row * A.row_words);
+    const uint64_t* __restrict__ rowp = (INLINE_ROW ? A.inline_row : rows) + (size_t)row * A.row_words;
     const uint32_t n_in = A.n_in, n_out = A.n_out, n_ops = A.n_ops;
     const int64_t n = A.n;
     const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + n_in + n_out + A.n_red);
