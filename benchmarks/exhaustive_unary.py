@@ -1,7 +1,7 @@
 """Exhaustive parity of the unary opcodes over ALL 2^32 fp32 bit patterns: HIP engine (through the C-ABI) against the oracle
 (C restatement of RandomVariableFromFloatArray: `(float)exp((double)x)` etc.).  Not a pytest (≈ 2-4 minutes on the GPU box):
 
-    python benchmarks/exhaustive_unary.py [--ops EXP,LOG,SQRT,INVERT,POW_S:0.5,POW_S:-2.7] [--fast] [--json out.json]
+    python benchmarks/exhaustive_unary.py [--ops EXP,LOG,SQRT,INVERT,POW_S:0.5,CAP_S:nan,DIV_S:3] [--fast] [--json out.json]
 
 --fast measures FMHIP_MATH_FAST (hardware exp/log): there the figure of interest is max_ulp (stated bound: 2).
 
@@ -21,8 +21,8 @@ def oracle_chunk(args):
     import oracle
     x = np.arange(start, start + CHUNK, dtype=np.uint64).astype(np.uint32).view(np.float32)
     with np.errstate(all="ignore"):
-        if op.startswith("POW_S:"):                 # "POW_S:<exponent>"
-            return oracle.f_v1s1("POW_S", x, float(op.split(":")[1]))
+        if ":" in op:                               # "<scalar opcode>:<scalar>", e.g. POW_S:0.5, CAP_S:nan, DIV_S:3
+            return oracle.f_v1s1(op.split(":")[0], x, float(op.split(":")[1]))
         return oracle.f_v1s0(op, x)
 
 
@@ -53,7 +53,7 @@ def main():
         for start, want in zip(starts, pool.map(oracle_chunk, [(op, s) for s in starts])):
             x = np.arange(start, start + CHUNK, dtype=np.uint64).astype(np.uint32).view(np.float32)
             v = fm.DeviceVector.from_host(x)
-            got = (v.v1s1("POW_S", float(op.split(":")[1])) if op.startswith("POW_S:") else v.v1s0(op)).to_float32()
+            got = (v.v1s1(op.split(":")[0], float(op.split(":")[1])) if ":" in op else v.v1s0(op)).to_float32()
             gn, wn = np.isnan(got), np.isnan(want)
             nan_mismatch += int((gn != wn).sum())
             bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(gn & wn)
