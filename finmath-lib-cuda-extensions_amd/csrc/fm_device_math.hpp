@@ -31,6 +31,9 @@ __device__ __forceinline__ float jmax(float a, float b) { return __builtin_eleme
 // off Σx² (fm_kernel_parts.hpp).  (inline asm: the builtin would first canonicalise both inputs with a v_max_f32 x,x each)
 __device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// three operands per instruction, same semantics: an accumulator takes two new elements at a time
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // java.lang.Math.pow special cases that differ from C99 pow (see oracle/rv_float.c jpow).
 __device__ __forceinline__ double jpow(double x, double y) {
     if (y == 0.0) return 1.0;

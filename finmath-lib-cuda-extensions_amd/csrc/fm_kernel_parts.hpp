@@ -74,19 +74,19 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
             const double dv = (double)x[j];
             acc_sum += dv;
             acc_sq = __builtin_fma(dv, dv, acc_sq);
-            acc_min = hw_min(acc_min, x[j]);
-            acc_max = hw_max(acc_max, x[j]);
         }
+#pragma unroll
+        for (int j = 0; j < E; j += 2) { acc_min = hw_min3(acc_min, x[j], x[j + 1]); acc_max = hw_max3(acc_max, x[j], x[j + 1]); }
     } else if (pass_full) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const double dv = (double)x[j] - shift;
             acc_sum += dv;
             acc_sq = __builtin_fma(dv, dv, acc_sq);
-            acc_min = hw_min(acc_min, x[j]);
-            acc_max = hw_max(acc_max, x[j]);
             nan_mask |= __ballot(x[j] != x[j]);
         }
+#pragma unroll
+        for (int j = 0; j < E; j += 2) { acc_min = hw_min3(acc_min, x[j], x[j + 1]); acc_max = hw_max3(acc_max, x[j], x[j + 1]); }
     } else {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
