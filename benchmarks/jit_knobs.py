@@ -29,13 +29,17 @@ def child():
     outs = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
     sys.path.insert(0, ROOT)
     import bench
-    if os.environ.get("KNOB_NO_REDUCE"):            # the same stream without the fused reductions (output vector only)
+    drop = set(filter(None, os.environ.get("KNOB_DROP", "").split("+")))      # e.g. LOG+SQRT: those methods become abs()
+    if os.environ.get("KNOB_NO_REDUCE") or drop:    # variants of the stream: without the fused reductions / without some methods
         p = fm.Program(3)
         x, y, z = 0, 1, 2
+        f = lambda name, a: p.op("ABS" if name in drop else name, a)
         t = p.op("SUB", p.op("MULT", p.op("DIV_S", p.op("ADD_S", x, s=4.0), s=2.0), y), z)
-        u = p.op("SQRT", p.op("ABS", p.op("LOG", p.op("EXP", t))))
+        u = f("SQRT", p.op("ABS", f("LOG", f("EXP", t))))
         v = p.op("ADDPRODUCT", p.op("FLOOR_S", p.op("CAP_S", u, s=1.5), s=0.25), y, z)
-        p.output(p.op("CHOOSE", t, v, x))
+        w = p.op("CHOOSE", t, v, x)
+        p.output(w)
+        if not os.environ.get("KNOB_NO_REDUCE"): p.reduce(w)
         p.compile()
     else:
         p = bench.build_stream_s(fm)
@@ -64,10 +68,12 @@ def main():
         e, g, w, pf, *rest = c.split(",")
         env = dict(os.environ, FMHIP_JIT_ELEMS=e, FMHIP_JIT_GROUP=g, FMHIP_JIT_WAVES=w, FMHIP_JIT_PREFETCH=pf)
         if rest: env["FMHIP_ELEMS_PER_BLOCK"] = rest[0]
-        if len(rest) > 1 and rest[1] == "noreduce": env["KNOB_NO_REDUCE"] = "1"
+        if len(rest) > 1 and "noreduce" in rest[1:]: env["KNOB_NO_REDUCE"] = "1"
+        for r in rest[1:]:
+            if r.startswith("drop="): env["KNOB_DROP"] = r[5:]
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        rec = {"elems": int(e), "group": int(g), "waves": int(w), "prefetch": int(pf), "elems_per_block": int(rest[0]) if rest else 8192, "reduce": not (len(rest) > 1 and rest[1] == "noreduce")}
+        rec = {"elems": int(e), "group": int(g), "waves": int(w), "prefetch": int(pf), "elems_per_block": int(rest[0]) if rest else 8192, "reduce": not (len(rest) > 1 and "noreduce" in rest[1:]), "drop": [r[5:] for r in rest[1:] if r.startswith("drop=")]}
         if line: rec.update(json.loads(line[-1]))
         else: rec["error"] = (r.stderr or r.stdout)[-400:]
         print(json.dumps(rec), flush=True)

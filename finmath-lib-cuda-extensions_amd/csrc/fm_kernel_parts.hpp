@@ -108,27 +108,51 @@ __device__ __forceinline__ void red_finish(const double shift, const double acc_
     if (shift == 0.0) nan_mask |= __ballot(acc_sq != acc_sq);
 }
 
-// fp64 min/max with java.lang.Math semantics for the final combine of the per-workgroup partials
-__device__ __forceinline__ double jmin_d(double a, double b) {
-    if (a != a) return a;
-    if (a == 0.0 && b == 0.0 && (__double_as_longlong(b) < 0)) return b;
-    return (a <= b) ? a : b;
-}
-__device__ __forceinline__ double jmax_d(double a, double b) {
-    if (a != a) return a;
-    if (a == 0.0 && b == 0.0 && (__double_as_longlong(a) < 0)) return b;
-    return (a >= b) ? a : b;
-}
-
 // Device-coherent accesses for the hand-off between workgroups (possibly on different XCDs, whose L2s are not coherent
 // with each other): `sc1` stores / loads go through to memory, no cache-wide write-back or invalidate is needed.
 __device__ __forceinline__ void store_coherent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_coherent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup and reduction:
-// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  The LAST workgroup of a row to arrive (device-scope counter) then sums
-// the row's partials in a FIXED order (thread t takes workgroups t, t+256, …, then an LDS tree) and writes the final
-// moments: deterministic, no float atomics, and no second launch.
+// Number of arrival-counting groups of a row with `blocks` workgroups (see block_combine): 1 below 512, up to 7.
+__device__ __forceinline__ uint32_t combine_groups(uint32_t blocks) { return blocks >= 512u ? (blocks >= 1792u ? 7u : blocks >> 8) : 1u; }
+// Slots of the partial array per (row, reduction): one per workgroup + one per group (FM_COMBINE_GROUP_SLOTS >= 7).
+constexpr uint32_t FM_COMBINE_GROUP_SLOTS = 8;
+
+// One wave adds the partials p[first], p[first + stride], … (count of them; 4 doubles {Σ, Σ², min, max} each) in a FIXED
+// order: lane l takes the elements l, l + 64, … (the loads of 8 of them issued before the first is used — one at a time
+// every element is a dependent memory round trip), then the wave64 DPP tree.  The result is valid in lane 63.
+__device__ __forceinline__ void wave_sum_partials(const double* __restrict__ p, uint32_t first, uint32_t stride, uint32_t count,
+                                                  double& s1, double& s2, float& mn, float& mx)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    s1 = 0.0; s2 = 0.0; mn = __builtin_huge_valf(); mx = -__builtin_huge_valf();
+    for (uint32_t k0 = lane; k0 < count; k0 += 64u * 8u) {
+        double v[8][4];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u) {
+            const uint32_t k = k0 + u * 64u;
+            const double* q = p + (size_t)(first + (k < count ? k : k0) * stride) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[u][c] = load_coherent(q + c);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; ++u)
+            if (k0 + u * 64u < count) { s1 += v[u][0]; s2 += v[u][1]; mn = jmin(mn, (float)v[u][2]); mx = jmax(mx, (float)v[u][3]); }      // min / max are floats, widened
+    }
+    wave_reduce(s1, s2, mn, mx);
+}
+
+// Workgroup combine: wave64 DPP reduction, the 4 waves of the workgroup through LDS, one partial per workgroup and reduction:
+// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  Waves 1-3 are finished after the LDS hand-off: the rest — the coherent
+// stores, the wait for them, the arrival counter and its round trip, ≈ 3-4 µs — keeps ONE wave slot of the workgroup busy, not
+// four (measured on the bench launch: see DESIGN.md §4.2).
+// Arrival counting: device-scope atomics execute at the memory side, ≈ 11-13 ns apiece on one cache line, so a row of
+// thousands of workgroups (one vector of 2^26 paths: 8192) would queue on a single counter for longer than the kernel runs
+// (measured: 128 µs instead of 45).  A row therefore counts in G = combine_groups(gridDim.x) groups (workgroup b belongs to
+// group b mod G; each group counter in a cache line — a plane — of its own: 32 B apart was not enough).  The LAST workgroup
+// of a group adds the group's partials in a fixed order (wave_sum_partials) and, if G > 1, stores the group partial behind
+// the row's workgroup partials and moves the second-level counter; the last of those adds the G group partials.  The final
+// moments are a deterministic function of the data and of gridDim.x: no float atomics, no second launch.
 template <int NRED>
 __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], const double (&acc_sq)[NRED],
                                               const float (&acc_min)[NRED], const float (&acc_max)[NRED],
@@ -138,19 +162,26 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
 {
     __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
     __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
-    __shared__ double sh[4][FM_BLOCK];
-    __shared__ uint32_t last_flag;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
         double s1 = acc_sum[r], s2 = acc_sq[r];
         float mn = acc_min[r], mx = acc_max[r];
         if (nan_mask[r] != 0ull) { mn = __builtin_nanf(""); mx = mn; }      // wave-uniform
         wave_reduce(s1, s2, mn, mx);
-        if (lane == 63) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
+        if (lane == 63u) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // the wave that stays rotates with the workgroup index: the waves of a workgroup sit on different SIMDs, and a new
+    // workgroup needs a free slot on every one of them — lingering waves all on the same SIMD would block it just the same
+    if (wave != (blockIdx.x & 3u)) return;
+
+    const uint32_t slots = gridDim.x + FM_COMBINE_GROUP_SLOTS;             // per (row, reduction)
+    const uint32_t G = combine_groups(gridDim.x);
+    const uint32_t g = blockIdx.x % G;
+    const uint32_t members = (gridDim.x - g + G - 1u) / G;
+    uint32_t group_last = 0u;
+    if (lane == 0u) {
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
             double s1 = lds_sum[r][0], s2 = lds_sq[r][0];
@@ -160,73 +191,59 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
                 s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
                 mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
             }
-            double* out = partials + (((size_t)row * NRED + r) * gridDim.x + blockIdx.x) * 4;
+            double* out = partials + (((size_t)row * NRED + r) * slots + blockIdx.x) * 4;
             store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
         }
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // Arrival counting.  Device-scope atomics execute at the memory side, ≈ 11-13 ns apiece on one address: a row of
-        // thousands of workgroups (one vector of 2^26 paths: 8192) would queue there for longer than the kernel runs
-        // (measured: 128 µs instead of 45).  Rows with many workgroups therefore count in up to 7 groups (workgroup b
-        // belongs to group b mod G), the last arrival of each group moves a second-level counter, and the last of those
-        // is the last workgroup of the row.  The queue is per cache line, not per address (7 group counters 32 B apart:
-        // still 72 µs), so every group counter lives in a plane of its own: counter + plane·FM_COUNTER_PLANE.
-        const uint32_t G = gridDim.x >= 512u ? (gridDim.x >= 1792u ? 7u : gridDim.x >> 8) : 1u;
-        const uint32_t g = blockIdx.x % G;
-        const uint32_t members = (gridDim.x - g + G - 1u) / G;
-        uint32_t last = 0u;
         const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == members - 1u) {
             __hip_atomic_store(counter + (size_t)g * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-            if (G == 1u) last = 1u;
-            else {
-                const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (groups_done == G - 1u) { __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1u; }
-            }
+            group_last = 1u;
         }
-        last_flag = last;
     }
-    __syncthreads();
-    if (last_flag == 0u) return;                                             // workgroup-uniform
+    if (__builtin_amdgcn_readfirstlane(group_last) == 0u) return;           // lane 0 is the first active lane
+
+    // ---- this wave belongs to the last workgroup of group g: add the group's partials
+    uint32_t row_last = (G == 1u) ? 1u : 0u;
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
-        const double* p = partials + ((size_t)row * NRED + r) * gridDim.x * 4;
-        double s1 = 0.0, s2 = 0.0, mn = __builtin_huge_val(), mx = -__builtin_huge_val();
-        // Thread t adds the partials of workgroups t, t+256, … in that order.  The loads of 8 of them are issued before
-        // the first is used: left one at a time (the compiler keeps coherent loads in program order and waits for each
-        // before the dependent add), a row of 8192 workgroups cost 32 memory round trips here — ≈ 40 µs of a 45 µs kernel.
-        for (uint32_t b0 = threadIdx.x; b0 < gridDim.x; b0 += FM_BLOCK * 8u) {
-            double v[8][4];
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u) {
-                const uint32_t b = b0 + u * FM_BLOCK;
-                const double* q = p + (size_t)(b < gridDim.x ? b : b0) * 4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[u][k] = load_coherent(q + k);
+        double* base = partials + ((size_t)row * NRED + r) * slots * 4;
+        double s1, s2; float mn, mx;
+        wave_sum_partials(base, g, G, members, s1, s2, mn, mx);
+        if (lane == 63u) {
+            if (G == 1u) {
+                double* o = results + ((size_t)row * NRED + r) * 4;
+                // NaN results are canonicalised: which NaN (sign, payload) an fp64 add of two NaNs returns depends on the operand
+                // order the compiler picked, and the two execution tiers must agree bit for bit
+                o[0] = (s1 != s1) ? __builtin_nan("") : s1; o[1] = (s2 != s2) ? __builtin_nan("") : s2;
+                o[2] = (mn != mn) ? __builtin_nan("") : (double)mn; o[3] = (mx != mx) ? __builtin_nan("") : (double)mx;
+            } else {
+                double* out = base + (size_t)(gridDim.x + g) * 4;
+                store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
             }
+        }
+    }
+    if (G == 1u) return;
+    if (lane == 63u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (groups_done == G - 1u) { __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); row_last = 1u; }
+    }
+    row_last = __builtin_amdgcn_readlane(row_last, 63);
+    if (row_last == 0u) return;
+
+    // ---- last group of the row: add the G group partials
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; ++u)
-                if (b0 + u * FM_BLOCK < gridDim.x) { s1 += v[u][0]; s2 += v[u][1]; mn = jmin_d(mn, v[u][2]); mx = jmax_d(mx, v[u][3]); }
-        }
-        sh[0][threadIdx.x] = s1; sh[1][threadIdx.x] = s2; sh[2][threadIdx.x] = mn; sh[3][threadIdx.x] = mx;
-        __syncthreads();
-        for (int stride = FM_BLOCK / 2; stride > 0; stride >>= 1) {
-            if ((int)threadIdx.x < stride) {
-                sh[0][threadIdx.x] += sh[0][threadIdx.x + stride];
-                sh[1][threadIdx.x] += sh[1][threadIdx.x + stride];
-                sh[2][threadIdx.x] = jmin_d(sh[2][threadIdx.x], sh[2][threadIdx.x + stride]);
-                sh[3][threadIdx.x] = jmax_d(sh[3][threadIdx.x], sh[3][threadIdx.x + stride]);
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
+    for (int r = 0; r < NRED; ++r) {
+        const double* base = partials + ((size_t)row * NRED + r) * slots * 4;
+        double s1, s2; float mn, mx;
+        wave_sum_partials(base, gridDim.x, 1u, G, s1, s2, mn, mx);
+        if (lane == 63u) {
             double* o = results + ((size_t)row * NRED + r) * 4;
-            // NaN results are canonicalised: which NaN (sign, payload) an fp64 add of two NaNs returns depends on the operand
-            // order the compiler picked, and the two execution tiers must agree bit for bit
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const double v = sh[k][0]; o[k] = (v != v) ? __builtin_nan("") : v; }
+            o[0] = (s1 != s1) ? __builtin_nan("") : s1; o[1] = (s2 != s2) ? __builtin_nan("") : s2;
+            o[2] = (mn != mn) ? __builtin_nan("") : (double)mn; o[3] = (mx != mx) ? __builtin_nan("") : (double)mx;
         }
-        __syncthreads();
     }
 }
 

@@ -92,7 +92,11 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     for (int j = 0; j < E; ++j) asm volatile("" : "=v"(R[j]));
 
     // A.tiles_per_row counts passes of FM_BLOCK*E elements.
-    for (uint32_t tile = blockIdx.x; tile < A.tiles_per_row; tile += gridDim.x) {
+    // workgroup b takes the tiles [b·P, (b+1)·P) — the same assignment as the specialised kernels (jit.cpp)
+    const uint32_t tiles_per_block = (A.tiles_per_row + gridDim.x - 1u) / gridDim.x;
+    const uint32_t tile_begin = blockIdx.x * tiles_per_block;
+    const uint32_t tile_end = tile_begin + tiles_per_block < A.tiles_per_row ? tile_begin + tiles_per_block : A.tiles_per_row;
+    for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
         // No divergent branch around the interpreter (it would make the compiler fetch instruction words and scalar
         // operands with VECTOR loads — measured: one global_load + 500 cycles per micro-op).  Lanes past the end read
         // element 0 and are masked at the stores / reductions.  Vectors are padded to 256 B, so a partially valid

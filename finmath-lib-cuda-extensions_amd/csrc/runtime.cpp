@@ -646,7 +646,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     void* partials = nullptr; size_t partials_cap = 0;
     void* results = nullptr;  size_t results_cap = 0;
     if (n_red > 0) {
-        partials = pool_.alloc((size_t)batch * n_red * bpr * 32, &partials_cap);
+        partials = pool_.alloc((size_t)batch * n_red * ((size_t)bpr + 8) * 32, &partials_cap);       // + FM_COMBINE_GROUP_SLOTS group partials per row
         if (dev_moments) results = dev_moments;
         else { try { results = pool_.alloc((size_t)batch * n_red * 32, &results_cap); } catch (...) { pool_.release(partials, partials_cap); throw; } }
     }
