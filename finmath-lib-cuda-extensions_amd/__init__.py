@@ -80,6 +80,18 @@ def fusion_hold(hold: bool) -> bool:
     return bool(prev.value)
 
 
+class holding:
+    """`with fm.holding(): …` — record under fusion_hold(True), restore the previous setting on exit (no flush)."""
+
+    def __enter__(self):
+        self._prev = fusion_hold(True)
+        return self
+
+    def __exit__(self, *exc):
+        fusion_hold(self._prev)
+        return False
+
+
 MATH_EXACT, MATH_FAST = 0, 1
 
 

@@ -166,11 +166,12 @@ def test_fusion_hold_batches_long_chains(gpu, oracle):
         res_plain = record(rvs)
         gpu.flush()
         launches_plain = gpu.pool_stats().n_kernel_launches - before
-        assert gpu.fusion_hold(True) is False
         before = gpu.pool_stats().n_kernel_launches
-        res_held = record(rvs)
-        assert gpu.pool_stats().n_kernel_launches == before            # nothing ran on the engine's own accord
-        assert gpu.fusion_hold(False) is True
+        with gpu.holding():
+            assert gpu.fusion_hold(True) is True                       # already held by the context manager
+            res_held = record(rvs)
+            assert gpu.pool_stats().n_kernel_launches == before        # nothing ran on the engine's own accord
+        assert gpu.fusion_hold(False) is False                         # the context manager restored "not held"
         assert gpu.pool_stats().n_kernel_launches == before            # releasing the hold executes nothing by itself
         gpu.flush()
         launches_held = gpu.pool_stats().n_kernel_launches - before
