@@ -55,12 +55,43 @@ class FmhipError(RuntimeError):
         self.code = code
 
 
+def _source_hash() -> str:
+    """Content hash of everything libfmhip.so is built from (content, not mtimes: a snapshot copy of the tree keeps the former)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    files += [os.path.join(_HERE, "host", f) for f in sorted(os.listdir(os.path.join(_HERE, "host")))]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "fmhip.h"))
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+_HASH_PATH = LIB_PATH + ".srchash"
+
+
 def build(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 … → lib/libfmhip.so (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"])
     subprocess.check_call(["make", "-C", CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    with open(_HASH_PATH, "w") as fh:
+        fh.write(_source_hash())
     return LIB_PATH
+
+
+def _stale() -> bool:
+    """True when the library on disk was not built from the sources on disk (edited csrc, or never built)."""
+    if not os.path.exists(LIB_PATH):
+        return True
+    try:
+        with open(_HASH_PATH) as fh:
+            return fh.read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 _lib = None
@@ -74,7 +105,7 @@ def lib():
     # NOTE: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).  A process that uses both
     # must `import torch` BEFORE this library is loaded, so that the loader resolves our NEEDED
     # libamdhip64.so.7 to the runtime already in the process (one HIP runtime, shared device pointers).
-    if not os.path.exists(LIB_PATH):
+    if _stale():
         build()
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing — the HIP extension is required (no CPU fallback exists)")

@@ -195,8 +195,15 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
             store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
         }
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Ordering of this hand-off (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table): every partial is an sc1
+        // store drained by the s_waitcnt above before the counter moves; the last arriver learns that it is last from the value
+        // its own add RETURNED and loads the partials (all sc1 loads, wave_sum_partials) only after that.  The hardware keeps that
+        // order (the loads are issued behind a branch on the returned value); the signal fence keeps the COMPILER from moving the
+        // relaxed loads or stores across the relaxed add, whichever compiler (hipcc today, hiprtc at run time) builds this header.
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (arrived == members - 1u) {
             __hip_atomic_store(counter + (size_t)g * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             group_last = 1u;
@@ -228,6 +235,7 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
     if (lane == 63u) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (groups_done == G - 1u) { __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); row_last = 1u; }
     }
     row_last = __builtin_amdgcn_readlane(row_last, 63);

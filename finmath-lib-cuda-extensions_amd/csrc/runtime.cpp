@@ -141,6 +141,10 @@ void Engine::init(int device_index) {
     hip_check(hipSetDevice(device_index), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     ring_cap_ = size_t(4) << 20;
+    if (const char* e = std::getenv("FMHIP_RING_BYTES")) {      // tests shrink the ring so that a wrap costs a few launches, not thousands
+        const long long v = std::atoll(e);
+        if (v >= 4096) ring_cap_ = ((size_t)v + 255) & ~size_t(255);
+    }
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
@@ -223,6 +227,7 @@ size_t Engine::ring_reserve(size_t bytes) {
     if (ring_off_ + bytes > ring_cap_) {        // wrap: earlier tables may still be read by queued kernels
         hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(ring wrap)");
         ring_off_ = 0;
+        ++ring_generation_;                     // device copies of earlier tables are about to be overwritten: nobody may reuse them
     }
     const size_t off = ring_off_;
     ring_off_ += bytes;
@@ -1219,6 +1224,7 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
     require_init(); check_n(n_paths);
     if (n_steps <= 0 || n_factors <= 0 || !dt || !out || path_offset < 0)
         throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad Brownian motion description");
+    if (n_factors > 32768) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "more than 32768 factors");      // one launch keeps whole steps together (grid.y)
     const int64_t n_streams = (int64_t)n_steps * n_factors;
     const int64_t stride = (n_paths + 63) & ~int64_t(63);              // every vector 256-B aligned
     Buffer* slab = new_buffer(std::max<int64_t>(stride, 64) * n_streams);

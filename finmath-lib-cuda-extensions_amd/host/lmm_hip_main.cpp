@@ -1,7 +1,7 @@
 // lmm_hip — LMM ATM swaption calibration on the MI355X engine (BASELINE.json configs[3] and [4]).
 // One process = one GPU.  With --world W --rank R --nccl-id-file F the Monte-Carlo paths are sharded over W processes
 // (rank R simulates global paths [R·paths, (R+1)·paths) — the counter-based generator makes the union identical to a
-// single-GPU run); the ONLY communication is one RCCL all-reduce of the 144 expectation sums per objective evaluation
+// single-GPU run); the ONLY communication is one RCCL all-gather of the 144 x {Σ, Σ², min, max} expectation partials per objective evaluation
 // (SURVEY.md §8e).  Every rank then takes the same Levenberg–Marquardt step.
 #include <fstream>
 #include <thread>
@@ -40,41 +40,63 @@ int main(int argc, char** argv) {
         ncclComm_t comm = nullptr;
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)
         long long collectives = 0;
+        double collective_seconds = 0.0;                 // host wall time from enqueueing the collective to having its result (latency of the exchange incl. the read-back)
         if (o.world > 1 || !o.ncclIdFile.empty()) {
             if (o.ncclIdFile.empty()) throw std::runtime_error("--world needs --nccl-id-file");
-            ncclUniqueId id;
-            if (o.rank == 0) {                           // bootstrap: rank 0 publishes the unique id through a file
-                ncclCheck(ncclGetUniqueId(&id), "ncclGetUniqueId");
-                { std::ofstream f(o.ncclIdFile + ".tmp", std::ios::binary); f.write((const char*)&id, sizeof id); }
+            // Bootstrap: rank 0 publishes {nonce, unique id} through a file.  The nonce (--nccl-nonce, the launcher hands every rank the
+            // same fresh value) tells the id of THIS launch from one a crashed or earlier run left at the same path: the other ranks
+            // ignore a file that carries another nonce.  Rank 0 removes any stale file first and the new one once the communicator exists.
+            struct IdFile { uint64_t magic, nonce; ncclUniqueId id; } rec{};
+            const uint64_t MAGIC = 0x464d4e43434c4944ull;       // "FMNCCLID"
+            if (o.rank == 0) {
+                std::remove(o.ncclIdFile.c_str());
+                rec.magic = MAGIC; rec.nonce = (uint64_t)o.ncclNonce;
+                ncclCheck(ncclGetUniqueId(&rec.id), "ncclGetUniqueId");
+                { std::ofstream f(o.ncclIdFile + ".tmp", std::ios::binary); f.write((const char*)&rec, sizeof rec); }
                 std::rename((o.ncclIdFile + ".tmp").c_str(), o.ncclIdFile.c_str());
             } else {
                 for (int tries = 0; ; ++tries) {
                     std::ifstream f(o.ncclIdFile, std::ios::binary);
-                    if (f && f.read((char*)&id, sizeof id) && f.gcount() == (std::streamsize)sizeof id) break;
+                    if (f && f.read((char*)&rec, sizeof rec) && f.gcount() == (std::streamsize)sizeof rec && rec.magic == MAGIC && rec.nonce == (uint64_t)o.ncclNonce) break;
                     if (tries > 6000) throw std::runtime_error("timed out waiting for " + o.ncclIdFile);
                     std::this_thread::sleep_for(std::chrono::milliseconds(10));
                 }
             }
+            const ncclUniqueId id = rec.id;
             ncclCheck(ncclCommInitRank(&comm, o.world, id, o.rank), "ncclCommInitRank");
+            if (o.rank == 0) std::remove(o.ncclIdFile.c_str());                    // every rank has joined, i.e. has read it
             const int count = (int)m.swaptions.size();
-            check(fmhip_vec_create_uninitialized((int64_t)count * 8, &sums));       // 32 bytes per product
+            // [rank][product][Σ, Σ², min, max] doubles: every rank's partial moments, gathered (8 floats = 32 bytes per product and rank)
+            check(fmhip_vec_create_uninitialized((int64_t)count * 8 * o.world, &sums));
             void* stream = nullptr; check(fmhip_get_stream(&stream));
             const int64_t totalPaths = (int64_t)o.world * o.paths;
-            be.averages = [=, &collectives](const std::vector<RV>& v) {
+            const int world = o.world, rank = o.rank;
+            be.averages = [=, &collectives, &collective_seconds](const std::vector<RV>& v) {
                 std::vector<fmhip_vec> h;
                 for (const RV& x : v) {
                     auto p = dynamic_cast<const RandomVariableHip*>(x.get());
                     if (!p || p->isDeterministic()) throw std::runtime_error("sharded expectation of a non-device value");
                     h.push_back(p->deviceVector().handle());
                 }
+                if ((int)h.size() != count) throw std::runtime_error("sharded expectation: unexpected product count");
                 void* dev = nullptr; check(fmhip_vec_device_ptr(sums, &dev));
-                check(fmhip_reduce_moments_batch_device(h.data(), (int)h.size(), nullptr, dev));
-                ncclCheck(ncclAllReduce(dev, dev, h.size() * 4, ncclDouble, ncclSum, comm, (hipStream_t)stream), "ncclAllReduce");
+                double* all = (double*)dev;
+                check(fmhip_reduce_moments_batch_device(h.data(), count, nullptr, all + (size_t)rank * count * 4));
+                // The single exchange of an objective evaluation: every rank's {Σ, Σ², min, max} partials to every rank —
+                // an all-gather, so that min / max stay meaningful and the sums are added in RANK ORDER on every rank (bitwise equal
+                // results everywhere, whatever algorithm the library picks); 4.6 KB per rank, latency-bound.
+                const auto t0 = std::chrono::steady_clock::now();
+                ncclCheck(ncclAllGather(all + (size_t)rank * count * 4, all, (size_t)count * 4, ncclDouble, comm, (hipStream_t)stream), "ncclAllGather");
                 ++collectives;
-                std::vector<float> raw(h.size() * 8);
-                check(fmhip_vec_read_float(sums, raw.data(), (int64_t)raw.size()));  // same stream: ordered after the all-reduce
-                std::vector<double> out(h.size());
-                for (size_t k = 0; k < h.size(); ++k) { double s; std::memcpy(&s, &raw[k * 8], 8); out[k] = s / (double)totalPaths; }
+                std::vector<float> raw((size_t)count * 8 * world);
+                check(fmhip_vec_read_float(sums, raw.data(), (int64_t)raw.size()));  // same stream: ordered after the collective
+                collective_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                std::vector<double> out((size_t)count);
+                for (int k = 0; k < count; ++k) {
+                    double total = 0.0;
+                    for (int r = 0; r < world; ++r) { double s; std::memcpy(&s, &raw[((size_t)r * count + k) * 8], 8); total += s; }
+                    out[(size_t)k] = total / (double)totalPaths;
+                }
                 return out;
             };
         }
@@ -97,11 +119,11 @@ int main(int argc, char** argv) {
             }
             char buf[768];
             std::snprintf(buf, sizeof buf, ", \"kernel_launches\": %lld, \"path_ops\": %.6e, \"device_bytes_reserved\": %lld, \"device\": \"%s\", "
-                          "\"world\": %d, \"rank\": %d, \"total_paths\": %lld, \"rccl_all_reduces\": %lld, "
+                          "\"world\": %d, \"rank\": %d, \"total_paths\": %lld, \"rccl_collectives\": %lld, \"rccl_collective_seconds\": %.6f, "
                           "\"specialised_kernels\": %lld, \"specialisations_from_disk_cache\": %lld, \"specialisations_pending\": %lld, \"specialisation_seconds\": %.3f, "
                           "\"algorithmic_bytes\": %lld, \"specialised_launches\": %lld",
                           (long long)(s.n_kernel_launches - s0.n_kernel_launches), (double)(s.n_ops_executed - s0.n_ops_executed) * (double)o.paths,
-                          (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives,
+                          (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives, collective_seconds,
                           (long long)jc, (long long)jd, (long long)jp, js, (long long)(bytes1 - bytes0), (long long)jl);
             return std::string(buf) + prof;
         };

@@ -11,7 +11,7 @@ namespace fmhost { namespace lmm {
 struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
-    int world = 1, rank = 0; std::string ncclIdFile;
+    int world = 1, rank = 0; std::string ncclIdFile; long long ncclNonce = 0;
     int chunk = 0;                                         // LIBOR components per fused launch; 0 = back end default
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     std::string brownian = "philox";                        // philox (counter-based, on the device) | mersenne (finmath's CPU generator through the factory)
@@ -31,6 +31,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--world") o.world = std::atoi(next());
         else if (a == "--rank") o.rank = std::atoi(next());
         else if (a == "--nccl-id-file") o.ncclIdFile = next();
+        else if (a == "--nccl-nonce") o.ncclNonce = std::atoll(next());
         else if (a == "--profile") o.profile = true;
         else if (a == "--brownian") o.brownian = next();
         else if (a == "--jacobian-batch") o.jacobianBatch = std::atoi(next());

@@ -247,3 +247,4 @@ def bm_generate(seed: int, dt, n_factors: int, n_paths: int, path_offset: int = 
 
 
 from .random_variable_float import RandomVariableFromFloatArray, RandomVariableFloatFactory  # noqa: E402,F401
+from .random_variable_double import RandomVariableFromDoubleArray, RandomVariableFromArrayFactory  # noqa: E402,F401

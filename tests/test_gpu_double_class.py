@@ -1,0 +1,154 @@
+"""North-star clause "results match the reference RandomVariableFromArrayFactory on the same inputs within a stated float
+tolerance": the HIP path (fp32 storage and arithmetic) against the DOUBLE-precision class, same double[] inputs.
+
+The real RandomVariableFromArrayFactory / RandomVariableFromDoubleArray live in finmath-lib 5.1.3 (not vendored); the
+comparator is the stand-in oracle/random_variable_double.py + oracle/rv_double.c ("parity unpinned" at bit level, which is
+why this is a TOLERANCE test).  Inputs and cases: the reference's own operator test, RandomVariableGPUTest.java:190-357
+(x = 100 000 doubles of `new Random(31415)`, y = the constant realizations[0]), stream S and the four reductions on the
+configs[1] inputs (1 M paths).
+
+THE TOLERANCE, stated:  |hip - double| <= T · (1 + |double|)  with
+    T = 1e-7            the reference's intended bound (RandomVariableGPUTest.java:217: `> 1E-7*(1+Math.abs(xr1[i]))`), for
+                        every case whose result carries ONE fp32 rounding of O(1) operands;
+    T = k · 2^-24       for the cases whose data path holds k > 1 fp32 roundings (the narrowing of each double input to
+                        fp32 counts, RandomVariableCuda.java:768-774): a quotient or product of two narrowed operands has
+                        k = 3 half-ulp errors = 1.79e-7 relative and cannot meet 1e-7·(1+|x|) once |x| > 1.3 — which is why
+                        the reference keeps `vid` and `invert` commented out (:282-296) and never asserts its flag (:215-222).
+    k per case is listed in ROUNDINGS below.  Measured worst ratio against the plain 1e-7 bound over all cases: 1.16.
+NaN-ness must agree exactly.  Reductions: |Δ| <= 1e-7·(1+|value|).
+"""
+import numpy as np
+import pytest
+
+from test_gpu_reference_tests import OPERATOR_CASES
+
+REFERENCE_TOL = 1e-7            # RandomVariableGPUTest.java:217
+HALF_ULP = 2.0 ** -24           # relative error of one fp32 rounding
+
+# fp32 roundings on the longest data path (input narrowings included); default 1 → the reference's bound
+ROUNDINGS = {"chain": 14, "addSumProduct": 6, "accrue": 4, "discount": 4, "addProduct": 4, "addRatio": 5, "subRatio": 5,
+             "div": 3, "vid": 3, "mult": 3, "invert": 2, "choose": 2, "isNaN": 1}
+
+
+def tolerance(case: str) -> float:
+    k = max([v for prefix, v in ROUNDINGS.items() if case.startswith(prefix)] + [1])
+    return max(REFERENCE_TOL, k * HALF_ULP)
+
+
+def run_case(f, factory, stream):
+    x = factory.createRandomVariable(0.0, stream)
+    y = factory.createRandomVariable(0.0, float(stream[0]))
+    with np.errstate(all="ignore"):
+        r = f(x, y)
+        return np.asarray(r.getRealizations(), dtype=np.float64), r.getFiltrationTime()
+
+
+def check_case(name, got, want):
+    want = np.broadcast_to(want, got.shape) if want.shape != got.shape else want
+    assert (np.isnan(got) == np.isnan(want)).all(), f"{name}: NaN-ness differs"
+    ok = np.isfinite(want)
+    assert (got[~ok & ~np.isnan(want)] == want[~ok & ~np.isnan(want)]).all(), f"{name}: infinities differ"
+    err = np.abs(got[ok] - want[ok]) / (1.0 + np.abs(want[ok]))
+    worst = err.max(initial=0.0)
+    assert worst <= tolerance(name), f"{name}: |hip - double| / (1 + |double|) = {worst:.3e} > {tolerance(name):.3e}"
+    return worst / REFERENCE_TOL
+
+
+@pytest.fixture(scope="module")
+def stream(oracle):
+    return oracle.java_random_doubles(31415, 100000)          # RandomVariableGPUTest.java:194-201
+
+
+def test_tolerance_is_attainable_by_an_fp32_class(oracle, stream):
+    """CPU: the reference's own fp32 twin against the double stand-in obeys the stated tolerance on every case — i.e. the
+    tolerance is what fp32 storage costs, not slack for the device (the HIP path equals the twin bit for bit on the
+    non-transcendental cases, tests/test_gpu_reference_tests.py)."""
+    ratios = {}
+    for name, f in sorted(OPERATOR_CASES.items()):
+        got, gt = run_case(f, oracle.RandomVariableFloatFactory(), stream)
+        want, wt = run_case(f, oracle.RandomVariableFromArrayFactory(), stream)
+        assert gt == wt, name
+        ratios[name] = check_case(name, got, want)
+    assert max(ratios.values()) < 1.25          # worst case against the plain 1e-7·(1+|x|): 1.16 (chain, addSumProduct, div)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [False, True], ids=["eager", "fused"])
+@pytest.mark.parametrize("name", sorted(OPERATOR_CASES))
+def test_operators_vs_double_class(gpu, oracle, stream, name, fusion):
+    f = OPERATOR_CASES[name]
+    want, wt = run_case(f, oracle.RandomVariableFromArrayFactory(), stream)
+    prev = gpu.set_fusion(fusion)
+    try:
+        got, gt = run_case(f, gpu.RandomVariableHipFactory(), stream)
+    finally:
+        gpu.set_fusion(prev)
+    assert gt == wt
+    check_case(name, got, want)
+
+
+@pytest.mark.gpu
+def test_every_opcode_vs_double_apply(gpu, oracle):
+    """Every opcode of include/fmhip.h alone, on the configs[1] inputs (x, y, z from the LCG seeds 31415 / 27182 / 16180,
+    SURVEY.md §8d config 2; y, z shifted by +0.5 as divisors / log arguments), against oracle.d_apply on the SAME doubles."""
+    n = 1_000_000
+    xd = oracle.java_random_doubles(31415, n)
+    yd = oracle.java_random_doubles(27182, n) + 0.5
+    zd = oracle.java_random_doubles(16180, n) + 0.5
+    x, y, z = (gpu.DeviceVector.from_host(oracle.f_from_double(v)) for v in (xd, yd, zd))
+    s = 1.0 / 3.0
+    cases = []
+    for op in oracle.V1S0: cases.append((op, x.v1s0(op) if op != "LOG" else y.v1s0(op), (xd if op != "LOG" else yd,), 3 if op in ("INVERT", "SQUARED") else 2))
+    for op in oracle.V1S1: cases.append((op, x.v1s1(op, s), (xd, s), 2 if op not in ("MULT_S", "DIV_S", "VID_S", "POW_S") else 3))
+    for op in oracle.V2S0: cases.append((op, x.v2s0(op, y), (xd, yd), 3))
+    for op in oracle.V2S1: cases.append((op, x.v2s1(op, y, s), (xd, yd, s), 5))
+    for op in oracle.V3S0: cases.append((op, x.v3s0(op, y, z), (xd, yd, zd), 5))
+    for op, dev, args, k in cases:
+        with np.errstate(all="ignore"):
+            want = oracle.d_apply(op, *args)
+        got = dev.to_float32().astype(np.float64)
+        assert (np.isnan(got) == np.isnan(want)).all(), op
+        ok = np.isfinite(want)
+        err = (np.abs(got[ok] - want[ok]) / (1.0 + np.abs(want[ok]))).max()
+        assert err <= max(REFERENCE_TOL, k * HALF_ULP), f"{op}: {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_stream_s_and_reductions_vs_double_class_full_size(gpu, oracle):
+    """BASELINE.json configs[1] at full size: stream S over 1 M paths as ONE fused launch with its fused {Σ, Σ², min, max},
+    against the double class evaluating the same twelve methods on the same double[] inputs."""
+    n = 1_000_000
+    xd = oracle.java_random_doubles(31415, n)
+    yd = oracle.java_random_doubles(27182, n) + 0.5
+    zd = oracle.java_random_doubles(16180, n) + 0.5
+
+    def stream_s(rf):
+        x, y, z = (rf.createRandomVariable(0.0, v) for v in (xd, yd, zd))
+        t = x.add(4.0).div(2.0).mult(y).sub(z)
+        u = t.exp().log().abs().sqrt()
+        v = u.cap(1.5).floor(0.25).addProduct(y, z)
+        return t.choose(v, x)
+
+    wd = stream_s(oracle.RandomVariableFromArrayFactory())
+    prev = gpu.set_fusion(True)
+    try:
+        wg = stream_s(gpu.RandomVariableHipFactory())
+        got = wg.getRealizations()
+        moments = {"avg": wg.getAverage(), "var": wg.getVariance(), "min": wg.getMin(), "max": wg.getMax()}
+    finally:
+        gpu.set_fusion(prev)
+    want = wd.getRealizations()
+    # 14 fp32 roundings on the data path (3 narrowings + 11 rounding methods; choose rounds nothing)
+    err = (np.abs(got - want) / (1.0 + np.abs(want))).max()
+    assert err <= 14 * HALF_ULP, f"stream S: {err:.3e}"
+    # typical error is far below the bound: 99.9 % of the paths meet the reference's plain 1e-7·(1+|x|)
+    assert (np.abs(got - want) <= REFERENCE_TOL * (1.0 + np.abs(want))).mean() >= 0.999
+    ref = {"avg": wd.getAverage(), "var": wd.getVariance(), "min": wd.getMin(), "max": wd.getMax()}
+    for k in ref:                           # reductions: fp64 accumulation of fp32 values vs fp64 of doubles
+        assert abs(moments[k] - ref[k]) <= 14 * HALF_ULP * (1.0 + abs(ref[k])), (k, moments[k], ref[k])
+    # and the reductions alone, on the raw input x: the reference's bound
+    xg = gpu.RandomVariableHipFactory().createRandomVariable(0.0, xd)
+    xr = oracle.RandomVariableFromArrayFactory().createRandomVariable(0.0, xd)
+    for name in ("getAverage", "getVariance", "getMin", "getMax", "getStandardDeviation", "getSampleVariance"):
+        a, b = getattr(xg, name)(), getattr(xr, name)()
+        assert abs(a - b) <= REFERENCE_TOL * (1.0 + abs(b)), (name, a, b)
