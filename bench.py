@@ -17,6 +17,14 @@ cpu_baseline: the oracle (C restatement of the reference's CPU class, one single
 
 Multi-GPU (torchrun, one rank per GPU): independent Monte-Carlo path blocks per rank (weak scaling, no data-path
 collective); the only exchange is ONE small RCCL all-gather of the per-rank expectation partials per step.
+
+The default run carries BOTH halves of BASELINE.json's metric in ONE JSON line: the stream line above (top level,
+contract keys unchanged) and, under "lmm", the LIBOR-Market-Model ATM calibration at 1 M paths per GPU (configs[3]; with
+N ranks configs[4]: N x 1 M paths, one RCCL all-gather of the 144 expectation partials per objective evaluation) — wall
+seconds, LM iterations, evaluations, mean deviation against the reference's 2e-4 acceptance, its own roofline (algorithmic
+bytes of ALL program launches of the real calibration / their summed device time) and its own cpu_baseline.  The
+calibration runs in the native driver bin/lmm_hip (C++ over the C-ABI), started as a child process BEFORE this process
+touches the GPU.  `--workload stream` / `--workload lmm` run one half only.
 """
 import argparse
 import ctypes as C
@@ -64,34 +72,53 @@ def synthetic_inputs(fm, batch, n, rank):
     return rows
 
 
-def cpu_baseline(target_seconds=12.0, all_cores_seconds=6.0):
-    """Stream S on the CPU oracle, one 1M-path triple per pass, repeated for ~target_seconds (the reference's cost model:
-    single-threaded loops).  Additionally, for information, the same loop in one fresh process per host core over
-    independent triples (`all_cores`: what path-sharding over the CPU's cores would give)."""
+def cpu_baseline(target_seconds=8.0, all_cores_seconds=6.0):
+    """Stream S on the CPU oracle, one 1M-path triple per pass (the reference's cost model: single-threaded loops, one fresh
+    array per method), repeated for ~target_seconds per class:
+      * headline: the DOUBLE class the north star names (RandomVariableFromArrayFactory → RandomVariableFromDoubleArray,
+        finmath-lib 5.1.3, not vendored: timed is the stand-in oracle/rv_double.c);
+      * `float_twin`: the reference's in-tree fp32 twin RandomVariableFromFloatArray (oracle/rv_float.c);
+      * `all_cores` (information): the fp32 loop in one fresh process per host core over independent triples."""
     import oracle as o
     n = N_PATHS
-    x = o.f_from_double(o.java_random_doubles(31415, n))
-    y = o.f_from_double(o.java_random_doubles(27182, n) + 0.5)
-    z = o.f_from_double(o.java_random_doubles(16180, n) + 0.5)
+    xd, yd, zd = o.java_random_doubles(31415, n), o.java_random_doubles(27182, n) + 0.5, o.java_random_doubles(16180, n) + 0.5
+    x, y, z = o.f_from_double(xd), o.f_from_double(yd), o.f_from_double(zd)
 
-    def one_pass():
+    def pass_float():
         t = o.f_v2s0("SUB", o.f_v2s0("MULT", o.f_v1s1("DIV_S", o.f_v1s1("ADD_S", x, 4.0), 2.0), y), z)
         u = o.f_v1s0("SQRT", o.f_v1s0("ABS", o.f_v1s0("LOG", o.f_v1s0("EXP", t))))
         v = o.f_v3s0("ADDPRODUCT", o.f_v1s1("FLOOR_S", o.f_v1s1("CAP_S", u, 1.5), 0.25), y, z)
         w = o.f_v3s0("CHOOSE", t, v, x)
         return o.f_average(w), o.f_variance(w), o.f_min(w), o.f_max(w)
 
-    one_pass()
-    passes, t0 = 0, time.perf_counter()
-    while True:
+    def pass_double():
+        d = o.d_apply
+        t = d("SUB", d("MULT", d("DIV_S", d("ADD_S", xd, 4.0), 2.0), yd), zd)
+        u = d("SQRT", d("ABS", d("LOG", d("EXP", t))))
+        v = d("ADDPRODUCT", d("FLOOR_S", d("CAP_S", u, 1.5), 0.25), yd, zd)
+        w = d("CHOOSE", t, v, xd)
+        return o.d_average(w), o.d_variance(w), o.d_min(w), o.d_max(w)
+
+    def timed(one_pass, seconds):
         one_pass()
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt >= target_seconds or passes >= 2000:
-            break
-    result = {"value": N_OPS * n * passes / dt, "unit": "path-ops/s", "cores": 1, "kind": "port",
-              "sample": f"{passes} passes of stream S over one 1M-path (x,y,z) triple, {dt:.1f} s, "
-                        f"C restatement of RandomVariableFromFloatArray (one loop + one fresh array per op)"}
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            one_pass()
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or passes >= 2000:
+                return passes, dt
+
+    pd, td = timed(pass_double, target_seconds)
+    result = {"value": N_OPS * n * pd / td, "unit": "path-ops/s", "cores": 1, "kind": "port",
+              "sample": f"{pd} passes of stream S over one 1M-path (x,y,z) triple in {td:.1f} s on the double-precision stand-in for "
+                        f"RandomVariableFromDoubleArray (oracle/rv_double.c: one loop + one fresh array per method)"}
+    if all_cores_seconds < 0:              # internal: one worker of the all-cores leg times the fp32 loop only
+        pf, tf = timed(pass_float, target_seconds)
+        return {"value": N_OPS * n * pf / tf}
+    pf, tf = timed(pass_float, target_seconds)
+    result["float_twin"] = {"value": N_OPS * n * pf / tf, "unit": "path-ops/s", "cores": 1, "kind": "port",
+                            "sample": f"{pf} passes in {tf:.1f} s on the C restatement of the reference's RandomVariableFromFloatArray"}
     if all_cores_seconds > 0:
         import subprocess
         cores = max(1, min(len(os.sched_getaffinity(0)), 64))
@@ -101,91 +128,110 @@ def cpu_baseline(target_seconds=12.0, all_cores_seconds=6.0):
         for pr in procs:
             out, _ = pr.communicate(timeout=all_cores_seconds * 6 + 60)
             if pr.returncode == 0 and out.strip():
-                w = json.loads(out.strip().splitlines()[-1])
-                total += w["value"]
-        result["all_cores"] = {"value": total, "unit": "path-ops/s", "cores": cores,
-                               "sample": f"{cores} processes x ~{all_cores_seconds:.0f} s of the same single-threaded loop over independent triples"}
+                total += json.loads(out.strip().splitlines()[-1])["value"]
+        result["all_cores"] = {"value": total, "unit": "path-ops/s", "cores": cores, "kind": "port",
+                               "sample": f"{cores} processes x ~{all_cores_seconds:.0f} s of the fp32 twin's loop over independent triples"}
     return result
 
 
-def lmm_workload(args):
-    """BASELINE.json configs[3]: LMM ATM swaption calibration (LIBORMarketModelCalibrationATMTest inputs) at 1 M paths on one
-    MI355X — the native driver host/lmm.hpp over the C-ABI — next to the same driver on the CPU twin (bounded sample:
-    objective evaluations at the same path count; a full CPU calibration would take hours)."""
+LMM_HIP = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
+LMM_CPU = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
+
+
+def lmm_leg(args, world, rank, nonce, cpu_base=True):
+    """BASELINE.json configs[3] / [4]: LMM ATM swaption calibration (LIBORMarketModelCalibrationATMTest.java:186-340 inputs,
+    acceptance :466) at `--paths` paths per GPU in the native driver host/lmm.hpp over the C-ABI.  Runs in child processes
+    (one lmm_hip per rank; LOCAL_RANK picks the device) and must be called BEFORE this process touches the GPU.
+      run 1  the calibration, unprofiled: wall seconds = the metric's second half (cold code-object cache on a fresh box);
+      run 2  the same calibration with every program launch bracketed by HIP events on the runtime stream (--profile):
+             roofline.achieved = algorithmic bytes of all launches (fmhip_traffic_stats) / their summed device time;
+      N = 1 also: profiled replay of objective evaluations one at a time and 8 in lock-step (what a launch shape is worth),
+             and the cpu_baseline: ONE objective evaluation of the same model at the same path count on the CPU twin
+             (oracle/host/lmm_cpu, ~15 s on one core), scaled by the number of evaluations the calibration needed.
+    Returns the dict that goes under "lmm" (rank 0) or None."""
     import subprocess
-    lmm_hip = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
-    lmm_cpu = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
-    if not os.path.exists(lmm_hip):          # build products of csrc/Makefile and oracle/Makefile
+    if not os.path.exists(LMM_HIP):          # build products of csrc/Makefile and oracle/Makefile
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "csrc")], stdout=subprocess.DEVNULL)
-    if not os.path.exists(lmm_cpu):
+    if not os.path.exists(LMM_CPU):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     paths = args.paths                      # per GPU; configs[4] = 1M paths on each of 8 GPUs (path sharding, weak scaling)
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    cmd = [lmm_hip, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)]
-    if world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1":
-        # one native process per GPU (LOCAL_RANK picks the device); they find each other through an RCCL unique-id file
-        idfile = os.path.join("/tmp", f"fmhip_nccl_id_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")   # same launcher parent on every rank
-        cmd += ["--world", str(world), "--rank", str(rank), "--nccl-id-file", idfile]
-    t0 = time.perf_counter()
-    out = subprocess.run(cmd, capture_output=True, text=True)
-    if out.returncode != 0:
-        raise RuntimeError(f"lmm_hip rank {rank} failed: {out.stderr}")
-    wall = time.perf_counter() - t0
-    warm_seconds = None
-    if world == 1:                       # the same calibration again: specialised kernels now come from the code-object cache
-        out2 = subprocess.run(cmd, capture_output=True, text=True)
-        if out2.returncode == 0:
-            warm_seconds = json.loads(out2.stdout.strip().splitlines()[-1])["seconds"]
+    base = [LMM_HIP, "--paths", str(paths), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations)]
+
+    def dist_args(tag):
+        if nonce is None:
+            return []
+        # one native process per GPU; they find each other through an RCCL unique-id file whose name and content carry the
+        # launch's nonce (handed to every rank by the launcher's store), so an id left by another run is never picked up
+        return ["--world", str(world), "--rank", str(rank), "--nccl-id-file", f"/tmp/fmhip_nccl_id_{nonce}_{tag}", "--nccl-nonce", str(nonce)]
+
+    def run(cmd, env=None):
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        if out.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)} (rank {rank}) failed: {out.stderr[-2000:]}")
+        return json.loads(out.stdout.strip().splitlines()[-1]), time.perf_counter() - t0
+
+    r, wall = run(base + dist_args("a"))
+    rp, _ = run(base + ["--profile"] + dist_args("b"))
     if rank != 0:
-        return
-    if "--nccl-id-file" in cmd and os.path.exists(cmd[-1]):
-        os.remove(cmd[-1])
-    r = json.loads(out.stdout.strip().splitlines()[-1])
-    line = {"metric": f"LMM calib wall-time, {world}x1M paths" if world > 1 else "LMM calib wall-time, 1M paths",
-            "value": r["seconds"], "unit": "s", "n_gpus": world, "steps": r["iterations"],
-            "warmup": 0, "ms_per_step": r["seconds"] / max(1, r["iterations"]) * 1e3, "higher_is_better": False, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LIBOR Market Model ATM swaption calibration (80 forward rates, 1 factor, spot measure, normal state space, "
-                                   "144 swaptions, 50 volatility parameters, Levenberg-Marquardt with finite differences)",
-                       "paths": paths * world, "paths_per_gpu": paths, "rccl_all_reduces": r.get("rccl_all_reduces", 0), "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
-                       "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
-                       "rms_deviation": r["rms_deviation"], "mean_deviation": r["mean_deviation"],
-                       "acceptance": "abs(mean deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
-                       "seconds_with_warm_code_object_cache": warm_seconds, "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
-                       "specialisations_pending_at_exit": r.get("specialisations_pending"),
-                       "specialisation_seconds": r.get("specialisation_seconds"),
-                       "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"], "process_wall_s": wall},
-            "roofline": None}
-    # Roofline of the calibration's op stream: a profiled replay of 16 objective evaluations on the steady-state tier (every
-    # program specialised — FMHIP_JIT=sync; an unprofiled evaluation first fills the code-object cache), every program launch
-    # bracketed by HIP events on the runtime stream.  achieved = algorithmic bytes of all launches / their summed device time.
+        return None
+    kernel_s = rp["kernel_ms_total"] / 1e3
+    lmm = {"metric": "LMM calib wall-time, 1M paths" if world == 1 else f"LMM calib wall-time, {world}x1M paths (path-sharded)",
+           "value": r["seconds"], "unit": "s", "higher_is_better": False, "n_gpus": world, "paths_per_gpu": paths, "paths": paths * world,
+           "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
+           "seconds_per_objective_evaluation": r["seconds"] / r["evaluations"],
+           "mean_deviation": r["mean_deviation"], "rms_deviation": r["rms_deviation"], "initial_rms": r["initial_rms"],
+           "acceptance": "abs(mean_deviation) < 2e-4 (LIBORMarketModelCalibrationATMTest.java:466)",
+           "accepted": abs(r["mean_deviation"]) < 2e-4,
+           "workload": "LIBORMarketModelCalibrationATMTest inputs: 80 forward rates, 1 factor, spot measure, normal state space, 144 ATM swaptions, "
+                       "50 volatility parameters, Levenberg-Marquardt with finite differences; native driver over the C-ABI",
+           "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"],
+           "process_wall_s": wall, "seconds_second_run_warm_code_object_cache_profiled": rp["seconds"],
+           "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
+           "rccl": {"calls": r.get("rccl_collectives", 0), "summed_latency_s": r.get("rccl_collective_seconds", 0.0),
+                    "what": "one all-gather of 144 x {sum, sumsq, min, max} fp64 partials per objective evaluation; latency = enqueue to result on the host"},
+           "roofline": {"bound": "hbm", "achieved": rp["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["achieved_GBps"] / HBM_PEAK_GBS,
+                        "traffic": None, "kernel": "all fused-program launches of the calibration itself (rank 0)",
+                        "launches": rp["profiled_launches"], "specialised_launches": rp["specialised_launches"],
+                        "algorithmic_bytes": rp["algorithmic_bytes"], "summed_kernel_s": kernel_s,
+                        "device_busy_fraction_of_wall": kernel_s / rp["seconds"],
+                        "timing": "one HIP event pair per launch on the runtime stream, summed"}}
     if world == 1:
         env = dict(os.environ, FMHIP_JIT="sync")
-        subprocess.run([lmm_hip, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", "8"], capture_output=True, text=True, env=env)
-        pr = subprocess.run([lmm_hip, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "16", "--jacobian-batch", "8", "--profile"],
-                            capture_output=True, text=True, env=env)
-        if pr.returncode == 0:
-            pj = json.loads(pr.stdout.strip().splitlines()[-1])
-            line["roofline"] = {"bound": "hbm", "achieved": pj["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": pj["achieved_GBps"] / HBM_PEAK_GBS, "traffic": None,
-                                "kernel": "all fused-program launches of 16 objective evaluations (80-step simulation + 144 swaption valuations each), "
-                                          "simulated 8 at a time in lock-step as the calibration's Jacobian does",
-                                "launches": pj["profiled_launches"], "specialised_launches": pj["specialised_launches"],
-                                "kernel_ms_per_evaluation": pj["kernel_ms_total"] / 16, "algorithmic_bytes_per_evaluation": pj["algorithmic_bytes"] / 16,
-                                "note": "one evaluation at a time: 702 dependent launches of ~65 MB, launch-granularity-bound at 3.2-3.4 TB/s; 8 in lock-step: the same launches with 8 rows"}
-    if not args.no_cpu_baseline and world == 1:
-        c = subprocess.run([lmm_cpu, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"], capture_output=True, text=True, check=True)
-        cj = json.loads(c.stdout.strip().splitlines()[-1])
-        per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]
-        line["cpu_baseline"] = {"value": per_eval * r["evaluations"], "unit": "s", "cores": 1, "kind": "port",
-                                "sample": f"1 objective evaluation of the same model at {paths} paths on the CPU twin = {per_eval:.2f} s, "
-                                          f"scaled by the {r['evaluations']} evaluations the calibration needed"}
-    print(json.dumps(line), flush=True)
+        for key, batch in (("replay_one_at_a_time", 1), ("replay_8_in_lock_step", 8)):
+            pj, _ = run([LMM_HIP, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", str(batch), "--profile"], env=env)
+            lmm["roofline"][key] = {"achieved": pj["achieved_GBps"], "frac": pj["achieved_GBps"] / HBM_PEAK_GBS, "launches_per_evaluation": pj["profiled_launches"] / 8,
+                                    "kernel_ms_per_evaluation": pj["kernel_ms_total"] / 8}
+        if cpu_base:
+            cj, _ = run([LMM_CPU, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"])
+            per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]
+            lmm["cpu_baseline"] = {"value": per_eval * r["evaluations"], "unit": "s", "cores": 1, "kind": "port",
+                                   "sample": f"1 objective evaluation of the same model at {paths} paths on the CPU twin = {per_eval:.2f} s, "
+                                             f"scaled by the {r['evaluations']} evaluations the calibration needed"}
+    return lmm
+
+
+def rendezvous_nonce(world, rank):
+    """Rendezvous WITHOUT touching the GPU: a TCP store on MASTER_ADDR:MASTER_PORT hands every rank the launch's nonce now and
+    carries the process group of the stream leg later.  Under torchrun the store is hosted by the launcher's agent
+    (TORCHELASTIC_USE_AGENT_STORE) and every rank is a client; launched by hand, rank 0 hosts it."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    hosted_by_agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0 and not hosted_by_agent,
+                          timeout=datetime.timedelta(seconds=900))
+    key = "fmhip_nonce_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if rank == 0:
+        store.set(key, str(int.from_bytes(os.urandom(6), "little")))
+    return store, int(store.get(key).decode())
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["stream", "lmm"], default="stream")
+    ap.add_argument("--workload", choices=["both", "stream", "lmm"], default="both")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg (back-to-back launches); 0 = skip")
     ap.add_argument("--lmm-iterations", type=int, default=12)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -196,14 +242,24 @@ def main():
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)      # internal: one process of the all-cores CPU baseline
     args = ap.parse_args()
     if args.cpu_worker > 0:
-        print(json.dumps(cpu_baseline(args.cpu_worker, 0.0)), flush=True)
+        print(json.dumps(cpu_baseline(args.cpu_worker, -1.0)), flush=True)
         return
-    if args.workload == "lmm":
-        return lmm_workload(args)
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # FMHIP_BENCH_FORCE_DIST=1 exercises the collective paths with a single rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1"
+    store, nonce = rendezvous_nonce(world, rank) if use_dist else (None, None)
+    lmm = None
+    if args.workload in ("both", "lmm"):
+        lmm = lmm_leg(args, world, rank, nonce, cpu_base=not args.no_cpu_baseline)     # child processes; this process has not touched the GPU yet
+    if args.workload == "lmm":
+        if rank == 0:
+            line = dict(lmm)
+            line.update({"steps": lmm["lm_iterations"], "warmup": 0, "ms_per_step": lmm["value"] / max(1, lmm["lm_iterations"]) * 1e3,
+                         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": lmm.pop("workload")}})
+            print(json.dumps(line), flush=True)
+        return
     # stdout carries the ONE JSON line and nothing else: native libraries (RCCL prints a version banner on the first
     # communicator) write to file descriptor 1 directly, so fd 1 is pointed at stderr and the line goes to the saved fd.
     sys.stdout.flush()
@@ -215,12 +271,8 @@ def main():
     import torch                         # before libfmhip: one HIP runtime in the process (see _native.lib)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    # FMHIP_BENCH_FORCE_DIST=1 exercises the collective path with a single rank (rehearsal on a 1-GPU box)
-    use_dist = world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1"
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", store=store, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
     fm.init(local_rank)
@@ -242,6 +294,8 @@ def main():
     computed = [torch.cuda.Event() for _ in range(2)] if use_dist else None
     gathered_ev = [None, None]
     step_no = [0]
+    rccl_events = []                     # (begin, end) on the collective stream, one pair per all-gather of the timed region
+    timing_rccl = [False]
 
     def step():
         # one launch: 12 ops over B triples + fused reductions; moments stay on the device
@@ -254,7 +308,13 @@ def main():
             computed[k].record(ext_stream)
             comm_stream.wait_event(computed[k])
             with torch.cuda.stream(comm_stream):
+                if timing_rccl[0]:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(comm_stream)
                 dist.all_gather_into_tensor(gathers[k], partials[k])
+                if timing_rccl[0]:
+                    e1.record(comm_stream)
+                    rccl_events.append((e0, e1))
                 gathered_ev[k] = torch.cuda.Event()
                 gathered_ev[k].record(comm_stream)
 
@@ -274,6 +334,7 @@ def main():
     # HIP events on the RUNTIME stream (the stream the kernel is launched on) around the timed region: device time of the K
     # back-to-back launches, gaps included — the live figure behind roofline.achieved
     ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timing_rccl[0] = use_dist
     t0 = time.perf_counter()
     ev_begin.record(ext_stream)
     for _ in range(args.steps):
@@ -281,11 +342,23 @@ def main():
     ev_end.record(ext_stream)
     barrier_sync()
     elapsed = time.perf_counter() - t0
+    timing_rccl[0] = False
     region_kernel_s = ev_begin.elapsed_time(ev_end) / 1e3 / args.steps
+    per_gpu_kernel_s = [region_kernel_s]
+    rccl = None
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine = torch.tensor([region_kernel_s], dtype=torch.float64, device=f"cuda:{local_rank}")
+        everyone = torch.zeros(world, dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_gather_into_tensor(everyone, mine)
+        per_gpu_kernel_s = [float(v) for v in everyone.tolist()]
+        lat_ms = [a.elapsed_time(b) for a, b in rccl_events]
+        rccl = {"calls": len(lat_ms), "summed_latency_ms": float(sum(lat_ms)), "max_latency_ms": float(max(lat_ms)) if lat_ms else 0.0,
+                "bytes_per_rank_and_call": B * 32,
+                "what": "one all-gather of the B x {sum, sumsq, min, max} fp64 expectation partials per step, on its own stream, overlapped "
+                        "with the next step's launch; latency = device time of the collective (HIP events on that stream, rank 0)"}
 
     # combined expectations (sanity: finite, and identical on every rank by construction)
     par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
@@ -336,16 +409,42 @@ def main():
     fm.profile_enable(False)
     fast_kernel_s = fast_ms / 1e3 / max(1, fast_n)
 
-    # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes, gfx950
-    # correction applied) — measured offline on this exact workload and committed under profiles/; null for other shapes.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "round01_hbm_traffic.json")) as fh:
-            prof = json.load(fh)
-        if prof["workload"]["paths"] == n and prof["workload"]["batch"] == B:
-            traffic = prof["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # Sustained leg: >= 2 s of back-to-back launches of the headline program, timed in chunks of 50 launches (one HIP event
+    # pair per chunk on the runtime stream): the clock the chip holds under this load settles after ~0.4 s, a 20-step
+    # region does not see that.
+    sustained = None
+    if args.sustained_seconds > 0:
+        chunk = 50
+        n_chunks = max(4, int(args.sustained_seconds / (chunk * avg_kernel_s)))
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunks + 1)]
+        fm.synchronize()
+        evs[0].record(ext_stream)
+        for c in range(n_chunks):
+            for _ in range(chunk):
+                prog.run_into(rows, out_rows, want_moments=False, device_moments=partial.data_ptr())
+            evs[c + 1].record(ext_stream)
+        fm.synchronize()
+        us = [evs[c].elapsed_time(evs[c + 1]) * 1e3 / chunk for c in range(n_chunks)]
+        total_s = sum(us) * chunk / 1e6
+        tail = us[len(us) // 2:]
+        sustained = {"seconds": total_s, "launches": n_chunks * chunk, "avg_kernel_us": sum(us) / len(us), "min_chunk_avg_us": min(us), "max_chunk_avg_us": max(us),
+                     "second_half_avg_us": sum(tail) / len(tail), "frac": alg_bytes / (sum(us) / len(us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "second_half_frac": alg_bytes / (sum(tail) / len(tail) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "timing": f"HIP events on the runtime stream around chunks of {chunk} back-to-back launches"}
+
+    # HBM traffic of the same kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950
+    # correction applied): NOT measured in this run — counters need a profiler pass of their own — but OFFLINE on this exact
+    # workload, committed under profiles/ (newest round first); null for other shapes.
+    traffic, traffic_source = None, None
+    for name in ("round02_hbm_traffic.json", "round01_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                prof = json.load(fh)
+            if prof["workload"]["paths"] == n and prof["workload"]["batch"] == B:
+                traffic, traffic_source = prof["hbm_bytes_per_launch"], f"offline rocprofv3 --pmc passes of this workload: profiles/{name}"
+                break
+        except Exception:
+            continue
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -363,13 +462,16 @@ def main():
                        "parallelism": f"path-shard x{world}" if world > 1 else "single GPU",
                        "device": dev_name, "compute_units": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ("fm_jit_<hash>_t (specialised kernel of stream S, generated + compiled at run time)" if tier == 1
                                     else "fm::fm_program_kernel<1, false, 8, 9, 3, float __vector(9)>"),
                          "tier": "specialised" if tier == 1 else "interpreter", "vgprs": jit_vgprs,
                          "avg_kernel_us": avg_kernel_s * 1e6, "avg_kernel_us_one_event_pair_per_launch": per_launch_kernel_s * 1e6,
                          "timing": "HIP events on the runtime stream around the K timed launches, duration / K (launch gaps included)",
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "per_gpu_frac": [alg_bytes / t / 1e9 / HBM_PEAK_GBS for t in per_gpu_kernel_s]},
+            "sustained": sustained,
+            "rccl": rccl,
             "mean_w": mean_w,
             "interpreter_tier": None if interp_kernel_s is None else {
                 "note": "same program on the bytecode interpreter kernel (tier 0, no compilation)",
@@ -384,6 +486,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+        if lmm is not None:
+            line["lmm"] = lmm
         print(json.dumps(line), file=json_out, flush=True)
 
     del rows, out_rows

@@ -70,11 +70,13 @@ def test_reduce_moments_batch(gpu, oracle):
 
 def test_sharded_driver_path_with_rccl_world_of_one(tmp_path):
     """The path-sharded driver (BASELINE.json configs[4]) with a world of ONE rank: RCCL communicator bootstrap through the
-    id file, device-side batched expectation partials, ncclAllReduce on the runtime stream.  The result must equal the
+    id file (nonce-checked), device-side batched expectation partials, ncclAllGather on the runtime stream.  The result must equal the
     unsharded run; and a 'rank 1 of 2'-style path offset must equal --path-offset (shard invariance of the generator)."""
     plain = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate")
-    dist = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate", "--world", 1, "--rank", 0, "--nccl-id-file", tmp_path / "id")
-    assert dist["rccl_all_reduces"] >= 1 and dist["world"] == 1
+    (tmp_path / "id").write_bytes(b"stale id file of an earlier launch" * 8)          # rank 0 must replace it, not trip over it
+    dist = run(LMM_HIP, "--paths", 4000, "--mode", "evaluate", "--world", 1, "--rank", 0, "--nccl-id-file", tmp_path / "id", "--nccl-nonce", 12345)
+    assert dist["rccl_collectives"] >= 1 and dist["world"] == 1 and dist["rccl_collective_seconds"] > 0
+    assert not (tmp_path / "id").exists()                                              # removed once the communicator exists
     a, b = np.array(plain["model_volatility"]), np.array(dist["model_volatility"])
     assert np.max(np.abs(a - b) / a) <= 1e-12
 
@@ -99,3 +101,39 @@ def test_mersenne_brownian_motion_through_the_factory():
     a, b, c = np.array(cpu["model_volatility"]), np.array(hip["model_volatility"]), np.array(philox["model_volatility"])
     assert np.max(np.abs(a - b) / a) <= 1e-12
     assert np.max(np.abs(b - c) / c) > 1e-6 and np.max(np.abs(b - c) / c) < 0.2       # another stream of random numbers, same model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] at FULL size: 1 M paths on one MI355X (80 x 80 x 4 MB of LIBOR state per parameter set).
+
+
+def test_full_size_objective_evaluation_equals_its_two_path_shards_and_the_cpu_twin():
+    """1 M-path objective evaluation (80-step simulation + 144 Monte-Carlo valuations).
+    (i) size-independent property: every expectation is linear in the paths, and the counter-based generator makes the
+        paths [0, 500k) and [500k, 1M) of the big run identical to two shard runs (--path-offset) — so each of the 144 model
+        volatilities (= expectation x a constant) must equal the mean of the two shard results to fp64 summation order;
+    (ii) the same evaluation on the CPU twin (oracle/host/lmm_cpu, ≈ 15 s on one core): every op of the model is bit-exact
+        fp32 arithmetic, only the fp64 summation order of getAverage differs."""
+    full = run(LMM_HIP, "--paths", 1000000, "--mode", "evaluate")
+    lo = run(LMM_HIP, "--paths", 500000, "--mode", "evaluate")
+    hi = run(LMM_HIP, "--paths", 500000, "--mode", "evaluate", "--path-offset", 500000)
+    a = np.array(full["model_volatility"])
+    b = 0.5 * (np.array(lo["model_volatility"]) + np.array(hi["model_volatility"]))
+    assert a.shape == (144,) and np.all(a > 0)
+    assert np.max(np.abs(a - b) / a) <= 1e-12
+    assert np.max(np.abs(np.array(lo["model_volatility"]) - np.array(hi["model_volatility"])) / a) > 1e-6      # the shards ARE different paths
+    cpu = run(LMM_CPU, "--paths", 1000000, "--mode", "evaluate")
+    c = np.array(cpu["model_volatility"])
+    assert np.max(np.abs(a - c) / c) <= 1e-12
+
+
+def test_full_size_calibration_meets_the_reference_acceptance():
+    """LIBORMarketModelCalibrationATMTest at 1 M paths (the reference runs 10 000 on the CPU): Levenberg-Marquardt over 50
+    volatility parameters, every objective evaluation a fresh 1 M-path simulation; acceptance as the reference asserts it,
+    `Math.abs(averageDeviation) < 2E-4` (LIBORMarketModelCalibrationATMTest.java:466)."""
+    r = run(LMM_HIP, "--paths", 1000000, "--mode", "calibrate", "--max-iterations", 12)
+    assert r["paths"] == 1000000 and r["swaptions"] == 144 and r["active_parameters"] == 50
+    assert abs(r["mean_deviation"]) < 2e-4
+    assert r["rms_deviation"] < 0.05 * r["initial_rms"]                 # the fit, not just the mean, has converged
+    assert r["evaluations"] >= 50 * r["iterations"]                      # finite-difference Jacobian: one re-simulation per parameter
+    assert r["seconds"] < 60.0                                           # the CPU twin needs ≈ 15 s per EVALUATION at this size

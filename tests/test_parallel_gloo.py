@@ -66,3 +66,34 @@ def test_path_shard_covers_everything_once(fm):
             assert all(o % 4 == 0 for o, c in blocks if c > 0)
             sizes = [c for _, c in blocks]
             assert max(sizes) - min(sizes) <= 7 or n < 4 * world        # one group of 4 plus the ragged end
+
+
+_RDV_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import bench
+import torch, torch.distributed as dist
+world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+store, nonce = bench.rendezvous_nonce(world, rank)          # no GPU touched: TCP store (hosted by torchrun's agent here)
+dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world)       # the same store carries the process group
+mine = torch.tensor([float(nonce)], dtype=torch.float64)
+got = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(got, mine)
+assert all(float(v) == float(nonce) for v in got) and nonce > 0
+if rank == 0: print("nonce agreed on", world, "ranks")
+dist.destroy_process_group()
+'''
+
+
+def test_bench_rendezvous_hands_every_rank_the_same_nonce(tmp_path):
+    """bench.py --gpus N (as the driver launches it: torchrun, one rank per GPU) gives the native LMM driver of every rank
+    the same fresh nonce for its RCCL bootstrap file before any rank touches the GPU, and reuses the store for the process
+    group of the stream leg.  Two CPU ranks under torchrun, gloo."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rdv.py"
+    script.write_text(_RDV_SCRIPT % {"root": root})
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "nonce agreed on 2 ranks" in r.stdout
