@@ -29,6 +29,7 @@ def child():
     outs = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
     sys.path.insert(0, ROOT)
     import bench
+    if os.environ.get("KNOB_FAST"): fm.set_math_mode(fm.MATH_FAST)
     drop = set(filter(None, os.environ.get("KNOB_DROP", "").split("+")))      # e.g. LOG+SQRT: those methods become abs()
     if os.environ.get("KNOB_NO_REDUCE") or drop:    # variants of the stream: without the fused reductions / without some methods
         p = fm.Program(3)
@@ -54,7 +55,18 @@ def child():
     for _ in range(4):
         fm.profile_enable(True); run(100); ms, k = fm.profile_read(); fm.profile_enable(False)
         vals.append(ms / k * 1e3)
-    print(json.dumps({"tier": p.tier(), "us": [round(v, 1) for v in vals], "moments": partial[:4].tolist()}), flush=True)
+    # sustained: ~1.5 s of back-to-back launches, HIP events on the runtime stream around chunks of 50 (as bench.py's sustained leg)
+    ext = torch.cuda.ExternalStream(fm.stream_ptr(), device=torch.device("cuda", 0))
+    chunks = int(1.5 / (50 * vals[-1] * 1e-6))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(chunks + 1)]
+    evs[0].record(ext)
+    for c in range(chunks):
+        run(50); evs[c + 1].record(ext)
+    fm.synchronize()
+    us = [evs[c].elapsed_time(evs[c + 1]) * 20.0 for c in range(chunks)]
+    tail = us[len(us) // 2:]
+    print(json.dumps({"tier": p.tier(), "us": [round(v, 1) for v in vals], "sustained_us": round(sum(us) / len(us), 1), "sustained_second_half_us": round(sum(tail) / len(tail), 1),
+                      "moments": partial[:4].tolist()}), flush=True)
 
 
 def main():
@@ -71,9 +83,10 @@ def main():
         if len(rest) > 1 and "noreduce" in rest[1:]: env["KNOB_NO_REDUCE"] = "1"
         for r in rest[1:]:
             if r.startswith("drop="): env["KNOB_DROP"] = r[5:]
+            if r == "fast": env["KNOB_FAST"] = "1"
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        rec = {"elems": int(e), "group": int(g), "waves": int(w), "prefetch": int(pf), "elems_per_block": int(rest[0]) if rest else 8192, "reduce": not (len(rest) > 1 and "noreduce" in rest[1:]), "drop": [r[5:] for r in rest[1:] if r.startswith("drop=")]}
+        rec = {"elems": int(e), "group": int(g), "waves": int(w), "prefetch": int(pf), "elems_per_block": int(rest[0]) if rest else 8192, "reduce": not (len(rest) > 1 and "noreduce" in rest[1:]), "drop": [r[5:] for r in rest[1:] if r.startswith("drop=")], "fast": "fast" in rest[1:]}
         if line: rec.update(json.loads(line[-1]))
         else: rec["error"] = (r.stderr or r.stdout)[-400:]
         print(json.dumps(rec), flush=True)

@@ -13,9 +13,15 @@ __global__ void __launch_bounds__(256) triad(const f32x4* const* __restrict__ ta
   const int64_t i = (int64_t)blockIdx.x*256+threadIdx.x;
   if (i < n4) { const f32x4 r = __builtin_nontemporal_load(a+i) + __builtin_nontemporal_load(b+i) + __builtin_nontemporal_load(c+i); __builtin_nontemporal_store(r, o+i); }
 }
-int main(){
+__global__ void fill_random(float* p, int64_t n, uint32_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x*256+threadIdx.x; i < n; i += (int64_t)gridDim.x*256) { uint32_t v = (uint32_t)i*2654435761u ^ seed; v ^= v >> 15; v *= 0x2c1b3c6du; v ^= v >> 12; p[i] = 0.5f + (float)(v >> 8) * (1.0f/16777216.0f); }
+}
+int main(int argc, char** argv){
+  const bool random_data = argc > 1 && argv[1][0] == 'r';        // "r": random operands instead of zeros (data-dependent power / clocks)
+  printf("%s operands\n", random_data ? "random" : "zero");
   const int B=64; const int64_t n=1000000, n4=n/4; std::vector<float*> h(B*4);
-  for(int i=0;i<B*4;i++){ CK(hipMalloc(&h[i], n*4+1024)); CK(hipMemset(h[i], 0, n*4)); }
+  for(int i=0;i<B*4;i++){ CK(hipMalloc(&h[i], n*4+1024)); CK(hipMemset(h[i], 0, n*4)); if (random_data) fill_random<<<1024,256>>>(h[i], n, (uint32_t)i*7919u); }
+  CK(hipDeviceSynchronize());
   float** dtab; CK(hipMalloc(&dtab, B*4*8)); CK(hipMemcpy(dtab, h.data(), B*4*8, hipMemcpyHostToDevice));
   const double bytes = 16.0*n*B; const f32x4* const* t = (const f32x4* const*)dtab;
   const int blocks = 60, per = 200;

@@ -7,7 +7,7 @@
 //                       RandomVariableCuda.java:483-557 + the 27 kernels of RandomVariableCudaKernel.cu),
 //                       optionally ending in fused {Σ, Σ², min, max} reductions (replaces the
 //                       D2H-and-host-loop reductions, RandomVariableCuda.java:830-901).
-//   fm_bm_kernel        counter-based Philox4x32-10 + Box–Muller normal increments (replaces
+//   fm_bm_kernel        counter-based Philox4x32-10 + LDS-table-driven inverse-normal-CDF increments (replaces
 //                       curandGenerateNormal, BrownianMotionCudaWithRandomVariableCuda.java:168-178).
 //   fm_fill_kernel      constant fill.
 //
@@ -22,6 +22,7 @@
 #include "fm_program.h"
 #include "fm_device_math.hpp"
 #include "fm_kernel_parts.hpp"
+#include "fm_normal_table.hpp"
 #include "kernels.h"
 
 namespace fm {
@@ -44,6 +45,8 @@ typedef float f32x9 __attribute__((ext_vector_type(9)));   // > 8 elements: dyna
             __builtin_amdgcn_sched_barrier(0);                                                          \
         }                                                                                               \
         break;
+// sqrt: all E elements share one special-case branch (fm_device_math.hpp: sqrt_all)
+#define FM_USQRT case U_SQRT: sqrt_all<E>(a); break;
 #define FM_U1(CODE) case CODE: {                                                                        \
         float p[E];                                                                                     \
         _Pragma("unroll") for (int j = 0; j < E; ++j) p[j] = R[j][r1];                                  \
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             const uint32_t r1 = (w >> 8) & 15u, r2 = (w >> 12) & 15u, st = (w >> 16) & 15u;
             switch (code) {
                 FM_U1(U_LDA)
-                FM_U0(U_SQUARED) FM_U0(U_SQRT) FM_U0H(U_EXP) FM_U0H(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
+                FM_U0(U_SQUARED) FM_USQRT FM_U0H(U_EXP) FM_U0H(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
                 FM_U0(U_ISNAN) FM_U0(U_EXP_FAST) FM_U0(U_LOG_FAST)
                 FM_U0(U_CAP_S) FM_U0(U_FLOOR_S) FM_U0(U_ADD_S) FM_U0(U_SUB_S) FM_U0(U_BUS_S) FM_U0(U_MULT_S)
                 FM_U0(U_DIV_S) FM_U0(U_VID_S)
@@ -209,8 +212,15 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 + Box–Muller normal increments.  Normative definition: oracle/philox_normal.c —
-// the operation order below must not be changed without changing that file (bit-for-bit parity).
+// Philox4x32-10 + inverse-normal-CDF increments.  Normative definition: oracle/philox_normal.c — the operation order
+// below must not be changed without changing that file (bit-for-bit parity).
+//
+// Write-only: 4 B per normal, nothing read.  The budget of a byte mover at the 6.2–6.4 TB/s streaming ceiling is ≈ 0.65 ns
+// per normal and SIMD; measured without memory traffic (benchmarks/valu_cost.hip): Philox4x32-10 alone 0.32 ns (10 rounds of
+// two v_mad_u64_u32), round 1's IEEE-only Box–Muller on top 1.17 ns in all (2.3–2.8 TB/s written, VALU-bound).  The
+// transform is therefore an LDS-table-driven inverse CDF by hierarchical segmentation: leading-zero count (the octave of the
+// tail) and three mantissa bits pick one of 256 cubics — one v_ffbh_u32, four integer instructions, one int→float conversion,
+// one ds_read_b128, three FMAs, one v_bfi for the sign: ≈ 12 VALU instructions per normal instead of ≈ 45.
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -230,97 +240,78 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ float spec_logf(float u)
+// One standard normal from one 32-bit word; `table` = the 256 x {c0, c1, c2, c3} cubics in LDS (fm_normal_table.hpp).
+__device__ __forceinline__ float spec_normal(uint32_t w, const f32x4* table)
 {
-    const uint32_t b = __float_as_uint(u);
-    int e = (int)(b >> 23) - 127;
-    float f = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);
-    if (f > 1.41421354f) { f = f * 0.5f; e += 1; }
-    const float s = (f - 1.0f) / (f + 1.0f);
-    const float z = s * s;
-    float p = 0.222222224f;
-    p = __builtin_fmaf(p, z, 0.285714298f);
-    p = __builtin_fmaf(p, z, 0.400000006f);
-    p = __builtin_fmaf(p, z, 0.666666687f);
-    p = p * z;
-    const float lnf = __builtin_fmaf(s, p, s + s);
-    const float ef = (float)e;
-    return __builtin_fmaf(ef, 0.693145751953125f, __builtin_fmaf(ef, 1.42860677e-06f, lnf));
+    const uint32_t k = (w << 1) | 1u;                               // odd: p = k·2^-33 in (0, 1/2)
+    const uint32_t lz = (uint32_t)__builtin_clz(k);                 // k != 0: plain v_ffbh_u32
+    const uint32_t norm = k << lz;
+    const uint32_t idx = (norm >> 28) & 7u;
+    const float tf = (float)(norm & 0x0FFFFFFFu);                   // v_cvt_f32_u32: round to nearest even, like the oracle's cast
+    const f32x4 c = table[lz * 8u + idx];                           // one ds_read_b128
+    float m = __builtin_fmaf(c.w, tf, c.z);
+    m = __builtin_fmaf(m, tf, c.y);
+    m = __builtin_fmaf(m, tf, c.x);
+    return __uint_as_float((__float_as_uint(m) & 0x7FFFFFFFu) | (w & 0x80000000u));    // copysign(|z|, bit 31): one v_bfi_b32
 }
 
-__device__ __forceinline__ void spec_box_muller(uint32_t ra, uint32_t rb, float& za, float& zb)
-{
-    const float u1 = __builtin_fmaf((float)ra, 0x1p-32f, 0x1p-33f);
-    const float radius = __builtin_sqrtf(-2.0f * spec_logf(u1));
-    const float t = (float)(rb >> 8) * 0x1p-22f;
-    const int q = (int)t;
-    const float fr = t - (float)q;
-    const bool swap = fr > 0.5f;
-    const float g = swap ? 1.0f - fr : fr;
-    const float x = g * 1.57079637f;
-    const float x2 = x * x;
-    float ps = 2.75573188e-06f;
-    ps = __builtin_fmaf(ps, x2, -1.98412701e-04f);
-    ps = __builtin_fmaf(ps, x2, 8.33333377e-03f);
-    ps = __builtin_fmaf(ps, x2, -1.66666672e-01f);
-    ps = ps * x2;
-    const float sinx = __builtin_fmaf(x, ps, x);
-    float pc = -2.75573192e-07f;
-    pc = __builtin_fmaf(pc, x2, 2.48015876e-05f);
-    pc = __builtin_fmaf(pc, x2, -1.38888892e-03f);
-    pc = __builtin_fmaf(pc, x2, 4.16666679e-02f);
-    pc = __builtin_fmaf(pc, x2, -0.5f);
-    const float cosx = __builtin_fmaf(pc, x2, 1.0f);
-    const float sp = swap ? cosx : sinx;
-    const float cp = swap ? sinx : cosx;
-    float c, s;
-    switch (q & 3) {
-    case 0:  c =  cp; s =  sp; break;
-    case 1:  c = -sp; s =  cp; break;
-    case 2:  c = -cp; s = -sp; break;
-    default: c =  sp; s = -cp; break;
-    }
-    za = radius * c;
-    zb = radius * s;
-}
-
-__device__ __forceinline__ void normal4(uint32_t k0, uint32_t k1, uint64_t pb, uint32_t stream, float z[4])
+__device__ __forceinline__ void normal4(uint32_t k0, uint32_t k1, uint64_t pb, uint32_t stream, const f32x4* table, float z[4])
 {
     uint32_t r[4];
     philox4x32_10((uint32_t)pb, (uint32_t)(pb >> 32), stream, 0x464D4850u, k0, k1, r);
-    spec_box_muller(r[0], r[1], z[0], z[1]);
-    spec_box_muller(r[2], r[3], z[2], z[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) z[j] = spec_normal(r[j], table);
 }
 
-// grid = (tiles of 256 float4, n_streams).  Vector `stream` lives at slab + stream * stride_floats.
-__global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A)
+// grid = (path tiles of FM_BM_TILE float4, groups of FM_BM_STREAMS streams).  Vector `stream` lives at slab + stream * stride_floats.
+// A workgroup copies the 4 KB table into LDS once and then writes FM_BM_STREAMS x FM_BM_TILE float4 = 64 KB of increments.
+constexpr int FM_BM_PASSES = 2;                                     // float4 per lane and stream
+constexpr int FM_BM_TILE = FM_BLOCK * FM_BM_PASSES;                 // float4 per workgroup and stream (2048 paths)
+constexpr int FM_BM_STREAMS = 8;                                    // streams (step x factor vectors) per workgroup
+static_assert(FM_NORMAL_TABLE_ENTRIES == FM_BLOCK, "one table entry per thread in the LDS copy");
+
+__global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A, const uint32_t n_streams)
 {
-    const uint32_t stream = blockIdx.y;
-    const float sq = A.sqrt_dt[stream / A.n_factors];
-    float4* __restrict__ out = reinterpret_cast<float4*>(A.slab + (size_t)stream * A.stride_floats);
+    __shared__ f32x4 table[FM_NORMAL_TABLE_ENTRIES];
+    table[threadIdx.x] = reinterpret_cast<const f32x4*>(FM_NORMAL_TABLE)[threadIdx.x];
+    __syncthreads();
     const int64_t n4 = (A.n_paths + 3) >> 2;
-    const uint32_t gstream = A.stream0 + stream;
-    for (int64_t i4 = (int64_t)blockIdx.x * FM_BLOCK + threadIdx.x; i4 < n4; i4 += (int64_t)gridDim.x * FM_BLOCK) {
-        const uint64_t g0 = (uint64_t)(A.path_offset + i4 * 4);    // global index of this lane's first path
-        float z[4];
-        if ((g0 & 3u) == 0) {
-            normal4(A.key0, A.key1, g0 >> 2, gstream, z);
-        } else {                                                   // shard offset not a multiple of 4: two blocks
-            float za[4], zb[4];
-            normal4(A.key0, A.key1, g0 >> 2, gstream, za);
-            normal4(A.key0, A.key1, (g0 >> 2) + 1, gstream, zb);
-            const uint32_t sft = (uint32_t)(g0 & 3u);
+    const uint32_t s_begin = blockIdx.y * FM_BM_STREAMS;
+    const uint32_t s_end = s_begin + FM_BM_STREAMS < n_streams ? s_begin + FM_BM_STREAMS : n_streams;
+    int64_t i4[FM_BM_PASSES];
+    uint64_t g0[FM_BM_PASSES];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t idx = sft + j;
-                float v = 0.0f;
+    for (int t = 0; t < FM_BM_PASSES; ++t) {
+        i4[t] = (int64_t)blockIdx.x * FM_BM_TILE + t * FM_BLOCK + threadIdx.x;
+        g0[t] = (uint64_t)(A.path_offset + i4[t] * 4);             // global index of this lane's first path
+    }
+    const bool aligned = (A.path_offset & 3) == 0;                  // wave-uniform
+    for (uint32_t stream = s_begin; stream < s_end; ++stream) {
+        const float sq = A.sqrt_dt[stream / A.n_factors];
+        f32x4* __restrict__ out = reinterpret_cast<f32x4*>(A.slab + (size_t)stream * A.stride_floats);
+        const uint32_t gstream = A.stream0 + stream;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) { if (idx == (uint32_t)m) v = za[m]; if (idx == (uint32_t)(m + 4)) v = zb[m]; }
-                z[j] = v;
+        for (int t = 0; t < FM_BM_PASSES; ++t) {
+            float z[4];
+            if (aligned) {
+                normal4(A.key0, A.key1, g0[t] >> 2, gstream, table, z);
+            } else {                                               // shard offset not a multiple of 4: two blocks
+                float za[4], zb[4];
+                normal4(A.key0, A.key1, g0[t] >> 2, gstream, table, za);
+                normal4(A.key0, A.key1, (g0[t] >> 2) + 1, gstream, table, zb);
+                const uint32_t sft = (uint32_t)(g0[t] & 3u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t idx = sft + j;
+                    float v = 0.0f;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { if (idx == (uint32_t)m) v = za[m]; if (idx == (uint32_t)(m + 4)) v = zb[m]; }
+                    z[j] = v;
+                }
             }
+            // written once, read by a later launch long after it has left the caches (4 GB at config 3): streaming store
+            if (i4[t] < n4) __builtin_nontemporal_store(f32x4{ sq * z[0], sq * z[1], sq * z[2], sq * z[3] }, out + i4[t]);
         }
-        // written once, read by a later launch long after it has left the caches (4 GB at config 3): streaming store
-        __builtin_nontemporal_store(f32x4{ sq * z[0], sq * z[1], sq * z[2], sq * z[3] }, reinterpret_cast<f32x4*>(out) + i4);
     }
 }
 
@@ -367,10 +358,10 @@ hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double*
 hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st)
 {
     const int64_t n4 = (a.n_paths + 3) >> 2;
-    int64_t bx = (n4 + FM_BLOCK - 1) / FM_BLOCK;
-    if (bx > 4096) bx = 4096;
+    int64_t bx = (n4 + FM_BM_TILE - 1) / FM_BM_TILE;                // n_paths <= 2^31: at most 2^20 tiles
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(fm_bm_kernel, dim3((uint32_t)bx, n_streams, 1), dim3(FM_BLOCK), 0, st, a);
+    const uint32_t by = (n_streams + FM_BM_STREAMS - 1) / FM_BM_STREAMS;
+    hipLaunchKernelGGL(fm_bm_kernel, dim3((uint32_t)bx, by, 1), dim3(FM_BLOCK), 0, st, a, n_streams);
     return hipGetLastError();
 }
 

@@ -31,7 +31,7 @@ _LIB_PATH = os.path.join(_HERE, "libfm_oracle.so")
 
 def build(force: bool = False) -> str:
     """Compile the C restatement (gcc, seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("rv_float.c", "rv_double.c", "java_random.c", "philox_normal.c", "fm_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("rv_float.c", "rv_double.c", "java_random.c", "philox_normal.c", "fm_oracle.h", "normal_table.h")]
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if stale:

@@ -12,18 +12,23 @@
  *   ctr  = { lo32(pb), hi32(pb), stream, 0x464D4850 }        pb = global path index / 4,
  *                                                            stream = step * n_factors + factor
  *   r[0..3] = Philox4x32-10(ctr, key)                        (Salmon et al., SC'11; Random123)
- *   (z0,z1) = BoxMuller(r0, r1),  (z2,z3) = BoxMuller(r2, r3)   → paths 4pb … 4pb+3
+ *   z[i]    = Normal(r[i])                                   → paths 4pb … 4pb+3
  *
- * BoxMuller uses only IEEE-754 correctly rounded fp32 operations (+, *, /, sqrt, fma) in a fixed order,
- * so CPU and GPU produce identical bits:
- *   u1 = fma((float)ra, 2^-32, 2^-33)            in (0, 1]
- *   t  = (float)(rb >> 8) * 2^-22                 = 4*u2 in [0, 4), exact
- *   radius = sqrt(-2 ln u1)   with ln from an atanh series on the reduced mantissa
- *   (cos, sin)(2π u2)         by quadrant + octant reflection and Taylor polynomials on [0, π/4]
+ * Normal(w) — round 2 re-specification for CDNA4 (round 1: Box–Muller restricted to IEEE-correct fp32 operations, ≈ 72
+ * VALU instructions per normal, 2.3–2.8 TB/s written; the write stream can take ≈ 25): inverse normal CDF by HIERARCHICAL
+ * SEGMENTATION (Lee, Luk, Villasenor, Cheung 2006): one 32-bit word → one normal,
+ *   sign = bit 31;  k = (w << 1) | 1  (odd);  p = k·2^-33 in (0, 1/2)           never 0 or 1/2
+ *   lz = clz(k): the octave of the tail;  norm = k << lz;  idx = bits 28..30 of norm;  tf = (float)(norm & 0x0FFFFFFF)
+ *   |z| = fma(fma(fma(c3, tf, c2), tf, c1), tf, c0),  {c0..c3} = TABLE[lz·8 + idx]   (normal_table.h, tools/normal_table.py:
+ *          cubic per segment fitted to -Φ^-1(p); max abs error 5.4e-7 ≈ one fp32 rounding at |z| ≈ 4…6)
+ *   z = copysign(|z|, sign)
+ * Integer operations, one exact int→float conversion with rounding to nearest, three fp32 FMAs: CPU and GPU produce
+ * identical bits.  |z| <= 6.36 (p >= 2^-33).
  *
  * Philox4x32-10 is pinned by the Random123 known-answer vectors (tests/test_oracle_known_answers.py).
  */
 #include "fm_oracle.h"
+#include "normal_table.h"
 #include <math.h>
 #include <string.h>
 
@@ -52,57 +57,18 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 static inline float bits_to_float(uint32_t b) { float f; memcpy(&f, &b, 4); return f; }
 static inline uint32_t float_to_bits(float f) { uint32_t b; memcpy(&b, &f, 4); return b; }
 
-/* ln(u) for u in (0,1], fp32, fixed operation order. */
-static float spec_logf(float u) {
-    uint32_t b = float_to_bits(u);
-    int e = (int)(b >> 23) - 127;                                  /* u is normal: u >= 2^-33 */
-    float f = bits_to_float((b & 0x007FFFFFu) | 0x3F800000u);      /* [1,2) */
-    if (f > 1.41421354f) { f = f * 0.5f; e += 1; }                 /* (0.7071, 1.4142] */
-    const float s = (f - 1.0f) / (f + 1.0f);
-    const float z = s * s;
-    float p = 0.222222224f;                                        /* 2/9 */
-    p = fmaf(p, z, 0.285714298f);                                  /* 2/7 */
-    p = fmaf(p, z, 0.400000006f);                                  /* 2/5 */
-    p = fmaf(p, z, 0.666666687f);                                  /* 2/3 */
-    p = p * z;
-    const float lnf = fmaf(s, p, s + s);
-    const float ef = (float)e;
-    return fmaf(ef, 0.693145751953125f, fmaf(ef, 1.42860677e-06f, lnf));
-}
-
-static void spec_box_muller(uint32_t ra, uint32_t rb, float* za, float* zb) {
-    const float u1 = fmaf((float)ra, 0x1p-32f, 0x1p-33f);
-    const float radius = sqrtf(-2.0f * spec_logf(u1));
-    const float t = (float)(rb >> 8) * 0x1p-22f;
-    const int q = (int)t;
-    const float fr = t - (float)q;
-    const int swap = fr > 0.5f;
-    const float g = swap ? 1.0f - fr : fr;
-    const float x = g * 1.57079637f;                               /* π/2 */
-    const float x2 = x * x;
-    float ps = 2.75573188e-06f;                                    /*  1/9!  */
-    ps = fmaf(ps, x2, -1.98412701e-04f);                           /* -1/7!  */
-    ps = fmaf(ps, x2, 8.33333377e-03f);                            /*  1/5!  */
-    ps = fmaf(ps, x2, -1.66666672e-01f);                           /* -1/3!  */
-    ps = ps * x2;
-    const float sinx = fmaf(x, ps, x);
-    float pc = -2.75573192e-07f;                                   /* -1/10! */
-    pc = fmaf(pc, x2, 2.48015876e-05f);                            /*  1/8!  */
-    pc = fmaf(pc, x2, -1.38888892e-03f);                           /* -1/6!  */
-    pc = fmaf(pc, x2, 4.16666679e-02f);                            /*  1/4!  */
-    pc = fmaf(pc, x2, -0.5f);
-    const float cosx = fmaf(pc, x2, 1.0f);
-    const float sp = swap ? cosx : sinx;                           /* sin, cos of fr*π/2 */
-    const float cp = swap ? sinx : cosx;
-    float c, s;
-    switch (q & 3) {
-    case 0:  c =  cp; s =  sp; break;
-    case 1:  c = -sp; s =  cp; break;
-    case 2:  c = -cp; s = -sp; break;
-    default: c =  sp; s = -cp; break;
-    }
-    *za = radius * c;
-    *zb = radius * s;
+/* One standard normal from one 32-bit word (see the header). */
+static float spec_normal(uint32_t w) {
+    const uint32_t k = (w << 1) | 1u;
+    const int lz = __builtin_clz(k);                               /* k is odd: never 0 */
+    const uint32_t norm = k << lz;
+    const uint32_t idx = (norm >> 28) & 7u;
+    const float tf = (float)(norm & 0x0FFFFFFFu);                  /* round to nearest even (default mode) */
+    const float* c = ORC_NORMAL_TABLE + ((uint32_t)lz * 8u + idx) * 4u;
+    float m = fmaf(c[3], tf, c[2]);
+    m = fmaf(m, tf, c[1]);
+    m = fmaf(m, tf, c[0]);
+    return bits_to_float((float_to_bits(m) & 0x7FFFFFFFu) | (w & 0x80000000u));
 }
 
 void orc_normal4(int64_t seed, uint64_t pb, uint32_t stream, float z[4]) {
@@ -110,8 +76,7 @@ void orc_normal4(int64_t seed, uint64_t pb, uint32_t stream, float z[4]) {
     const uint32_t ctr[4] = { (uint32_t)pb, (uint32_t)(pb >> 32), stream, FMHIP_RNG_DOMAIN };
     uint32_t r[4];
     orc_philox4x32_10(ctr, key, r);
-    spec_box_muller(r[0], r[1], &z[0], &z[1]);
-    spec_box_muller(r[2], r[3], &z[2], &z[3]);
+    for (int i = 0; i < 4; i++) z[i] = spec_normal(r[i]);
 }
 
 void orc_bm_increment(int64_t seed, uint32_t stream, int64_t path_offset, int64_t n, float sqrt_dt, float* out) {
