@@ -8,7 +8,7 @@ namespace fm {
 
 struct DevBmArgs {
     float*       slab;           // n_streams vectors, `stride_floats` apart (stride is a multiple of 64 floats)
-    const float* sqrt_dt;        // [n_steps]  (float)sqrt(dt[step])
+    const float* sqrt_dt;        // [n_streams]  (float)sqrt(dt[step of the stream]), one entry per local stream
     int64_t      stride_floats;
     int64_t      n_paths;        // paths held by this process
     int64_t      path_offset;    // global index of local path 0 (path sharding over GPUs)

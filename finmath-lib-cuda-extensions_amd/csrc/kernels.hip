@@ -223,6 +223,9 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 // one ds_read_b128, three FMAs, one v_bfi for the sign: ≈ 12 VALU instructions per normal instead of ≈ 45.
 // ---------------------------------------------------------------------------------------------
 
+// gfx950: any three-input boolean function is ONE instruction (v_bitop3_b32); 0x96 = a ^ b ^ c
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)c, 0x96); }
+
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                uint32_t k0, uint32_t k1, uint32_t out[4])
 {
@@ -233,26 +236,33 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        const uint32_t n0 = xor3(hi1, c1, k0), n2 = xor3(hi0, c3, k1);
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// One fp32 FMA that the SLP vectoriser cannot pair up (it packed the cubics of two normals into v_pk_fma_f32 at the price of
+// five v_mov per pair — more instructions than the three plain FMAs it replaced).
+__device__ __forceinline__ float fma1(float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
 // One standard normal from one 32-bit word; `table` = the 256 x {c0, c1, c2, c3} cubics in LDS (fm_normal_table.hpp).
+// 12 VALU instructions + one ds_read_b128.
 __device__ __forceinline__ float spec_normal(uint32_t w, const f32x4* table)
 {
-    const uint32_t k = (w << 1) | 1u;                               // odd: p = k·2^-33 in (0, 1/2)
-    const uint32_t lz = (uint32_t)__builtin_clz(k);                 // k != 0: plain v_ffbh_u32
+    const uint32_t k = (w << 1) | 1u;                               // odd: p = k·2^-33 in (0, 1/2)            v_lshl_or_b32
+    const uint32_t lz = (uint32_t)__builtin_clz(k);                 // k != 0                                   v_ffbh_u32
     const uint32_t norm = k << lz;
     const uint32_t idx = (norm >> 28) & 7u;
     const float tf = (float)(norm & 0x0FFFFFFFu);                   // v_cvt_f32_u32: round to nearest even, like the oracle's cast
     const f32x4 c = table[lz * 8u + idx];                           // one ds_read_b128
-    float m = __builtin_fmaf(c.w, tf, c.z);
-    m = __builtin_fmaf(m, tf, c.y);
-    m = __builtin_fmaf(m, tf, c.x);
-    return __uint_as_float((__float_as_uint(m) & 0x7FFFFFFFu) | (w & 0x80000000u));    // copysign(|z|, bit 31): one v_bfi_b32
+    float m = fma1(c.w, tf, c.z);
+    m = fma1(m, tf, c.y);
+    m = fma1(m, tf, c.x);
+    uint32_t z;                                                     // copysign(|z|, bit 31 of w): magnitude bits of m, sign bit of w
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(z) : "s"(0x7FFFFFFFu), "v"(m), "v"(w));     // (VOP3 on gfx9 takes no literal: the mask sits in an SGPR)
+    return __uint_as_float(z);
 }
 
 __device__ __forceinline__ void normal4(uint32_t k0, uint32_t k1, uint64_t pb, uint32_t stream, const f32x4* table, float z[4])
@@ -270,7 +280,10 @@ constexpr int FM_BM_TILE = FM_BLOCK * FM_BM_PASSES;                 // float4 pe
 constexpr int FM_BM_STREAMS = 8;                                    // streams (step x factor vectors) per workgroup
 static_assert(FM_NORMAL_TABLE_ENTRIES == FM_BLOCK, "one table entry per thread in the LDS copy");
 
-__global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A, const uint32_t n_streams)
+// sq_stream[s] = (float)sqrt(dt) of local stream s — a `const __restrict__` parameter of its own so that it is read with SCALAR loads:
+// fetched through the argument struct it became one global_load per stream, and waiting for a vector load waits for every older
+// STORE of the wave as well (vmcnt counts them together, in order) — the write stream drained once per stream (4.97 TB/s).
+__global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A, const float* __restrict__ sq_stream, const uint32_t n_streams)
 {
     __shared__ f32x4 table[FM_NORMAL_TABLE_ENTRIES];
     table[threadIdx.x] = reinterpret_cast<const f32x4*>(FM_NORMAL_TABLE)[threadIdx.x];
@@ -287,7 +300,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_bm_kernel(const DevBmArgs A, cons
     }
     const bool aligned = (A.path_offset & 3) == 0;                  // wave-uniform
     for (uint32_t stream = s_begin; stream < s_end; ++stream) {
-        const float sq = A.sqrt_dt[stream / A.n_factors];
+        const float sq = sq_stream[stream];
         f32x4* __restrict__ out = reinterpret_cast<f32x4*>(A.slab + (size_t)stream * A.stride_floats);
         const uint32_t gstream = A.stream0 + stream;
 #pragma unroll
@@ -361,7 +374,7 @@ hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st)
     int64_t bx = (n4 + FM_BM_TILE - 1) / FM_BM_TILE;                // n_paths <= 2^31: at most 2^20 tiles
     if (bx < 1) bx = 1;
     const uint32_t by = (n_streams + FM_BM_STREAMS - 1) / FM_BM_STREAMS;
-    hipLaunchKernelGGL(fm_bm_kernel, dim3((uint32_t)bx, by, 1), dim3(FM_BLOCK), 0, st, a, n_streams);
+    hipLaunchKernelGGL(fm_bm_kernel, dim3((uint32_t)bx, by, 1), dim3(FM_BLOCK), 0, st, a, a.sqrt_dt, n_streams);
     return hipGetLastError();
 }
 

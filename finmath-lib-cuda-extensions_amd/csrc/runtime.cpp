@@ -1231,13 +1231,14 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
     slab->refs = 0;
     void* sq_dev = nullptr; size_t sq_cap = 0;
     try {
-        float* st = (float*)ensure_stage((size_t)n_steps * 4);
+        float* st = (float*)ensure_stage((size_t)n_streams * 4);       // one entry per stream: the kernel reads it with a scalar load, no division
         for (int i = 0; i < n_steps; ++i) {
             if (!(dt[i] >= 0.0)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "negative time step");
-            st[i] = (float)std::sqrt(dt[i]);        // (float)Math.sqrt(timeStep), BrownianMotionCudaWithRandomVariableCuda.java:170
+            const float sq = (float)std::sqrt(dt[i]);                  // (float)Math.sqrt(timeStep), BrownianMotionCudaWithRandomVariableCuda.java:170
+            for (int f = 0; f < n_factors; ++f) st[(size_t)i * n_factors + f] = sq;
         }
-        sq_dev = pool_.alloc((size_t)n_steps * 4, &sq_cap);
-        hip_check(hipMemcpyAsync(sq_dev, st, (size_t)n_steps * 4, hipMemcpyHostToDevice, stream_), "sqrt_dt H2D");
+        sq_dev = pool_.alloc((size_t)n_streams * 4, &sq_cap);
+        hip_check(hipMemcpyAsync(sq_dev, st, (size_t)n_streams * 4, hipMemcpyHostToDevice, stream_), "sqrt_dt H2D");
         hip_check(hipStreamSynchronize(stream_), "sync");
         if (n_paths > 0) {
             const int64_t chunk = 32768 - (32768 % n_factors);         // grid.y limit; keep whole steps together
@@ -1245,7 +1246,7 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
                 const int64_t ns = std::min(chunk, n_streams - s0);
                 DevBmArgs a{};
                 a.slab = slab->ptr + s0 * stride;
-                a.sqrt_dt = (const float*)sq_dev + s0 / n_factors;
+                a.sqrt_dt = (const float*)sq_dev + s0;
                 a.stride_floats = stride; a.n_paths = n_paths; a.path_offset = path_offset;
                 a.key0 = (uint32_t)(uint64_t)seed; a.key1 = (uint32_t)((uint64_t)seed >> 32);
                 a.n_factors = (uint32_t)n_factors; a.stream0 = (uint32_t)s0;
