@@ -118,7 +118,8 @@ void fusion_max_weight_override(int v);      // FMHIP_FUSION_MAX_WEIGHT (experim
 HostProfile g_host_profile;
 void HostProfile::report() const {
     static const char* names[N_SLOTS] = { "call (record one method)", "release", "flush_all (total)", "  build_dag", "  run_dags (total)", "    launch (total)",
-                                          "      kernel launch API", "      row table upload", "reduce / reduce_batch (total)" };
+                                          "      kernel launch API", "      row table upload", "reduce / reduce_batch (total)",
+                                          "  flush: roots + components", "  build_big (walk, schedule, sign)", "  run_big_group (total)" };
     std::fprintf(stderr, "[fmhip host profile]\n");
     for (int i = 0; i < N_SLOTS; ++i)
         std::fprintf(stderr, "  %-32s %10lld calls %9.3f s %9.2f us/call\n", names[i], count[i], seconds[i], count[i] ? seconds[i] / count[i] * 1e6 : 0.0);
@@ -181,6 +182,8 @@ void Engine::shutdown() {
     node_pool_.clear();
     for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
     programs_.clear();
+    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) if (--seg.prog->refs == 0) delete seg.prog;
+    plan_cache_.clear();
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
     program_cache_.clear();
     pool_.purge();
@@ -765,6 +768,7 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
             } else {
                 dag.order.push_back(nd);
                 stack.pop_back();
+                if ((int)dag.order.size() > FM_MAX_OPS) return false;       // too large for one launch: no point in walking the rest
             }
         }
     }
@@ -854,15 +858,19 @@ bool Engine::run_dags(std::vector<Dag>& dags) {
 struct Engine::BigDag {
     std::vector<Node*> roots;
     std::vector<Node*> order;       // all pending nodes of the component, operands before users
+    std::vector<Node*> leaves;      // distinct materialised inputs, in discovery order (structural: equal for equal shapes)
     std::string sig;                // shape: per op {opcode, operand ids (16 bit), escapes?}
+    uint64_t hash = 0;              // of sig
 };
 
 bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
+    HostTimer timer(HostProfile::BUILD_BIG);
     big.roots = roots;
     const uint64_t ep = ++epoch_;
     std::vector<std::pair<Node*, int>> stack;
     int n_leaves = 0;
-    std::vector<Node*> leaves;
+    std::vector<Node*>& leaves = big.leaves;
+    leaves.clear();
     auto visit = [&](Node* nd) { nd->mark = ep; nd->tmp_id = -1; nd->tmp_uses = 0; };
     for (Node* root : roots) {
         if (root->mark == ep) continue;
@@ -879,6 +887,40 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
         }
     }
     if (big.order.size() > 60000) return false;
+    // Schedule: the DFS post-order above is A topological order, but not a good one to cut into launches — it lists a whole
+    // dependency chain (e.g. the running factor sum over all LIBOR components of an Euler step) before the values that merely
+    // consume one link of it, so every link would have to be materialised for a later segment.  List scheduling, consumers
+    // first: emit a ready node, then prefer the nodes it has just made ready (LIFO; ties by creation order).  A value is
+    // consumed as soon as possible after it is produced: short live ranges, few values crossing a cut — two Euler steps
+    // recorded back to back come out component by component, both steps of a component adjacent, and the intermediate state
+    // never touches HBM.  Every op computes the same thing in any topological order: results are unchanged bit for bit.
+    {
+        const size_t m = big.order.size();
+        for (size_t i = 0; i < m; ++i) big.order[i]->tmp_id = (int)i;
+        std::vector<int> indeg(m, 0), head(m + 1, 0);
+        for (size_t i = 0; i < m; ++i)
+            for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) { indeg[i]++; head[(size_t)c->tmp_id + 1]++; } }
+        for (size_t i = 0; i < m; ++i) head[i + 1] += head[i];
+        std::vector<int> consumers((size_t)head[m]), fill(head.begin(), head.end() - 1);
+        for (size_t i = 0; i < m; ++i)
+            for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) consumers[(size_t)fill[(size_t)c->tmp_id]++] = (int)i; }
+        auto by_id_desc = [&](int a, int b) { return big.order[(size_t)a]->id > big.order[(size_t)b]->id; };
+        std::vector<int> stack_ready;
+        for (size_t i = 0; i < m; ++i) if (indeg[i] == 0) stack_ready.push_back((int)i);
+        std::sort(stack_ready.begin(), stack_ready.end(), by_id_desc);             // oldest node on top
+        std::vector<Node*> scheduled;
+        scheduled.reserve(m);
+        std::vector<int> fresh;
+        while (!stack_ready.empty()) {
+            const int i = stack_ready.back(); stack_ready.pop_back();
+            scheduled.push_back(big.order[(size_t)i]);
+            fresh.clear();
+            for (int q = head[(size_t)i]; q < head[(size_t)i + 1]; ++q) if (--indeg[(size_t)consumers[(size_t)q]] == 0) fresh.push_back(consumers[(size_t)q]);
+            std::sort(fresh.begin(), fresh.end(), by_id_desc);
+            stack_ready.insert(stack_ready.end(), fresh.begin(), fresh.end());
+        }
+        if (scheduled.size() == m) big.order.swap(scheduled);                      // (always: the pending graph is acyclic)
+    }
     big.sig.clear();
     big.sig.reserve(big.order.size() * 8 + 8);
     big.sig.push_back((char)('0' + math_mode));
@@ -890,6 +932,12 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
         for (int k = 0; k < 3; ++k) put16(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0);
         big.sig.push_back((nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) ? 'x' : '.');      // needed outside the component
     }
+    uint64_t h = 0x9e3779b97f4a7c15ull;               // 8 bytes at a time (the signature has 8 bytes per node plus one)
+    const char* p = big.sig.data();
+    size_t len = big.sig.size();
+    for (; len >= 8; p += 8, len -= 8) { uint64_t w; std::memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+    for (; len > 0; ++p, --len) { h = (h ^ (unsigned char)*p) * 0x100000001b3ull; }
+    big.hash = h;
     return true;
 }
 
@@ -937,18 +985,67 @@ bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag) {
     return true;
 }
 
+// One segment of a planned component for every member of a group: gather the row blocks by index, launch, commit.
+void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count) {
+    const int64_t n = group[first].order[(size_t)seg.out[0]]->n;
+    const size_t n_scal = seg.scal.empty() ? 1 : seg.scal.size();
+    std::vector<RowSpec> rows(count);
+    std::vector<float> scalars(count * n_scal, 0.0f);
+    std::vector<Buffer*> out_bufs;
+    out_bufs.reserve(count * seg.out.size());
+    try {
+        for (size_t c = 0; c < count; ++c) {
+            BigDag& big = group[first + c];
+            RowSpec& r = rows[c];
+            r.in.reserve(seg.in.size()); r.out.reserve(seg.out.size());
+            for (int32_t i : seg.in) {
+                Node* nd = i >= 0 ? big.order[(size_t)i] : big.leaves[(size_t)(-1 - i)];
+                if (!nd->buf) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "planned segment reads a value that has not been computed");
+                r.in.push_back(nd->buf->ptr);
+            }
+            for (size_t k = 0; k < seg.out.size(); ++k) { Buffer* b = new_buffer(n); out_bufs.push_back(b); r.out.push_back(b->ptr); }
+            float* sc = scalars.data() + c * n_scal;
+            for (size_t k = 0; k < seg.scal.size(); ++k) sc[k] = (float)big.order[(size_t)seg.scal[k]]->scalar;
+            r.scalars = sc; r.shifts = nullptr;
+        }
+        launch(seg.prog, n, rows, nullptr, nullptr);
+    } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
+    // commit (as run_dags): outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
+    for (size_t c = 0; c < count; ++c)
+        for (size_t k = 0; k < seg.out.size(); ++k) { Node* nd = group[first + c].order[(size_t)seg.out[k]]; nd->buf = out_bufs[c * seg.out.size() + k]; pending_.erase(nd); }
+    for (size_t c = 0; c < count; ++c)
+        for (size_t k = 0; k < seg.out.size(); ++k) {
+            Node* nd = group[first + c].order[(size_t)seg.out[k]];
+            nd->refs_int++;                 // keep alive while its expression is dismantled
+            drop_expression(nd);
+            nd->refs_int--;
+        }
+}
+
 void Engine::run_big_group(std::vector<BigDag>& group) {
+    HostTimer timer(HostProfile::RUN_BIG);
     BigDag& g0 = group[0];
     const size_t n_ops = g0.order.size();
-    std::vector<uint32_t>* cuts = nullptr;
-    auto it = split_cache_.find(g0.sig);
-    if (it != split_cache_.end()) cuts = &it->second;
-    std::vector<uint32_t> fresh;
-    size_t s = 0, stage = 0;
+    const size_t max_batch = 1024;
+    auto planned = plan_cache_.find(g0.hash);
+    if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
+    const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
+    if (planned != plan_cache_.end()) {
+        for (const BigPlan::Seg& seg : planned->second.segs)
+            for (size_t off = 0; off < group.size(); off += max_batch) run_planned_segment(seg, group, off, std::min(max_batch, group.size() - off));
+        return;
+    }
+    // First component of this shape: find the cuts (longest segment that fits one launch, again and again), run it through the
+    // general path, and write the plan down.  Node -> index in g0 for the plan (segment_dag reuses the nodes' scratch fields).
+    std::unordered_map<const Node*, int32_t> index_of;
+    index_of.reserve(n_ops + g0.leaves.size());
+    for (size_t i = 0; i < n_ops; ++i) index_of[g0.order[i]] = (int32_t)i;
+    for (size_t i = 0; i < g0.leaves.size(); ++i) index_of[g0.leaves[i]] = -1 - (int32_t)i;
+    BigPlan plan;
+    size_t s = 0;
     while (s < n_ops) {
         size_t e = 0;
-        if (cuts) e = (*cuts)[stage];
-        else {
+        {
             // longest segment starting at s that fits one launch.  Inputs grow monotonically with the end; outputs and live
             // values do not: collect every end that passes the cheap checks, then take the largest one that also compiles.
             std::vector<size_t> cheap;
@@ -967,19 +1064,28 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
                 e = cheap[k];
             }
             if (e == 0) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "an operation does not fit one launch");
-            fresh.push_back((uint32_t)e);
         }
         std::vector<Dag> dags(group.size());
         for (size_t c = 0; c < group.size(); ++c)
             if (!segment_dag(group[c], s, e, dags[c])) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "inconsistent segment of a split component");
-        const size_t max_batch = 1024;
+        {
+            BigPlan::Seg seg;
+            seg.prog = program_cache_.at(dags[0].sig);
+            for (Node* l : dags[0].leaves) seg.in.push_back(index_of.at(l));
+            for (Node* o : dags[0].outs) seg.out.push_back(index_of.at(o));
+            for (size_t i = s; i < e; ++i) if (op_info(g0.order[i]->opcode).scalar) seg.scal.push_back((int32_t)i);
+            plan.segs.push_back(std::move(seg));
+        }
         for (size_t off = 0; off < dags.size(); off += max_batch) {
             std::vector<Dag> part(std::make_move_iterator(dags.begin() + off), std::make_move_iterator(dags.begin() + std::min(dags.size(), off + max_batch)));
             if (!run_dags(part)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "segment of a split component does not fit one launch");
         }
-        s = e; ++stage;
+        s = e;
     }
-    if (!cuts) split_cache_[g0.sig] = fresh;
+    if (collision) return;
+    for (BigPlan::Seg& seg : plan.segs) seg.prog->refs++;              // the plan holds its programs (pool_purge drops both caches together)
+    plan.sig = g0.sig;
+    plan_cache_[g0.hash] = std::move(plan);
 }
 
 bool Engine::try_fused(const std::vector<Node*>& roots) {
@@ -1006,6 +1112,7 @@ void Engine::flush_all() {
     HostTimer timer(HostProfile::FLUSH);
     require_init();
     for (int round = 0; round < 1000000; ++round) {
+        std::unique_ptr<HostTimer> t_components(new HostTimer(HostProfile::FLUSH_COMPONENTS));
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
         for (Node* nd : pending_) if (nd->refs_int == 0 && nd->refs_ext > 0) roots.push_back(nd);
         if (roots.empty()) {
@@ -1042,6 +1149,7 @@ void Engine::flush_all() {
             if (!comps.count(c)) comp_order.push_back(c);
             comps[c].push_back(roots[i]);
         }
+        t_components.reset();
         // one DAG per component; group identical structures
         std::unordered_map<std::string, std::vector<Dag>> groups;
         std::vector<std::string> group_order;
@@ -1068,19 +1176,27 @@ void Engine::flush_all() {
             std::unordered_set<int> big_comps;
             std::vector<int> big_order;
             for (Node* r : leftovers) { const int c = comp_of[r]; if (big_comps.insert(c).second) big_order.push_back(c); }
-            std::unordered_map<std::string, std::vector<BigDag>> big_groups;
-            std::vector<std::string> big_group_order;
+            // grouped by a 64-bit hash of (shape signature, vector length): the signatures are ~10 KB strings, hashed ONCE in build_big
+            std::unordered_map<uint64_t, std::vector<BigDag>> big_groups;
+            std::vector<uint64_t> big_group_order;
             for (int c : big_order) {
                 std::vector<Node*> roots;
                 for (Node* r : comps[c]) if (!r->buf) roots.push_back(r);
                 if (roots.empty()) continue;
                 BigDag b;
                 if (!build_big(roots, b)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "pending expression too large");
-                std::string key = b.sig; key.push_back('#'); key += std::to_string(roots[0]->n);
-                if (!big_groups.count(key)) big_group_order.push_back(key);
-                big_groups[key].push_back(std::move(b));
+                uint64_t key = b.hash ^ ((uint64_t)roots[0]->n * 0x9E3779B97F4A7C15ull);
+                auto& members = big_groups[key];
+                if (members.empty()) big_group_order.push_back(key);
+                else if (members[0].sig != b.sig || members[0].roots[0]->n != roots[0]->n) {       // hash collision (practically never): a group of its own
+                    key = key * 0xff51afd7ed558ccdull + big_group_order.size() + 1;
+                    big_group_order.push_back(key);
+                    big_groups[key].push_back(std::move(b));
+                    continue;
+                }
+                members.push_back(std::move(b));
             }
-            for (const std::string& key : big_group_order) run_big_group(big_groups[key]);
+            for (uint64_t key : big_group_order) run_big_group(big_groups[key]);
         }
     }
 }
@@ -1278,6 +1394,8 @@ void Engine::pool_purge() {
     require_init();
     hip_check(hipStreamSynchronize(stream_), "sync");
     pool_.purge();
+    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) if (--seg.prog->refs == 0) delete seg.prog;
+    plan_cache_.clear();
     for (auto it = program_cache_.begin(); it != program_cache_.end();) { if (--it->second->refs == 0) delete it->second; it = program_cache_.erase(it); }
 }
 

@@ -200,10 +200,22 @@ private:
     bool try_fused(const std::vector<Node*>& roots);
     struct Dag;
     struct BigDag;
+    // What it takes to run a component of a known shape again: per segment the program and where its row block comes from.
+    // Indices >= 0 address BigDag::order, indices < 0 the leaves (-1 - index).  Built the first time a shape is seen (by the
+    // general path: segment search, Dag per segment, signature strings), then every later component of that shape — the next
+    // Euler steps, the other parameter sets of a Jacobian batch, the next objective evaluation — is executed straight from
+    // the plan: no Dag, no strings, no hash lookups per segment (the general path cost ≈ 16 µs of host time per segment and
+    // member, which made two-step groups of the LMM simulation host-bound).
+    struct BigPlan {
+        struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; };
+        std::vector<Seg> segs;
+        std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
+    };
     bool build_big(const std::vector<Node*>& roots, BigDag& big);
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     void run_big_group(std::vector<BigDag>& group);
-    std::unordered_map<std::string, std::vector<uint32_t>> split_cache_;      // component shape -> segment ends (partitioner)
+    void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count);
+    std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
     bool run_dags(std::vector<Dag>& dags);
 };
@@ -213,7 +225,7 @@ void hip_check(hipError_t e, const char* what);
 // Host-side time accounting of the front-end (FMHIP_HOST_PROFILE=1 prints the table at shutdown): where the wall time of
 // a launch-bound caller (the LMM calibration: 31 000 method calls and 700 launches per objective evaluation) goes.
 struct HostProfile {
-    enum Slot { CALL, RELEASE, FLUSH, BUILD_DAG, RUN_DAGS, LAUNCH, LAUNCH_API, ROW_UPLOAD, REDUCE, N_SLOTS };
+    enum Slot { CALL, RELEASE, FLUSH, BUILD_DAG, RUN_DAGS, LAUNCH, LAUNCH_API, ROW_UPLOAD, REDUCE, FLUSH_COMPONENTS, BUILD_BIG, RUN_BIG, N_SLOTS };
     bool on = false;
     double seconds[N_SLOTS] = { 0 };
     long long count[N_SLOTS] = { 0 };

@@ -164,7 +164,13 @@ struct Backend {
     // all Monte-Carlo expectations of one objective evaluation (default: one getAverage() per product)
     std::function<std::vector<double>(const std::vector<RV>&)> averages = [](const std::vector<RV>& v) {
         std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
-    int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum)
+    int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum); used when stepsPerLaunch == 1
+    // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  With 2, the
+    // engine's scheduler (runtime.cpp: build_big, consumers first) cuts the pending graph of two steps into launches of a few
+    // components x BOTH steps: the state between the two steps never touches HBM (1.5 instead of 2.4 vectors moved per
+    // component and step).  A group never spans a time index whose state a product reads (`keep`).  1 = one step at a time,
+    // flushed every `chunk` components (the scheme of round 1).  The arithmetic per path is the same either way.
+    int stepsPerLaunch = 2;
     int jacobianBatch = 1;                  // finite-difference bumps evaluated in lock-step (rows of the same launches)
 };
 
@@ -189,39 +195,51 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
         sim.numeraire[0] = be.factory->createRandomVariable(0.0, 1.0);
     }
     std::vector<RV> factorSum(K);                                                        // Σ_k λ_k δ/(1+δ L_k): running over components
-    for (int i = 0; i < lastTimeIndex; ++i) {
-        const double t = td.getTime(i), dt = td.getTimeStep(i);
-        const RV dW = be.brownianMotion->getBrownianIncrement(i, 0);
-        for (size_t k = 0; k < K; ++k) {
-            auto& cur = sims[k].libor[(size_t)i];
-            auto& nxt = sims[k].libor[(size_t)i + 1];
-            nxt.resize((size_t)n);
-            for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = cur[(size_t)j];       // fixed LIBORs
-            factorSum[k] = nullptr;
-        }
-        for (int j0 = i + 1; j0 < n; j0 += be.chunk) {
-            const int j1 = std::min(n, j0 + be.chunk);
+    const int S = std::max(1, be.stepsPerLaunch);
+    for (int i0 = 0; i0 < lastTimeIndex;) {
+        int i1 = std::min(i0 + S, lastTimeIndex);
+        if (keep) for (int s2 = i0 + 1; s2 < i1; ++s2) if ((*keep)[(size_t)s2]) { i1 = s2; break; }   // a state somebody reads ends the group
+        if (S > 1) be.hold(true);
+        for (int i = i0; i < i1; ++i) {
+            const double t = td.getTime(i), dt = td.getTimeStep(i);
+            const RV dW = be.brownianMotion->getBrownianIncrement(i, 0);
             for (size_t k = 0; k < K; ++k) {
                 auto& cur = sims[k].libor[(size_t)i];
                 auto& nxt = sims[k].libor[(size_t)i + 1];
-                for (int j = j0; j < j1; ++j) {
-                    const double lambda = vols[k]->volatility(t, td.getTime(j));         // one factor: loading = volatility
-                    // temporaries die before the flush: a live handle would make them extra outputs of the fused launch
-                    const RV& L = cur[(size_t)j];
-                    const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
-                    factorSum[k] = factorSum[k] ? factorSum[k]->add(transform) : transform;
-                    const RV drift = factorSum[k]->mult(lambda);
-                    nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);   // Euler step, normal state space
-                }
+                nxt.resize((size_t)n);
+                for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = cur[(size_t)j];       // fixed LIBORs
+                factorSum[k] = nullptr;
             }
-            if (j1 - j0 == be.chunk) be.flush();
+            for (int j0 = i + 1; j0 < n; j0 += be.chunk) {
+                const int j1 = std::min(n, j0 + be.chunk);
+                for (size_t k = 0; k < K; ++k) {
+                    auto& cur = sims[k].libor[(size_t)i];
+                    auto& nxt = sims[k].libor[(size_t)i + 1];
+                    for (int j = j0; j < j1; ++j) {
+                        const double lambda = vols[k]->volatility(t, td.getTime(j));         // one factor: loading = volatility
+                        // temporaries die before the flush: a live handle would make them extra outputs of the fused launch
+                        const RV& L = cur[(size_t)j];
+                        const RV transform = be.factory->createRandomVariable(lambda * delta)->discount(L, delta);   // λδ/(1+δL)
+                        factorSum[k] = factorSum[k] ? factorSum[k]->add(transform) : transform;
+                        const RV drift = factorSum[k]->mult(lambda);
+                        nxt[(size_t)j] = L->addProduct(drift, dt)->addProduct(dW, lambda);   // Euler step, normal state space
+                    }
+                }
+                if (S == 1 && j1 - j0 == be.chunk) be.flush();
+            }
+            for (size_t k = 0; k < K; ++k)
+                sims[k].numeraire[(size_t)i + 1] = sims[k].numeraire[(size_t)i]->accrue(sims[k].libor[(size_t)i][(size_t)i], delta);   // rolled-over bank account
+            for (size_t k = 0; k < K; ++k) factorSum[k] = nullptr;
         }
-        for (size_t k = 0; k < K; ++k)
-            sims[k].numeraire[(size_t)i + 1] = sims[k].numeraire[(size_t)i]->accrue(sims[k].libor[(size_t)i][(size_t)i], delta);   // rolled-over bank account
-        for (size_t k = 0; k < K; ++k) factorSum[k] = nullptr;
+        // states no product reads lose their handles BEFORE the flush: a pending value without a handle is an intermediate of the
+        // fused launches, not an output (the state between the steps of a group is never materialised)
+        if (keep)
+            for (int i = i0; i < i1; ++i)
+                if (!(*keep)[(size_t)i])
+                    for (size_t k = 0; k < K; ++k) { sims[k].libor[(size_t)i].clear(); sims[k].libor[(size_t)i].shrink_to_fit(); }
+        if (S > 1) be.hold(false);
         be.flush();
-        if (keep && !(*keep)[(size_t)i])
-            for (size_t k = 0; k < K; ++k) { sims[k].libor[(size_t)i].clear(); sims[k].libor[(size_t)i].shrink_to_fit(); }
+        i0 = i1;
     }
     return sims;
 }

@@ -33,6 +33,7 @@ int main(int argc, char** argv) {
         if (!(std::getenv("FMHIP_LMM_HOLD") && std::getenv("FMHIP_LMM_HOLD")[0] == '0'))       // =0: measurement of the effect only
             be.hold = [](bool h) { check(fmhip_fusion_hold(h ? 1 : 0, nullptr)); };
         if (o.chunk > 0) be.chunk = o.chunk;
+        if (o.stepsPerLaunch > 0) be.stepsPerLaunch = o.stepsPerLaunch;
         be.jacobianBatch = o.jacobianBatch > 0 ? o.jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
