@@ -1,0 +1,218 @@
+// fmhip_jni.cpp — the JNI layer of net.finmath.hip.Native: ONE function per C-ABI function of include/fmhip.h, no logic
+// beyond argument marshalling ("JNI layer = one Java_net_finmath_hip_Native_* function per C-ABI function").
+//
+// UNCOMPILED / UNTESTED in this repository: the build image has no JDK (no jni.h).  CMakeLists.txt at the repository root
+// builds it only when find_package(JNI) succeeds.  tests/test_jni_binding_cpu.py checks on every run that the set of functions
+// here, the native methods of java/net/finmath/hip/Native.java and the exports of include/fmhip.h are the same set.
+//
+// Marshalling rules: Java arrays are pinned with Get/ReleasePrimitiveArrayCritical around the ONE native call (no copy; the
+// engine narrows double → float itself, RandomVariableCuda.java:768-774); out-parameters are 1-element (or documented-length)
+// arrays; a null array where the C function accepts NULL is passed through as NULL.
+#include <jni.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "fmhip.h"
+
+namespace {
+
+// RAII pin of a primitive Java array (may be null).
+template <typename T>
+struct Pin {
+    JNIEnv* env; jarray arr; T* p; jint mode;
+    Pin(JNIEnv* e, jarray a, jint release_mode = 0) : env(e), arr(a), p(nullptr), mode(release_mode) { if (a) p = (T*)e->GetPrimitiveArrayCritical(a, nullptr); }
+    ~Pin() { if (arr && p) env->ReleasePrimitiveArrayCritical(arr, p, mode); }
+    jsize length() const { return arr ? env->GetArrayLength(arr) : 0; }
+};
+
+// fmhip_prog_op[] from the parallel arrays of Native.programCreate / programSource
+std::vector<fmhip_prog_op> program_ops(JNIEnv* env, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar) {
+    const jsize n = opcode ? env->GetArrayLength(opcode) : 0;
+    std::vector<fmhip_prog_op> ops((size_t)n);
+    Pin<jint> po(env, opcode, JNI_ABORT), pa(env, a, JNI_ABORT), pb(env, b, JNI_ABORT), pc(env, c, JNI_ABORT);
+    Pin<jdouble> ps(env, scalar, JNI_ABORT);
+    for (jsize i = 0; i < n; ++i) ops[(size_t)i] = { po.p[i], pa.p[i], pb.p[i], pc.p[i], ps.p ? ps.p[i] : 0.0 };
+    return ops;
+}
+
+inline void set1(JNIEnv* env, jintArray arr, jint v) { if (arr && env->GetArrayLength(arr) > 0) env->SetIntArrayRegion(arr, 0, 1, &v); }
+inline void set1(JNIEnv* env, jlongArray arr, jlong v) { if (arr && env->GetArrayLength(arr) > 0) env->SetLongArrayRegion(arr, 0, 1, &v); }
+
+} // namespace
+
+#define FMJ(ret, name) extern "C" JNIEXPORT ret JNICALL Java_net_finmath_hip_Native_##name
+
+// ---------------------------------------------------------------- lifecycle
+FMJ(jint, init)(JNIEnv*, jclass, jint deviceIndex) { return fmhip_init(deviceIndex); }
+FMJ(jint, shutdown)(JNIEnv*, jclass) { return fmhip_shutdown(); }
+FMJ(jint, isInitialized)(JNIEnv*, jclass) { return fmhip_is_initialized(); }
+FMJ(jint, abiVersion)(JNIEnv*, jclass) { return fmhip_abi_version(); }
+FMJ(jstring, lastError)(JNIEnv* env, jclass) { return env->NewStringUTF(fmhip_last_error()); }
+FMJ(jint, deviceInfo)(JNIEnv* env, jclass, jobjectArray name, jintArray computeUnits, jlongArray hbmBytes) {
+    char buf[256] = { 0 }; int cus = 0; int64_t hbm = 0;
+    const int st = fmhip_device_info(buf, (int)sizeof buf, &cus, &hbm);
+    if (st == FMHIP_OK) {
+        if (name && env->GetArrayLength(name) > 0) env->SetObjectArrayElement(name, 0, env->NewStringUTF(buf));
+        set1(env, computeUnits, (jint)cus); set1(env, hbmBytes, (jlong)hbm);
+    }
+    return st;
+}
+FMJ(jint, synchronize)(JNIEnv*, jclass) { return fmhip_synchronize(); }
+FMJ(jint, getStream)(JNIEnv* env, jclass, jlongArray stream) {
+    void* s = nullptr;
+    const int st = fmhip_get_stream(&s);
+    if (st == FMHIP_OK) set1(env, stream, (jlong)(intptr_t)s);
+    return st;
+}
+
+// ---------------------------------------------------------------- vectors
+FMJ(jlong, vecCreateFromDouble)(JNIEnv* env, jclass, jdoubleArray values) {
+    Pin<jdouble> p(env, values, JNI_ABORT);
+    fmhip_vec out = 0;
+    return fmhip_vec_create_from_double(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
+}
+FMJ(jlong, vecCreateFromFloat)(JNIEnv* env, jclass, jfloatArray values) {
+    Pin<jfloat> p(env, values, JNI_ABORT);
+    fmhip_vec out = 0;
+    return fmhip_vec_create_from_float(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
+}
+FMJ(jlong, vecCreateFilled)(JNIEnv*, jclass, jlong n, jdouble value) { fmhip_vec out = 0; return fmhip_vec_create_filled(n, value, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jlong, vecCreateUninitialized)(JNIEnv*, jclass, jlong n) { fmhip_vec out = 0; return fmhip_vec_create_uninitialized(n, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jint, vecRetain)(JNIEnv*, jclass, jlong v) { return fmhip_vec_retain(v); }
+FMJ(jint, vecRelease)(JNIEnv*, jclass, jlong v) { return fmhip_vec_release(v); }
+FMJ(jint, vecSize)(JNIEnv* env, jclass, jlong v, jlongArray size) {
+    int64_t n = 0;
+    const int st = fmhip_vec_size(v, &n);
+    if (st == FMHIP_OK) set1(env, size, (jlong)n);
+    return st;
+}
+FMJ(jint, vecReadDouble)(JNIEnv* env, jclass, jlong v, jdoubleArray out) { Pin<jdouble> p(env, out); return fmhip_vec_read_double(v, p.p, p.length()); }
+FMJ(jint, vecReadFloat)(JNIEnv* env, jclass, jlong v, jfloatArray out) { Pin<jfloat> p(env, out); return fmhip_vec_read_float(v, p.p, p.length()); }
+FMJ(jint, vecDevicePtr)(JNIEnv* env, jclass, jlong v, jlongArray devicePointer) {
+    void* ptr = nullptr;
+    const int st = fmhip_vec_device_ptr(v, &ptr);
+    if (st == FMHIP_OK) set1(env, devicePointer, (jlong)(intptr_t)ptr);
+    return st;
+}
+
+// ---------------------------------------------------------------- element-wise operations (the hot path: no allocation, no array)
+FMJ(jlong, callV1s0)(JNIEnv*, jclass, jint opcode, jlong a) { fmhip_vec out = 0; return fmhip_call_v1s0(opcode, a, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jlong, callV1s1)(JNIEnv*, jclass, jint opcode, jlong a, jdouble s) { fmhip_vec out = 0; return fmhip_call_v1s1(opcode, a, s, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jlong, callV2s0)(JNIEnv*, jclass, jint opcode, jlong a, jlong b) { fmhip_vec out = 0; return fmhip_call_v2s0(opcode, a, b, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jlong, callV2s1)(JNIEnv*, jclass, jint opcode, jlong a, jlong b, jdouble s) { fmhip_vec out = 0; return fmhip_call_v2s1(opcode, a, b, s, &out) == FMHIP_OK ? (jlong)out : 0; }
+FMJ(jlong, callV3s0)(JNIEnv*, jclass, jint opcode, jlong a, jlong b, jlong c) { fmhip_vec out = 0; return fmhip_call_v3s0(opcode, a, b, c, &out) == FMHIP_OK ? (jlong)out : 0; }
+
+// ---------------------------------------------------------------- lazy fusion front-end
+FMJ(jint, setFusion)(JNIEnv* env, jclass, jint enabled, jintArray previous) { int prev = 0; const int st = fmhip_set_fusion(enabled, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
+FMJ(jint, flush)(JNIEnv*, jclass) { return fmhip_flush(); }
+FMJ(jint, fusionHold)(JNIEnv* env, jclass, jint hold, jintArray previous) { int prev = 0; const int st = fmhip_fusion_hold(hold, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
+FMJ(jint, setMathMode)(JNIEnv* env, jclass, jint mode, jintArray previous) { int prev = 0; const int st = fmhip_set_math_mode(mode, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
+
+// ---------------------------------------------------------------- reductions
+FMJ(jint, reduceMoments)(JNIEnv* env, jclass, jlong v, jdouble shift, jdoubleArray moments4) {
+    fmhip_moments m;
+    const int st = fmhip_reduce_moments(v, shift, &m);
+    if (st == FMHIP_OK && moments4 && env->GetArrayLength(moments4) >= 4) { const jdouble d[4] = { m.sum, m.sumsq, m.min, m.max }; env->SetDoubleArrayRegion(moments4, 0, 4, d); }
+    return st;
+}
+FMJ(jint, reduceMomentsDevice)(JNIEnv*, jclass, jlong v, jdouble shift, jlong deviceOut) { return fmhip_reduce_moments_device(v, shift, (void*)(intptr_t)deviceOut); }
+FMJ(jint, reduceMomentsBatch)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jdoubleArray moments4PerVector) {
+    Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT); Pin<jdouble> pm(env, moments4PerVector);
+    static_assert(sizeof(fmhip_moments) == 4 * sizeof(double), "moments travel as 4 doubles");
+    return fmhip_reduce_moments_batch((const fmhip_vec*)pv.p, pv.length(), ps.p, (fmhip_moments*)pm.p);
+}
+FMJ(jint, reduceMomentsBatchDevice)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jlong deviceOut) {
+    Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT);
+    return fmhip_reduce_moments_batch_device((const fmhip_vec*)pv.p, pv.length(), ps.p, (void*)(intptr_t)deviceOut);
+}
+
+// ---------------------------------------------------------------- explicit fused programs
+FMJ(jlong, programCreate)(JNIEnv* env, jclass, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar, jint nInputs, jintArray outValues, jintArray reduceValues) {
+    const std::vector<fmhip_prog_op> ops = program_ops(env, opcode, a, b, c, scalar);
+    Pin<jint> po(env, outValues, JNI_ABORT), pr(env, reduceValues, JNI_ABORT);
+    fmhip_program out = 0;
+    return fmhip_program_create(ops.data(), (int)ops.size(), nInputs, (const int32_t*)po.p, po.length(), (const int32_t*)pr.p, pr.length(), &out) == FMHIP_OK ? (jlong)out : 0;
+}
+FMJ(jint, programRelease)(JNIEnv*, jclass, jlong p) { return fmhip_program_release(p); }
+FMJ(jint, programLaunchCount)(JNIEnv* env, jclass, jlong p, jintArray launches) { int n = 0; const int st = fmhip_program_launch_count(p, &n); if (st == FMHIP_OK) set1(env, launches, n); return st; }
+FMJ(jint, programRun)(JNIEnv* env, jclass, jlong p, jint batch, jlongArray inputs, jlongArray outputs, jdoubleArray reduceShift, jdoubleArray moments4, jlong deviceMoments) {
+    Pin<jlong> pi(env, inputs, JNI_ABORT), po(env, outputs); Pin<jdouble> ps(env, reduceShift, JNI_ABORT), pm(env, moments4);
+    return fmhip_program_run(p, batch, (const fmhip_vec*)pi.p, (fmhip_vec*)po.p, ps.p, (fmhip_moments*)pm.p, (void*)(intptr_t)deviceMoments);
+}
+FMJ(jint, programRunInto)(JNIEnv* env, jclass, jlong p, jint batch, jlongArray inputs, jlongArray outputs, jdoubleArray reduceShift, jdoubleArray moments4, jlong deviceMoments) {
+    Pin<jlong> pi(env, inputs, JNI_ABORT), po(env, outputs, JNI_ABORT); Pin<jdouble> ps(env, reduceShift, JNI_ABORT), pm(env, moments4);
+    return fmhip_program_run_into(p, batch, (const fmhip_vec*)pi.p, (const fmhip_vec*)po.p, ps.p, (fmhip_moments*)pm.p, (void*)(intptr_t)deviceMoments);
+}
+
+// ---------------------------------------------------------------- execution tiers
+FMJ(jint, setJit)(JNIEnv* env, jclass, jint mode, jintArray previous) { int prev = 0; const int st = fmhip_set_jit(mode, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
+FMJ(jint, jitWait)(JNIEnv*, jclass) { return fmhip_jit_wait(); }
+FMJ(jint, jitStats)(JNIEnv* env, jclass, jlongArray compiledFailedPendingDiskHits, jdoubleArray compileSeconds) {
+    int64_t compiled = 0, failed = 0, pending = 0, disk = 0; double seconds = 0.0;
+    const int st = fmhip_jit_stats(&compiled, &failed, &pending, &seconds, &disk);
+    if (st == FMHIP_OK) {
+        if (compiledFailedPendingDiskHits && env->GetArrayLength(compiledFailedPendingDiskHits) >= 4) { const jlong v[4] = { (jlong)compiled, (jlong)failed, (jlong)pending, (jlong)disk }; env->SetLongArrayRegion(compiledFailedPendingDiskHits, 0, 4, v); }
+        if (compileSeconds && env->GetArrayLength(compileSeconds) >= 1) env->SetDoubleArrayRegion(compileSeconds, 0, 1, &seconds);
+    }
+    return st;
+}
+FMJ(jint, programTier)(JNIEnv* env, jclass, jlong p, jintArray tierAndVgprs) {
+    int tier = 0, vgprs = 0;
+    const int st = fmhip_program_tier(p, &tier, &vgprs);
+    if (st == FMHIP_OK && tierAndVgprs && env->GetArrayLength(tierAndVgprs) >= 2) { const jint v[2] = { tier, vgprs }; env->SetIntArrayRegion(tierAndVgprs, 0, 2, v); }
+    return st;
+}
+FMJ(jstring, programSource)(JNIEnv* env, jclass, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar, jint nInputs, jintArray outValues, jintArray reduceValues) {
+    const std::vector<fmhip_prog_op> ops = program_ops(env, opcode, a, b, c, scalar);
+    std::vector<int32_t> outs, reds;
+    { Pin<jint> po(env, outValues, JNI_ABORT), pr(env, reduceValues, JNI_ABORT); outs.assign(po.p, po.p + po.length()); reds.assign(pr.p, pr.p + pr.length()); }
+    int64_t needed = 0;
+    if (fmhip_program_source(ops.data(), (int)ops.size(), nInputs, outs.data(), (int)outs.size(), reds.data(), (int)reds.size(), nullptr, 0, &needed) != FMHIP_OK) return nullptr;
+    std::string text((size_t)needed + 1, '\0');
+    if (fmhip_program_source(ops.data(), (int)ops.size(), nInputs, outs.data(), (int)outs.size(), reds.data(), (int)reds.size(), &text[0], needed + 1, &needed) != FMHIP_OK) return nullptr;
+    return env->NewStringUTF(text.c_str());
+}
+
+// ---------------------------------------------------------------- Brownian increments
+FMJ(jint, bmGenerate)(JNIEnv* env, jclass, jlong seed, jint nSteps, jint nFactors, jlong nPaths, jlong pathOffset, jdoubleArray dt, jlongArray outHandles) {
+    Pin<jdouble> pd(env, dt, JNI_ABORT); Pin<jlong> po(env, outHandles);
+    if (po.length() < (jsize)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_bm_generate(seed, nSteps, nFactors, nPaths, pathOffset, pd.p, (fmhip_vec*)po.p);
+}
+FMJ(jint, mersenneIncrements)(JNIEnv* env, jclass, jint seed, jint nSteps, jint nFactors, jlong nPaths, jdoubleArray dt, jdoubleArray hostOut) {
+    Pin<jdouble> pd(env, dt, JNI_ABORT), po(env, hostOut);
+    if ((int64_t)po.length() < (int64_t)nSteps * nFactors * nPaths || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_mersenne_increments(seed, nSteps, nFactors, nPaths, pd.p, po.p);
+}
+FMJ(jint, bmGenerateMersenne)(JNIEnv* env, jclass, jint seed, jint nSteps, jint nFactors, jlong nPaths, jdoubleArray dt, jlongArray outHandles) {
+    Pin<jdouble> pd(env, dt, JNI_ABORT); Pin<jlong> po(env, outHandles);
+    if (po.length() < (jsize)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_bm_generate_mersenne(seed, nSteps, nFactors, nPaths, pd.p, (fmhip_vec*)po.p);
+}
+FMJ(jdouble, inverseNormalCdf)(JNIEnv*, jclass, jdouble p) { return fmhip_inverse_normal_cdf(p); }
+
+// ---------------------------------------------------------------- pool
+FMJ(jint, poolClean)(JNIEnv*, jclass) { return fmhip_pool_clean(); }
+FMJ(jint, poolPurge)(JNIEnv*, jclass) { return fmhip_pool_purge(); }
+FMJ(jint, poolStats)(JNIEnv* env, jclass, jlongArray stats10) {
+    fmhip_pool_stats_t s;
+    const int st = fmhip_pool_stats(&s);
+    static_assert(sizeof(fmhip_pool_stats_t) == 10 * sizeof(int64_t), "pool statistics travel as 10 longs");
+    if (st == FMHIP_OK && stats10 && env->GetArrayLength(stats10) >= 10) env->SetLongArrayRegion(stats10, 0, 10, (const jlong*)&s);
+    return st;
+}
+
+// ---------------------------------------------------------------- measurement
+FMJ(jint, profileEnable)(JNIEnv*, jclass, jint enabled) { return fmhip_profile_enable(enabled); }
+FMJ(jint, trafficStats)(JNIEnv* env, jclass, jlongArray algorithmicBytesAndSpecialisedLaunches) {
+    int64_t bytes = 0, launches = 0;
+    const int st = fmhip_traffic_stats(&bytes, &launches);
+    if (st == FMHIP_OK && algorithmicBytesAndSpecialisedLaunches && env->GetArrayLength(algorithmicBytesAndSpecialisedLaunches) >= 2) { const jlong v[2] = { (jlong)bytes, (jlong)launches }; env->SetLongArrayRegion(algorithmicBytesAndSpecialisedLaunches, 0, 2, v); }
+    return st;
+}
+FMJ(jint, profileRead)(JNIEnv* env, jclass, jdoubleArray kernelMsTotal, jlongArray launches) {
+    double ms = 0.0; int64_t n = 0;
+    const int st = fmhip_profile_read(&ms, &n);
+    if (st == FMHIP_OK) { if (kernelMsTotal && env->GetArrayLength(kernelMsTotal) >= 1) env->SetDoubleArrayRegion(kernelMsTotal, 0, 1, &ms); set1(env, launches, (jlong)n); }
+    return st;
+}
