@@ -3,8 +3,8 @@ both execution tiers, as device time and algorithmic GB/s (4 B x N x (inputs + o
 
     python benchmarks/config2_sweep.py [--json out.json] [--ops LOG,CAP_S,moments]
 
-Two shapes: 64 independent tuples of N = 1 000 000 per launch (working set 0.5-1 GB >> the 256 MB Infinity Cache, i.e. the
-HBM-labelled figure) and one tuple of N = 2^26."""
+Three shapes: 64 independent tuples of N = 1 000 000 and of N = 2^20 per launch (working set 0.5-1 GB >> the 256 MB Infinity
+Cache, i.e. the HBM-labelled figure) and one tuple of N = 2^26."""
 import importlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
@@ -42,7 +42,7 @@ def timed(p, rows, outs, reps):
 def main():
     results = []
     only = set(sys.argv[sys.argv.index("--ops") + 1].split(",")) if "--ops" in sys.argv else None
-    for n, B, reps in ((1_000_000, 64, 6), (1 << 26, 1, 6)):
+    for n, B, reps in ((1_000_000, 64, 6), (1 << 20, 64, 6), (1 << 26, 1, 6)):       # the three sizes SURVEY.md §8(d) config 2 names
         rows = inputs(n, B)
         outs = [[fm.DeviceVector.filled(n, 0.0)] for _ in range(B)]
         for tname, tier in (("interpreter", fm.JIT_OFF), ("specialised", fm.JIT_SYNC)):

@@ -1,6 +1,6 @@
-"""profiles/round01_hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
+"""profiles/roundNN_hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
 
-    python benchmarks/hbm_traffic_summary.py <fetch_dir> <write_dir> > profiles/round01_hbm_traffic.json
+    python benchmarks/hbm_traffic_summary.py <fetch_dir> <write_dir> > profiles/round02_hbm_traffic.json
 
 Picks the dominant program kernel of the run (either tier; largest grid: stream S over 64 x 1M paths), averages the counter over its launches
 and applies the gfx950 corrections of MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE is doubled."""
@@ -29,8 +29,8 @@ alg = 4.0 * (3 + 1) * n * B
 print(json.dumps({
     "kernel": fetch_kernel,
     "workload": {"paths": n, "batch": B, "stream": "S (12 ops, 3 in, 1 out) + fused reduction"},
-    "method": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `python3 bench.py --steps 5 --warmup 2 "
-              "--no-cpu-baseline`; FETCH_SIZE doubled per the gfx950 correction (128-B requests tallied at 64 B, "
+    "method": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over `python3 bench.py --workload stream --steps 5 --warmup 2 "
+              "--sustained-seconds 0 --no-cpu-baseline`; FETCH_SIZE doubled per the gfx950 correction (128-B requests tallied at 64 B, "
               "MI355X_MICROARCH.md §HBM), WRITE_SIZE as is; counters are in KiB",
     "raw": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
     "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
