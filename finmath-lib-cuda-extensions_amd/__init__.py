@@ -125,6 +125,36 @@ def jit_stats() -> dict:
     return {"compiled": c.value, "failed": f.value, "pending": p.value, "compile_seconds": s.value, "disk_cache_hits": d.value}
 
 
+def graph_clone(roots, n_copies: int, leaf_from=(), leaf_to=(), scalars=None):
+    """fmhip_graph_clone: `n_copies` copies of the pending expressions below `roots` (DeviceVector objects).  Copy j reads
+    leaf_to[j][i] wherever the original reads leaf_from[i] and takes its scalar operands, in recording order, from scalars[j]
+    (None: the original's).  Returns a list of n_copies lists of DeviceVector, one per root."""
+    import numpy as _np
+    n_roots, n_map = len(roots), len(leaf_from)
+    r = (_C.c_int64 * n_roots)(*[v.handle for v in roots])
+    lf = (_C.c_int64 * max(1, n_map))(*[v.handle for v in leaf_from])
+    lt = (_C.c_int64 * max(1, n_map * n_copies))(*[v.handle for row in leaf_to for v in row])
+    sc, n_sc = None, 0
+    if scalars is not None:
+        a = _np.ascontiguousarray(scalars, dtype=_np.float64).reshape(n_copies, -1)
+        n_sc = a.shape[1]
+        sc = a.ctypes.data_as(_C.POINTER(_C.c_double))
+    out = (_C.c_int64 * max(1, n_roots * n_copies))()
+    _native.check(lib().fmhip_graph_clone(r, n_roots, n_copies, lf, lt, n_map, sc, n_sc, out))
+    return [[DeviceVector(out[j * n_roots + k], roots[k].n) for k in range(n_roots)] for j in range(n_copies)]
+
+
+def graph_scalars(roots):
+    """fmhip_graph_scalars: the scalar operands of the pending graph below `roots`, in recording order."""
+    import numpy as _np
+    r = (_C.c_int64 * len(roots))(*[v.handle for v in roots])
+    n = _C.c_int(0)
+    _native.check(lib().fmhip_graph_scalars(r, len(roots), None, 0, _C.byref(n)))
+    out = _np.zeros(max(1, n.value), dtype=_np.float64)
+    _native.check(lib().fmhip_graph_scalars(r, len(roots), out.ctypes.data_as(_C.POINTER(_C.c_double)), n.value, _C.byref(n)))
+    return out[:n.value]
+
+
 def flush() -> None:
     _native.check(lib().fmhip_flush())
 

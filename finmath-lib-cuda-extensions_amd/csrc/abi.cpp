@@ -111,6 +111,16 @@ int fmhip_fusion_hold(int hold, int* previous) {
         e.fusion_hold = hold != 0;
     });
 }
+int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
+                      const double* scalars, int n_scalars, fmhip_vec* out) {
+    return guarded([&] { Engine::get().graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out); });
+}
+int fmhip_graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int capacity, int* n_scalars) {
+    return guarded([&] {
+        if (!n_scalars) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null count pointer");
+        *n_scalars = Engine::get().graph_scalars(roots, n_roots, scalars_out, capacity);
+    });
+}
 int fmhip_set_math_mode(int mode, int* previous) {
     return guarded([&] {
         Engine& e = Engine::get();

@@ -119,7 +119,8 @@ HostProfile g_host_profile;
 void HostProfile::report() const {
     static const char* names[N_SLOTS] = { "call (record one method)", "release", "flush_all (total)", "  build_dag", "  run_dags (total)", "    launch (total)",
                                           "      kernel launch API", "      row table upload", "reduce / reduce_batch (total)",
-                                          "  flush: roots + components", "  build_big (walk, schedule, sign)", "  run_big_group (total)" };
+                                          "  flush: roots + components", "  build_big (walk, schedule, sign)", "  run_big_group (total)",
+                                          "graph_clone (total)" };
     std::fprintf(stderr, "[fmhip host profile]\n");
     for (int i = 0; i < N_SLOTS; ++i)
         std::fprintf(stderr, "  %-32s %10lld calls %9.3f s %9.2f us/call\n", names[i], count[i], seconds[i], count[i] ? seconds[i] / count[i] * 1e6 : 0.0);
@@ -177,7 +178,7 @@ void Engine::shutdown() {
         delete nd;
     }
     nodes_.clear();
-    pending_.clear();
+    pend_clear();
     for (Node* nd : node_pool_) delete nd;
     node_pool_.clear();
     for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
@@ -286,7 +287,7 @@ void Engine::node_unref_int(Node* nd) { nd->refs_int--; node_maybe_free(nd); }
 void Engine::node_maybe_free(Node* nd) {
     if (nd->refs_ext > 0 || nd->refs_int > 0) return;
     if (nd->buf) buffer_unref(nd->buf);
-    else { pending_.erase(nd); drop_expression(nd); }
+    else { pend_erase(nd); drop_expression(nd); }
     if (node_pool_.size() < 65536) node_pool_.push_back(nd); else delete nd;
 }
 
@@ -723,12 +724,98 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     int w = 1;
     for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
     nd->weight = w;
-    pending_.insert(nd);
+    pend_insert(nd);
     if (!fusion || (w > FUSION_MAX_WEIGHT && !fusion_hold)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
     }
     return nd->id;
+}
+
+// ---------------------------------------------------------------- replication of pending graphs (fmhip_graph_clone)
+
+void Engine::collect_pending(const fmhip_vec* roots, int n_roots, std::vector<Node*>& graph) {
+    if (n_roots <= 0 || !roots) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "no roots");
+    const uint64_t ep = ++epoch_;
+    std::vector<Node*> stack;
+    for (int r = 0; r < n_roots; ++r) {
+        Node* root = node(roots[r]);
+        if (root->buf || root->mark == ep) continue;
+        root->mark = ep; stack.push_back(root);
+        while (!stack.empty()) {
+            Node* nd = stack.back(); stack.pop_back();
+            graph.push_back(nd);
+            for (int k = 0; k < nd->n_in; ++k) { Node* c = nd->in[k]; if (!c->buf && c->mark != ep) { c->mark = ep; stack.push_back(c); } }
+        }
+    }
+    // recording order = ascending id, and a topological order: an operand exists before the operation that uses it
+    std::sort(graph.begin(), graph.end(), [](const Node* a, const Node* b) { return a->id < b->id; });
+}
+
+int Engine::graph_scalars(const fmhip_vec* roots, int n_roots, double* out, int capacity) {
+    require_init();
+    std::vector<Node*> graph;
+    collect_pending(roots, n_roots, graph);
+    int count = 0;
+    for (Node* nd : graph) if (op_info(nd->opcode).scalar) { if (out && count < capacity) out[count] = nd->scalar; ++count; }
+    return count;
+}
+
+void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
+                         const double* scalars, int n_scalars, fmhip_vec* out) {
+    HostTimer timer(HostProfile::CLONE);
+    require_init();
+    if (n_copies < 0 || n_map < 0 || !out || (n_map > 0 && (!leaf_from || !leaf_to))) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad graph replication request");
+    std::vector<Node*> graph;
+    collect_pending(roots, n_roots, graph);
+    const uint64_t ep_graph = ++epoch_;
+    int count_scalars = 0;
+    for (size_t i = 0; i < graph.size(); ++i) { graph[i]->mark = ep_graph; graph[i]->tmp_id = (int)i; count_scalars += op_info(graph[i]->opcode).scalar ? 1 : 0; }
+    if (scalars && n_scalars != count_scalars)
+        throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the graph has " + std::to_string(count_scalars) + " scalar operands, the caller supplied " + std::to_string(n_scalars));
+    const uint64_t ep_leaf = ++epoch_;
+    std::vector<Node*> from((size_t)n_map);
+    for (int i = 0; i < n_map; ++i) {
+        Node* l = node(leaf_from[i]);
+        if (l->mark == ep_graph) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a substituted operand lies inside the graph to be replicated");
+        l->mark = ep_leaf; l->tmp_id = i;
+        from[(size_t)i] = l;
+    }
+    std::vector<Node*> root_nodes((size_t)n_roots);
+    for (int r = 0; r < n_roots; ++r) root_nodes[(size_t)r] = node(roots[r]);
+    std::vector<Node*> to((size_t)n_map), copy(graph.size());
+    for (int j = 0; j < n_copies; ++j) {
+        for (int i = 0; i < n_map; ++i) {
+            to[(size_t)i] = node(leaf_to[(size_t)j * n_map + i]);
+            if (to[(size_t)i]->n != from[(size_t)i]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "a substituted operand differs in size");
+        }
+        const double* sc = scalars ? scalars + (size_t)j * n_scalars : nullptr;
+        int k_scalar = 0;
+        for (size_t i = 0; i < graph.size(); ++i) {
+            const Node* src = graph[i];
+            Node* nd;                                            // like new_node, but without a handle: inner values of a copy have none
+            if (!node_pool_.empty()) { nd = node_pool_.back(); node_pool_.pop_back(); *nd = Node(); } else nd = new Node();
+            nd->id = next_id_++; nd->n = src->n;
+            nd->opcode = src->opcode; nd->n_in = src->n_in; nd->weight = src->weight;
+            nd->scalar = src->scalar;
+            if (op_info(src->opcode).scalar) { if (sc) nd->scalar = sc[k_scalar]; ++k_scalar; }
+            for (int k = 0; k < src->n_in; ++k) {
+                Node* c = src->in[k];
+                Node* m = c->mark == ep_graph ? copy[(size_t)c->tmp_id] : (c->mark == ep_leaf ? to[(size_t)c->tmp_id] : c);
+                nd->in[k] = m; m->refs_int++;
+            }
+            pend_insert(nd);
+            copy[i] = nd;
+        }
+        for (int r = 0; r < n_roots; ++r) {
+            Node* root = root_nodes[(size_t)r];
+            Node* c = root->mark == ep_graph ? copy[(size_t)root->tmp_id] : (root->mark == ep_leaf ? to[(size_t)root->tmp_id] : root);   // a root that is already a vector: shared
+            c->refs_ext++;
+            if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+            out[(size_t)j * n_roots + r] = c->id;
+        }
+        // copies of values nobody holds and nothing uses cannot exist: every graph node is below a root
+    }
 }
 
 struct Engine::Dag {
@@ -835,7 +922,7 @@ bool Engine::run_dags(std::vector<Dag>& dags) {
     }
     // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t i = 0; i < dags.size(); ++i)
-        for (size_t k = 0; k < dags[i].outs.size(); ++k) { dags[i].outs[k]->buf = out_bufs[i][k]; pending_.erase(dags[i].outs[k]); }
+        for (size_t k = 0; k < dags[i].outs.size(); ++k) { dags[i].outs[k]->buf = out_bufs[i][k]; pend_erase(dags[i].outs[k]); }
     for (size_t i = 0; i < dags.size(); ++i)
         for (size_t k = 0; k < dags[i].outs.size(); ++k) {
             Node* nd = dags[i].outs[k];
@@ -1012,7 +1099,7 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
     } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
     // commit (as run_dags): outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t c = 0; c < count; ++c)
-        for (size_t k = 0; k < seg.out.size(); ++k) { Node* nd = group[first + c].order[(size_t)seg.out[k]]; nd->buf = out_bufs[c * seg.out.size() + k]; pending_.erase(nd); }
+        for (size_t k = 0; k < seg.out.size(); ++k) { Node* nd = group[first + c].order[(size_t)seg.out[k]]; nd->buf = out_bufs[c * seg.out.size() + k]; pend_erase(nd); }
     for (size_t c = 0; c < count; ++c)
         for (size_t k = 0; k < seg.out.size(); ++k) {
             Node* nd = group[first + c].order[(size_t)seg.out[k]];
@@ -1114,10 +1201,10 @@ void Engine::flush_all() {
     for (int round = 0; round < 1000000; ++round) {
         std::unique_ptr<HostTimer> t_components(new HostTimer(HostProfile::FLUSH_COMPONENTS));
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
-        for (Node* nd : pending_) if (nd->refs_int == 0 && nd->refs_ext > 0) roots.push_back(nd);
+        for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_int == 0 && nd->refs_ext > 0) roots.push_back(nd);
         if (roots.empty()) {
             Node* live = nullptr;
-            for (Node* nd : pending_) if (nd->refs_ext > 0) { live = nd; break; }
+            for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_ext > 0) { live = nd; break; }
             if (!live) return;
             materialize({ live });
             continue;

@@ -72,6 +72,10 @@ struct Node {
     // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
     uint64_t mark = 0;
     int     tmp_id = 0, tmp_uses = 0;
+    // membership in the engine's list of pending nodes (intrusive, O(1) insert / erase without hashing: recording a method is
+    // ≈ 60 ns in all, a hash-set insert was a third of it)
+    Node*   pend_prev = nullptr;
+    Node*   pend_next = nullptr;
 };
 
 // ---------------------------------------------------------------- compiled programs
@@ -122,6 +126,9 @@ public:
     int math_mode = FMHIP_MATH_EXACT;
     void flush_all();
     void materialize(const std::vector<Node*>& targets);
+    void graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
+                     const double* scalars, int n_scalars, fmhip_vec* out);
+    int graph_scalars(const fmhip_vec* roots, int n_roots, double* out, int capacity);
 
     // reductions
     void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out);
@@ -155,7 +162,7 @@ public:
     void profile_read(double* ms_total, int64_t* n);
 
 private:
-    Engine() = default;
+    Engine() { pend_clear(); }
     bool initialized_ = false;
     int device_ = -1;
     hipStream_t stream_ = nullptr;
@@ -163,7 +170,10 @@ private:
     Jit jit_;
     int64_t next_id_ = 1;
     std::unordered_map<int64_t, Node*> nodes_;
-    std::unordered_set<Node*> pending_;                          // nodes without storage (lazy expressions)
+    Node pending_head_;                                          // circular list of the nodes without storage (lazy expressions)
+    void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; }
+    void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr; }
+    void pend_clear() { pending_head_.pend_prev = pending_head_.pend_next = &pending_head_; }
     std::vector<Node*> node_pool_;                               // recycled Node objects
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure
@@ -183,6 +193,7 @@ private:
     size_t ring_reserve(size_t bytes);
 
     Node* new_node(int64_t n);
+    void collect_pending(const fmhip_vec* roots, int n_roots, std::vector<Node*>& graph);      // pending nodes below the roots, in recording order
     Buffer* new_buffer(int64_t n_floats);
     void buffer_unref(Buffer* b);
     void node_unref_int(Node* nd);
@@ -225,7 +236,7 @@ void hip_check(hipError_t e, const char* what);
 // Host-side time accounting of the front-end (FMHIP_HOST_PROFILE=1 prints the table at shutdown): where the wall time of
 // a launch-bound caller (the LMM calibration: 31 000 method calls and 700 launches per objective evaluation) goes.
 struct HostProfile {
-    enum Slot { CALL, RELEASE, FLUSH, BUILD_DAG, RUN_DAGS, LAUNCH, LAUNCH_API, ROW_UPLOAD, REDUCE, FLUSH_COMPONENTS, BUILD_BIG, RUN_BIG, N_SLOTS };
+    enum Slot { CALL, RELEASE, FLUSH, BUILD_DAG, RUN_DAGS, LAUNCH, LAUNCH_API, ROW_UPLOAD, REDUCE, FLUSH_COMPONENTS, BUILD_BIG, RUN_BIG, CLONE, N_SLOTS };
     bool on = false;
     double seconds[N_SLOTS] = { 0 };
     long long count[N_SLOTS] = { 0 };

@@ -171,6 +171,15 @@ struct Backend {
     // component and step).  A group never spans a time index whose state a product reads (`keep`).  1 = one step at a time,
     // flushed every `chunk` components (the scheme of round 1).  The arithmetic per path is the same either way.
     int stepsPerLaunch = 2;
+    // Optional (lazily fusing back ends): replicate the PENDING expressions below `roots` once per entry of leafTo — copy c reads
+    // leafTo[c][i] wherever the original reads leafFrom[i] and takes its scalar operands, in recording order, from (*scalars)[c]
+    // (nullptr: the original's) — and return the copies of the roots (fmhip_graph_clone).  With it the parameter sets of a Jacobian
+    // batch are not recorded one by one: set 0 is, the others are copies (≈ 50 ns per operation instead of a method call through
+    // the mirror classes, a handle and a release).  recordedScalars: the scalar operands below `roots` as recorded, for the
+    // driver's check of its own scalar lists.  Results are bit-identical either way.
+    std::function<std::vector<std::vector<RV>>(const std::vector<RV>& roots, const std::vector<RV>& leafFrom, const std::vector<std::vector<RV>>& leafTo,
+                                               const std::vector<std::vector<double>>* scalars)> clone;
+    std::function<std::vector<double>(const std::vector<RV>& roots)> recordedScalars;
     int jacobianBatch = 1;                  // finite-difference bumps evaluated in lock-step (rows of the same launches)
 };
 
@@ -196,14 +205,19 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
     }
     std::vector<RV> factorSum(K);                                                        // Σ_k λ_k δ/(1+δ L_k): running over components
     const int S = std::max(1, be.stepsPerLaunch);
+    static int cloneChecks = 0;                                                          // the first groups verify the scalar lists against the recording
     for (int i0 = 0; i0 < lastTimeIndex;) {
         int i1 = std::min(i0 + S, lastTimeIndex);
         if (keep) for (int s2 = i0 + 1; s2 < i1; ++s2) if ((*keep)[(size_t)s2]) { i1 = s2; break; }   // a state somebody reads ends the group
+        // From time index 2 on every value of the state is a vector (L_0 is fixed at time 0, the bank account is constant until
+        // L_1 is): the group's pending graph has the same shape for every parameter set — record set 0, replicate the others.
+        const bool cloning = K > 1 && S > 1 && keep && be.clone && i0 >= 2;
+        const size_t Krec = cloning ? 1 : K;
         if (S > 1) be.hold(true);
         for (int i = i0; i < i1; ++i) {
             const double t = td.getTime(i), dt = td.getTimeStep(i);
             const RV dW = be.brownianMotion->getBrownianIncrement(i, 0);
-            for (size_t k = 0; k < K; ++k) {
+            for (size_t k = 0; k < Krec; ++k) {
                 auto& cur = sims[k].libor[(size_t)i];
                 auto& nxt = sims[k].libor[(size_t)i + 1];
                 nxt.resize((size_t)n);
@@ -212,7 +226,7 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
             }
             for (int j0 = i + 1; j0 < n; j0 += be.chunk) {
                 const int j1 = std::min(n, j0 + be.chunk);
-                for (size_t k = 0; k < K; ++k) {
+                for (size_t k = 0; k < Krec; ++k) {
                     auto& cur = sims[k].libor[(size_t)i];
                     auto& nxt = sims[k].libor[(size_t)i + 1];
                     for (int j = j0; j < j1; ++j) {
@@ -227,9 +241,51 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
                 }
                 if (S == 1 && j1 - j0 == be.chunk) be.flush();
             }
-            for (size_t k = 0; k < K; ++k)
+            for (size_t k = 0; k < Krec; ++k)
                 sims[k].numeraire[(size_t)i + 1] = sims[k].numeraire[(size_t)i]->accrue(sims[k].libor[(size_t)i][(size_t)i], delta);   // rolled-over bank account
-            for (size_t k = 0; k < K; ++k) factorSum[k] = nullptr;
+            for (size_t k = 0; k < Krec; ++k) factorSum[k] = nullptr;
+        }
+        if (cloning) {
+            // roots: the state at the end of the group (components that moved) and the bank account after every step;
+            // substituted operands: the state and the bank account at the start; scalars: what the loop above passed, in its order
+            std::vector<RV> roots, leafFrom;
+            for (int j = i0 + 1; j < n; ++j) roots.push_back(sims[0].libor[(size_t)i1][(size_t)j]);
+            for (int i = i0; i < i1; ++i) roots.push_back(sims[0].numeraire[(size_t)i + 1]);
+            for (int j = i0; j < n; ++j) leafFrom.push_back(sims[0].libor[(size_t)i0][(size_t)j]);
+            leafFrom.push_back(sims[0].numeraire[(size_t)i0]);
+            auto scalarsOf = [&](const VolatilityModel& vol) {
+                std::vector<double> sc;
+                for (int i = i0; i < i1; ++i) {
+                    const double t = td.getTime(i), dt = td.getTimeStep(i);
+                    for (int j = i + 1; j < n; ++j) {
+                        const double lambda = vol.volatility(t, td.getTime(j));
+                        // constant.discount(L, δ) = L·δ → +1 → (λδ)/·;  factor sum · λ;  L + drift·dt;  … + dW·λ
+                        sc.push_back(delta); sc.push_back(1.0); sc.push_back(lambda * delta); sc.push_back(lambda); sc.push_back(dt); sc.push_back(lambda);
+                    }
+                    sc.push_back(delta);                                                   // accrue(L_i, δ)
+                }
+                return sc;
+            };
+            if (cloneChecks < 64 && be.recordedScalars) {
+                ++cloneChecks;
+                if (be.recordedScalars(roots) != scalarsOf(*vols[0])) throw std::runtime_error("lmm: the scalar list of the replicated Euler steps does not match the recording");
+            }
+            std::vector<std::vector<RV>> leafTo(K - 1);
+            std::vector<std::vector<double>> scalars(K - 1);
+            for (size_t k = 1; k < K; ++k) {
+                for (int j = i0; j < n; ++j) leafTo[k - 1].push_back(sims[k].libor[(size_t)i0][(size_t)j]);
+                leafTo[k - 1].push_back(sims[k].numeraire[(size_t)i0]);
+                scalars[k - 1] = scalarsOf(*vols[k]);
+            }
+            const std::vector<std::vector<RV>> copies = be.clone(roots, leafFrom, leafTo, &scalars);
+            for (size_t k = 1; k < K; ++k) {
+                auto& nxt = sims[k].libor[(size_t)i1];
+                nxt.resize((size_t)n);
+                for (int j = 0; j <= i0 && j < n; ++j) nxt[(size_t)j] = sims[k].libor[(size_t)i0][(size_t)j];     // fixed before the group
+                size_t r = 0;
+                for (int j = i0 + 1; j < n; ++j) nxt[(size_t)j] = copies[k - 1][r++];
+                for (int i = i0; i < i1; ++i) sims[k].numeraire[(size_t)i + 1] = copies[k - 1][r++];
+            }
         }
         // states no product reads lose their handles BEFORE the flush: a pending value without a handle is an intermediate of the
         // fused launches, not an output (the state between the steps of a group is never materialised)
@@ -282,6 +338,26 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<co
     const auto t1 = clk::now();
     const long long l1 = be.launches();
     std::vector<std::vector<RV>> values(K);
+    if (K > 1 && be.clone) {
+        // the 144 payoff chains read the kept states and carry the same scalars for every parameter set: record set 0, replicate
+        be.hold(true);
+        values[0].reserve(m.swaptions.size());
+        for (const Swaption& s : m.swaptions) values[0].push_back(swaptionValue(m, sims[0], s));
+        std::vector<RV> leafFrom;
+        std::vector<std::vector<RV>> leafTo(K - 1);
+        for (int e = 0; e <= lastIndex; ++e) {
+            if (!keep[(size_t)e]) continue;
+            for (size_t k = 0; k < K; ++k) {
+                std::vector<RV>& dst = k == 0 ? leafFrom : leafTo[k - 1];
+                for (int j = e; j < m.numberOfLibors(); ++j) dst.push_back(sims[k].libor[(size_t)e][(size_t)j]);
+                dst.push_back(sims[k].numeraire[(size_t)e]);
+            }
+        }
+        const std::vector<std::vector<RV>> copies = be.clone(values[0], leafFrom, leafTo, nullptr);
+        for (size_t k = 1; k < K; ++k) values[k] = copies[k - 1];
+        be.hold(false);
+        be.flush();
+    } else
     for (size_t k = 0; k < K; ++k) {            // one parameter set at a time: its 144 products are rows enough per launch, and
         be.hold(true);                          // the device starts on set 0 while the host records set 1 (holding all K sets
         values[k].reserve(m.swaptions.size());  // gave the fastest op stream, 5.7 TB/s, but a 3 % slower calibration)

@@ -35,6 +35,39 @@ int main(int argc, char** argv) {
         if (o.chunk > 0) be.chunk = o.chunk;
         if (o.stepsPerLaunch > 0) be.stepsPerLaunch = o.stepsPerLaunch;
         be.jacobianBatch = o.jacobianBatch > 0 ? o.jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
+        if (!(std::getenv("FMHIP_LMM_CLONE") && std::getenv("FMHIP_LMM_CLONE")[0] == '0')) {  // =0: every parameter set recorded by hand (A/B measurement)
+            auto handleOf = [](const RV& x) {
+                auto p = dynamic_cast<const RandomVariableHip*>(x.get());
+                if (!p || p->isDeterministic()) throw std::runtime_error("graph replication over a value that is not a device vector");
+                return p->deviceVector().handle();
+            };
+            be.clone = [handleOf](const std::vector<RV>& roots, const std::vector<RV>& leafFrom, const std::vector<std::vector<RV>>& leafTo,
+                                  const std::vector<std::vector<double>>* scalars) {
+                const int nRoots = (int)roots.size(), nMap = (int)leafFrom.size(), nCopies = (int)leafTo.size();
+                std::vector<fmhip_vec> r, lf, lt, out((size_t)nRoots * nCopies);
+                for (const RV& x : roots) r.push_back(handleOf(x));
+                for (const RV& x : leafFrom) lf.push_back(handleOf(x));
+                for (const auto& row : leafTo) { if ((int)row.size() != nMap) throw std::runtime_error("graph replication: ragged operand map"); for (const RV& x : row) lt.push_back(handleOf(x)); }
+                std::vector<double> sc;
+                int nScalars = 0;
+                if (scalars) { nScalars = (int)(*scalars)[0].size(); for (const auto& row : *scalars) { if ((int)row.size() != nScalars) throw std::runtime_error("graph replication: ragged scalar lists"); sc.insert(sc.end(), row.begin(), row.end()); } }
+                check(fmhip_graph_clone(r.data(), nRoots, nCopies, lf.data(), lt.data(), nMap, scalars ? sc.data() : nullptr, nScalars, out.data()));
+                std::vector<std::vector<RV>> copies((size_t)nCopies);
+                for (int c = 0; c < nCopies; ++c)
+                    for (int k = 0; k < nRoots; ++k)
+                        copies[(size_t)c].push_back(RandomVariableHip::of(roots[(size_t)k]->getFiltrationTime(), DeviceVector(out[(size_t)c * nRoots + k]), roots[(size_t)k]->size()));
+                return copies;
+            };
+            be.recordedScalars = [handleOf](const std::vector<RV>& roots) {
+                std::vector<fmhip_vec> r;
+                for (const RV& x : roots) r.push_back(handleOf(x));
+                int n = 0;
+                check(fmhip_graph_scalars(r.data(), (int)r.size(), nullptr, 0, &n));
+                std::vector<double> sc((size_t)n);
+                check(fmhip_graph_scalars(r.data(), (int)r.size(), sc.data(), n, &n));
+                return sc;
+            };
+        }
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
 

@@ -190,6 +190,22 @@ int fmhip_flush(void);
  * parameter sets of a Jacobian — and want them batched as rows of the same launches.  Releasing the hold executes nothing
  * by itself.  Returns the previous setting through *previous (may be NULL). */
 int fmhip_fusion_hold(int hold, int* previous);
+/* Replicate PENDING expressions: a caller that is about to record the same chain of methods again with other vectors and other
+ * scalar operands — the next scenario, the next bumped parameter set of a Jacobian — records it ONCE and asks for copies.
+ * The graph = every pending (not yet executed) operation below `roots`.  Copy j reads leaf_to[j*n_map + i] wherever the
+ * original reads leaf_from[i] (operands outside the graph; operands not listed are shared by all copies), and takes its scalar
+ * operands from scalars[j*n_scalars + k], k counting the graph's scalar-carrying operations in the order they were recorded
+ * (scalars == NULL: the original's; otherwise n_scalars must equal the graph's count — see fmhip_graph_scalars).
+ * out[j*n_roots + r] receives the copy of roots[r] (a handle the caller releases); the inner values of a copy have no handle.
+ * Cost ≈ 50 ns per operation and copy, against one C call, one handle and one release per operation when recorded by hand.
+ * The copies are ordinary pending expressions: the next flush batches them with the original as rows of the same launches.
+ * Requires the fusion front-end (fmhip_set_fusion); results are bit-identical to recording each copy by hand. */
+int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies,
+                      const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
+                      const double* scalars, int n_scalars, fmhip_vec* out);
+/* The scalar operands of the pending graph below `roots`, in recording order: *n_scalars receives their number, the first
+ * min(capacity, number) go to scalars_out (may be NULL).  Lets a caller check its scalar list against what it recorded. */
+int fmhip_graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int capacity, int* n_scalars);
 
 /* Arithmetic mode of exp and log (everything else is identical in both modes):
  *   FMHIP_MATH_EXACT (default): evaluated in fp64 and narrowed once — bit-identical to the reference's CPU twin

@@ -5,9 +5,9 @@
 // builds it only when find_package(JNI) succeeds.  tests/test_jni_binding_cpu.py checks on every run that the set of functions
 // here, the native methods of java/net/finmath/hip/Native.java and the exports of include/fmhip.h are the same set.
 //
-// Marshalling rules: Java arrays are pinned with Get/ReleasePrimitiveArrayCritical around the ONE native call (no copy; the
-// engine narrows double → float itself, RandomVariableCuda.java:768-774); out-parameters are 1-element (or documented-length)
-// arrays; a null array where the C function accepts NULL is passed through as NULL.
+// Marshalling rules: whole-vector uploads / read-backs pin their ONE array with Get/ReleasePrimitiveArrayCritical (no copy; the
+// engine narrows double → float itself, RandomVariableCuda.java:768-774); everything else uses Get/Release<Type>ArrayElements;
+// out-parameters are 1-element (or documented-length) arrays; a null array where the C function accepts NULL is passed as NULL.
 #include <jni.h>
 #include <cstdint>
 #include <string>
@@ -16,13 +16,28 @@
 
 namespace {
 
-// RAII pin of a primitive Java array (may be null).
+// RAII access to the elements of a primitive Java array (may be null).  Pin<T> = Get/Release<Type>ArrayElements: may copy, and
+// other JNI calls (further arrays, GetArrayLength) stay legal while it is held — used wherever several arrays travel together.
+template <typename T> struct ArrayOps;
+template <> struct ArrayOps<jint>    { static jint*    get(JNIEnv* e, jarray a) { return e->GetIntArrayElements((jintArray)a, nullptr); }       static void put(JNIEnv* e, jarray a, jint* p, jint m)    { e->ReleaseIntArrayElements((jintArray)a, p, m); } };
+template <> struct ArrayOps<jlong>   { static jlong*   get(JNIEnv* e, jarray a) { return e->GetLongArrayElements((jlongArray)a, nullptr); }     static void put(JNIEnv* e, jarray a, jlong* p, jint m)   { e->ReleaseLongArrayElements((jlongArray)a, p, m); } };
+template <> struct ArrayOps<jdouble> { static jdouble* get(JNIEnv* e, jarray a) { return e->GetDoubleArrayElements((jdoubleArray)a, nullptr); } static void put(JNIEnv* e, jarray a, jdouble* p, jint m) { e->ReleaseDoubleArrayElements((jdoubleArray)a, p, m); } };
+template <> struct ArrayOps<jfloat>  { static jfloat*  get(JNIEnv* e, jarray a) { return e->GetFloatArrayElements((jfloatArray)a, nullptr); }   static void put(JNIEnv* e, jarray a, jfloat* p, jint m)  { e->ReleaseFloatArrayElements((jfloatArray)a, p, m); } };
 template <typename T>
 struct Pin {
-    JNIEnv* env; jarray arr; T* p; jint mode;
-    Pin(JNIEnv* e, jarray a, jint release_mode = 0) : env(e), arr(a), p(nullptr), mode(release_mode) { if (a) p = (T*)e->GetPrimitiveArrayCritical(a, nullptr); }
-    ~Pin() { if (arr && p) env->ReleasePrimitiveArrayCritical(arr, p, mode); }
-    jsize length() const { return arr ? env->GetArrayLength(arr) : 0; }
+    JNIEnv* env; jarray arr; T* p; jint mode; jsize len;
+    Pin(JNIEnv* e, jarray a, jint release_mode = 0) : env(e), arr(a), p(nullptr), mode(release_mode), len(a ? e->GetArrayLength(a) : 0) { if (a) p = ArrayOps<T>::get(e, a); }
+    ~Pin() { if (arr && p) ArrayOps<T>::put(env, arr, p, mode); }
+    jsize length() const { return len; }
+};
+// The bulk transfers (upload / read-back of a whole vector): ONE array, pinned without a copy around the one native call; its
+// length is read before the critical region begins and no other JNI function is called inside it.
+template <typename T>
+struct Critical {
+    JNIEnv* env; jarray arr; T* p; jint mode; jsize len;
+    Critical(JNIEnv* e, jarray a, jint release_mode = 0) : env(e), arr(a), p(nullptr), mode(release_mode), len(a ? e->GetArrayLength(a) : 0) { if (a) p = (T*)e->GetPrimitiveArrayCritical(a, nullptr); }
+    ~Critical() { if (arr && p) env->ReleasePrimitiveArrayCritical(arr, p, mode); }
+    jsize length() const { return len; }
 };
 
 // fmhip_prog_op[] from the parallel arrays of Native.programCreate / programSource
@@ -67,12 +82,12 @@ FMJ(jint, getStream)(JNIEnv* env, jclass, jlongArray stream) {
 
 // ---------------------------------------------------------------- vectors
 FMJ(jlong, vecCreateFromDouble)(JNIEnv* env, jclass, jdoubleArray values) {
-    Pin<jdouble> p(env, values, JNI_ABORT);
+    Critical<jdouble> p(env, values, JNI_ABORT);
     fmhip_vec out = 0;
     return fmhip_vec_create_from_double(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
 }
 FMJ(jlong, vecCreateFromFloat)(JNIEnv* env, jclass, jfloatArray values) {
-    Pin<jfloat> p(env, values, JNI_ABORT);
+    Critical<jfloat> p(env, values, JNI_ABORT);
     fmhip_vec out = 0;
     return fmhip_vec_create_from_float(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
 }
@@ -86,8 +101,8 @@ FMJ(jint, vecSize)(JNIEnv* env, jclass, jlong v, jlongArray size) {
     if (st == FMHIP_OK) set1(env, size, (jlong)n);
     return st;
 }
-FMJ(jint, vecReadDouble)(JNIEnv* env, jclass, jlong v, jdoubleArray out) { Pin<jdouble> p(env, out); return fmhip_vec_read_double(v, p.p, p.length()); }
-FMJ(jint, vecReadFloat)(JNIEnv* env, jclass, jlong v, jfloatArray out) { Pin<jfloat> p(env, out); return fmhip_vec_read_float(v, p.p, p.length()); }
+FMJ(jint, vecReadDouble)(JNIEnv* env, jclass, jlong v, jdoubleArray out) { Critical<jdouble> p(env, out); return fmhip_vec_read_double(v, p.p, p.length()); }
+FMJ(jint, vecReadFloat)(JNIEnv* env, jclass, jlong v, jfloatArray out) { Critical<jfloat> p(env, out); return fmhip_vec_read_float(v, p.p, p.length()); }
 FMJ(jint, vecDevicePtr)(JNIEnv* env, jclass, jlong v, jlongArray devicePointer) {
     void* ptr = nullptr;
     const int st = fmhip_vec_device_ptr(v, &ptr);
@@ -106,6 +121,17 @@ FMJ(jlong, callV3s0)(JNIEnv*, jclass, jint opcode, jlong a, jlong b, jlong c) { 
 FMJ(jint, setFusion)(JNIEnv* env, jclass, jint enabled, jintArray previous) { int prev = 0; const int st = fmhip_set_fusion(enabled, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 FMJ(jint, flush)(JNIEnv*, jclass) { return fmhip_flush(); }
 FMJ(jint, fusionHold)(JNIEnv* env, jclass, jint hold, jintArray previous) { int prev = 0; const int st = fmhip_fusion_hold(hold, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
+FMJ(jint, graphClone)(JNIEnv* env, jclass, jlongArray roots, jint nCopies, jlongArray leafFrom, jlongArray leafTo, jdoubleArray scalars, jint nScalars, jlongArray out) {
+    Pin<jlong> pr(env, roots, JNI_ABORT), pf(env, leafFrom, JNI_ABORT), pt(env, leafTo, JNI_ABORT), po(env, out); Pin<jdouble> ps(env, scalars, JNI_ABORT);
+    if (pt.length() < pf.length() * nCopies || po.length() < pr.length() * nCopies || (ps.p && ps.length() < nScalars * nCopies)) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_graph_clone((const fmhip_vec*)pr.p, pr.length(), nCopies, (const fmhip_vec*)pf.p, (const fmhip_vec*)pt.p, pf.length(), ps.p, nScalars, (fmhip_vec*)po.p);
+}
+FMJ(jint, graphScalars)(JNIEnv* env, jclass, jlongArray roots, jdoubleArray scalarsOut, jintArray count) {
+    int n = 0, st;
+    { Pin<jlong> pr(env, roots, JNI_ABORT); Pin<jdouble> ps(env, scalarsOut); st = fmhip_graph_scalars((const fmhip_vec*)pr.p, pr.length(), ps.p, ps.length(), &n); }
+    if (st == FMHIP_OK) set1(env, count, n);
+    return st;
+}
 FMJ(jint, setMathMode)(JNIEnv* env, jclass, jint mode, jintArray previous) { int prev = 0; const int st = fmhip_set_math_mode(mode, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 
 // ---------------------------------------------------------------- reductions

@@ -287,3 +287,56 @@ def test_flush_fuses_overlapping_results_into_one_multi_output_launch(gpu, oracl
         for k in range(K):
             assert (got[g][0][k] == outs[k].getRealizations()).all(), (g, k)
         assert (got[g][1] == s.getRealizations()).all()
+
+
+def test_graph_clone_equals_recording_by_hand(gpu, oracle):
+    """fmhip_graph_clone: a pending chain recorded ONCE and replicated with other vectors and other scalars gives, copy by copy,
+    the bits of the same chain recorded by hand — and the copies run as rows of the original's launches."""
+    n, copies = 20011, 5
+    rng = np.random.default_rng(7)
+    hosts = [[oracle.f_from_double(rng.uniform(0.1, 2.0, n)) for _ in range(3)] for _ in range(copies + 1)]
+    shared_host = oracle.f_from_double(rng.normal(0.0, 1.0, n))
+    scal = [[0.5 + 0.1 * j, 1.25 - 0.05 * j, 0.25, 0.3 + j] for j in range(copies + 1)]
+
+    def record(vecs, shared, s):
+        x, y, z = vecs
+        t = x.v2s1("DISCOUNT", y, s[0]).v1s1("MULT_S", s[1])                  # scalars in recording order: s[0], s[1], s[2], s[3]
+        u = t.v2s1("ADDPRODUCT_VS", shared, s[2]).v2s0("ADD", z)
+        w = u.v1s1("FLOOR_S", s[3] - 5.0).v1s0("SQUARED")
+        return [u, w]                                                          # two roots sharing t
+
+    prev = gpu.set_fusion(True)
+    try:
+        with gpu.holding():
+            shared = gpu.DeviceVector.from_host(shared_host)
+            dev = [[gpu.DeviceVector.from_host(a) for a in row] for row in hosts]
+            want = [record(dev[j], shared, scal[j]) for j in range(copies + 1)]       # by hand, every set
+            want_bits = None
+        gpu.flush()
+        want_bits = [[v.to_float32().view(np.uint32) for v in pair] for pair in want]
+        before = gpu.pool_stats().n_kernel_launches
+        with gpu.holding():
+            roots = record(dev[0], shared, scal[0])                                     # once …
+            rec = gpu.graph_scalars(roots)
+            assert list(rec) == [scal[0][0], scal[0][1], scal[0][2], scal[0][3] - 5.0]
+            clone_scalars = [[s[0], s[1], s[2], s[3] - 5.0] for s in scal[1:]]
+            got = gpu.graph_clone(roots, copies, leaf_from=dev[0], leaf_to=dev[1:], scalars=clone_scalars)      # … and replicated
+            same = gpu.graph_clone(roots, 1)                                            # no substitutions, the original's scalars
+        gpu.flush()
+        launches = gpu.pool_stats().n_kernel_launches - before
+        assert launches == 1                                                           # original + 6 copies: rows of ONE launch
+        for k in range(2):
+            assert (roots[k].to_float32().view(np.uint32) == want_bits[0][k]).all()
+            assert (same[0][k].to_float32().view(np.uint32) == want_bits[0][k]).all()
+            for j in range(copies):
+                assert (got[j][k].to_float32().view(np.uint32) == want_bits[j + 1][k]).all(), (j, k)
+        # errors: wrong number of scalars; a substituted operand inside the graph
+        with gpu.holding():
+            roots = record(dev[0], shared, scal[0])
+            with pytest.raises(gpu.FmhipError):
+                gpu.graph_clone(roots, 1, scalars=[[1.0, 2.0]])
+            with pytest.raises(gpu.FmhipError):
+                gpu.graph_clone(roots, 1, leaf_from=[roots[0]], leaf_to=[[dev[1][0]]])
+        gpu.flush()
+    finally:
+        gpu.set_fusion(prev)
