@@ -164,6 +164,10 @@ struct Backend {
     // all Monte-Carlo expectations of one objective evaluation (default: one getAverage() per product)
     std::function<std::vector<double>(const std::vector<RV>&)> averages = [](const std::vector<RV>& v) {
         std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
+    // Optional: ENQUEUE the expectations of one parameter set and return a function that waits for them.  With it the Jacobian
+    // batches of a Levenberg–Marquardt iteration are pipelined — the host records batch b+1 while the device still works on
+    // batch b, and reads b's expectations afterwards — instead of idling the device at every batch boundary.
+    std::function<std::function<std::vector<double>()>(const std::vector<RV>&)> averagesAsync;
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum); used when stepsPerLaunch == 1
     // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  With 2, the
     // engine's scheduler (runtime.cpp: build_big, consumers first) cuts the pending graph of two steps into launches of a few
@@ -324,10 +328,27 @@ inline double bachelierAtmImpliedVolatility(double optionValue, double optionMat
 
 struct Valuation { std::vector<double> modelVolatility; double seconds_simulation = 0, seconds_valuation = 0; long long launches_simulation = 0, launches_valuation = 0; };
 
-inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be) {
+// An objective evaluation of K parameter sets whose expectations have been enqueued but not read yet (Backend::averagesAsync).
+struct PendingValuations {
+    std::vector<std::function<std::vector<double>()>> expectations;     // per parameter set: waits for the 144 Monte-Carlo averages
+    std::vector<Valuation> out;
+};
+
+inline std::vector<Valuation> evaluateManyFinish(const Market& m, PendingValuations& p) {
+    for (size_t k = 0; k < p.out.size(); ++k) {
+        const std::vector<double> optionValues = p.expectations[k]();
+        for (size_t q = 0; q < m.swaptions.size(); ++q)
+            p.out[k].modelVolatility.push_back(bachelierAtmImpliedVolatility(optionValues[q], m.swaptions[q].exercise, m.swaptions[q].annuity));
+    }
+    return std::move(p.out);
+}
+
+inline PendingValuations evaluateManyBegin(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be) {
     using clk = std::chrono::steady_clock;
     const size_t K = vols.size();
-    std::vector<Valuation> out(K);
+    PendingValuations pending;
+    std::vector<Valuation>& out = pending.out;
+    out.resize(K);
     int lastIndex = 0;
     for (const Swaption& s : m.swaptions) lastIndex = std::max(lastIndex, m.timeDiscretization.getTimeIndex(s.exercise));
     const auto t0 = clk::now();
@@ -366,9 +387,8 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<co
         be.flush();
     }
     for (size_t k = 0; k < K; ++k) {
-        const std::vector<double> optionValues = be.averages(values[k]);
-        for (size_t q = 0; q < m.swaptions.size(); ++q)
-            out[k].modelVolatility.push_back(bachelierAtmImpliedVolatility(optionValues[q], m.swaptions[q].exercise, m.swaptions[q].annuity));
+        if (be.averagesAsync) pending.expectations.push_back(be.averagesAsync(values[k]));
+        else { const std::vector<double> now = be.averages(values[k]); pending.expectations.push_back([now] { return now; }); }
     }
     const auto t2 = clk::now();
     for (size_t k = 0; k < K; ++k) {            // statistics: the batch's totals, split evenly
@@ -376,7 +396,12 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<co
         out[k].seconds_simulation = std::chrono::duration<double>(t1 - t0).count() / (double)K;
         out[k].seconds_valuation = std::chrono::duration<double>(t2 - t1).count() / (double)K;
     }
-    return out;
+    return pending;
+}
+
+inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<const VolatilityModel*>& vols, const Backend& be) {
+    PendingValuations p = evaluateManyBegin(m, vols, be);
+    return evaluateManyFinish(m, p);
 }
 
 inline Valuation evaluate(const Market& m, const VolatilityModel& vol, const Backend& be) {
@@ -431,26 +456,45 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
     for (int it = 0; it < maxIterations; ++it) {
         // Jacobian by forward differences: one re-simulation per active parameter (common random numbers)
         std::vector<double> J((size_t)nr * np);
+        // The batches are independent of each other: batch b+1 is recorded and enqueued BEFORE the expectations of batch b are
+        // read, so the device never waits for the host at a batch boundary (with a back end that has no averagesAsync the
+        // expectations are simply computed inside Begin).
+        struct InFlight { int a0 = 0, a1 = 0; std::vector<VolatilityModel> bumped; PendingValuations pending; bool valid = false; };
+        auto collect = [&](InFlight& f) {
+            if (!f.valid) return;
+            const std::vector<Valuation> vals = evaluateManyFinish(m, f.pending);
+            for (int a = f.a0; a < f.a1; ++a) {
+                const Valuation& val = vals[(size_t)(a - f.a0)];
+                res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
+                for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility - r[(size_t)k]) / parameterStep;
+            }
+            f.valid = false;
+        };
+        InFlight previous;
         for (int a0 = 0; a0 < np; a0 += std::max(1, be.jacobianBatch)) {
             const int a1 = std::min(np, a0 + std::max(1, be.jacobianBatch));
-            std::vector<VolatilityModel> bumped((size_t)(a1 - a0), vol);
+            InFlight current;
+            current.a0 = a0; current.a1 = a1;
+            current.bumped.assign((size_t)(a1 - a0), vol);
             std::vector<const VolatilityModel*> ptrs;
-            for (int a = a0; a < a1; ++a) { bumped[(size_t)(a - a0)].parameter[(size_t)active[(size_t)a]] += parameterStep; ptrs.push_back(&bumped[(size_t)(a - a0)]); }
-            std::vector<Valuation> vals;
-            try { vals = evaluateMany(m, ptrs, be); }
+            for (int a = a0; a < a1; ++a) { current.bumped[(size_t)(a - a0)].parameter[(size_t)active[(size_t)a]] += parameterStep; ptrs.push_back(&current.bumped[(size_t)(a - a0)]); }
+            try { current.pending = evaluateManyBegin(m, ptrs, be); current.valid = true; }
             catch (const std::exception& e) {           // K simultaneous states did not fit the device: one by one instead
                 if (ptrs.size() == 1 || std::string(e.what()).find("allocation") == std::string::npos) throw;
                 if (verbose) std::fprintf(stderr, "  batch of %zu bumps does not fit (%s): evaluating them one at a time\n", ptrs.size(), e.what());
                 be.flush();
-                vals.clear();
-                for (const VolatilityModel* p1 : ptrs) vals.push_back(evaluate(m, *p1, be));
+                collect(previous);
+                for (int a = a0; a < a1; ++a) {
+                    const Valuation val = evaluate(m, current.bumped[(size_t)(a - a0)], be);
+                    res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
+                    for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility - r[(size_t)k]) / parameterStep;
+                }
+                continue;
             }
-            for (int a = a0; a < a1; ++a) {
-                const Valuation& val = vals[(size_t)(a - a0)];
-                res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
-                for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility - r[(size_t)k]) / parameterStep;
-            }
+            collect(previous);
+            previous = std::move(current);
         }
+        collect(previous);
         std::vector<double> JtJ((size_t)np * np, 0.0), Jtr((size_t)np, 0.0);
         for (int a = 0; a < np; ++a) {
             for (int b = 0; b < np; ++b) { double s = 0; for (int k = 0; k < nr; ++k) s += J[(size_t)k * np + a] * J[(size_t)k * np + b]; JtJ[(size_t)a * np + b] = s; }

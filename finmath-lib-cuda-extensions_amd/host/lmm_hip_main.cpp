@@ -70,6 +70,29 @@ int main(int argc, char** argv) {
         }
         be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
         be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
+        if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))    // =0: every batch's expectations read before the next batch is recorded (A/B)
+            be.averagesAsync = [](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
+                std::vector<fmhip_vec> h;
+                int64_t n = 0;
+                for (const RV& x : v) {
+                    auto p = dynamic_cast<const RandomVariableHip*>(x.get());
+                    if (!p || p->isDeterministic()) { const std::vector<double> now = getAverages(v); return [now] { return now; }; }      // not all device vectors: no pipelining
+                    h.push_back(p->deviceVector().handle()); n = p->size();
+                }
+                const int count = (int)h.size();
+                fmhip_vec buf = 0;
+                check(fmhip_vec_create_uninitialized((int64_t)count * 8, &buf));     // count x {Σ, Σ², min, max} doubles, written by the reduction launch
+                void* dev = nullptr; check(fmhip_vec_device_ptr(buf, &dev));
+                check(fmhip_reduce_moments_batch_device(h.data(), count, nullptr, dev));       // enqueued; nobody waits
+                auto owner = std::make_shared<DeviceVector>(buf);
+                return [owner, count, n] {
+                    std::vector<float> raw((size_t)count * 8);
+                    check(fmhip_vec_read_float(owner->handle(), raw.data(), (int64_t)raw.size()));     // the only synchronisation of the evaluation
+                    std::vector<double> out((size_t)count);
+                    for (int k = 0; k < count; ++k) { double s; std::memcpy(&s, &raw[(size_t)k * 8], 8); out[(size_t)k] = s / (double)n; }
+                    return out;
+                };
+            };
 
         ncclComm_t comm = nullptr;
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)
@@ -105,6 +128,7 @@ int main(int argc, char** argv) {
             void* stream = nullptr; check(fmhip_get_stream(&stream));
             const int64_t totalPaths = (int64_t)o.world * o.paths;
             const int world = o.world, rank = o.rank;
+            be.averagesAsync = nullptr;                  // sharded: the gather buffer is shared between evaluations, expectations are read at once
             be.averages = [=, &collectives, &collective_seconds](const std::vector<RV>& v) {
                 std::vector<fmhip_vec> h;
                 for (const RV& x : v) {
