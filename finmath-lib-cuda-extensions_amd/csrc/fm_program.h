@@ -103,6 +103,17 @@ struct DevProgramArgs {
 };
 
 static_assert(sizeof(DevProgramArgs) <= 4096, "kernel arguments are limited to 4 KB");
+
+// Arguments of a ROLLED-LOOP kernel (runtime.cpp: rolled components): the body of one iteration is compiled into the kernel, the
+// iteration count and everything that differs between iterations (vector pointers, scalar operands) come from the row table:
+//   row = [G global input ptrs][CI carried-in ptrs][iterations x {LI input ptrs, LO output ptrs}][iterations x LS scalars (float)]
+struct DevRolledArgs {
+    int64_t  n;                          // elements per vector
+    uint32_t tiles_per_row;              // passes of FM_BLOCK*E elements
+    uint32_t row_words;                  // row stride in 8-byte words
+    uint32_t iterations;
+    uint32_t pad;
+};
 static_assert(FM_INLINE_WORDS >= FM_ROW_WORDS_MAX, "one row always fits");
 
 } // namespace fm

@@ -54,6 +54,8 @@ public:
     void quiesce();                                            // joins the worker only (process exit: no HIP calls)
     // Returns the (shared) slot of this program; compiles synchronously when `sync`, else queues it for the worker.
     std::shared_ptr<JitSlot> request(const DevProgramArgs& proto, bool sync);
+    // The same for a kernel pair given as source text (rolled loops, runtime.cpp): `elems` = elements per lane and pass.
+    std::shared_ptr<JitSlot> request_source(std::string source, int elems, bool sync);
     void wait_idle();                                          // until the queue is drained
     JitStats stats();
 private:

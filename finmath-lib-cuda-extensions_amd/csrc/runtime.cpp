@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <map>
+#include <sstream>
 #include <unordered_set>
 
 namespace fm {
@@ -142,7 +144,7 @@ void Engine::init(int device_index) {
     }
     hip_check(hipSetDevice(device_index), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
-    ring_cap_ = size_t(4) << 20;
+    ring_cap_ = size_t(32) << 20;                // row tables of rolled loops are ≈ 5 KB per row: room for hundreds of launches between wraps
     if (const char* e = std::getenv("FMHIP_RING_BYTES")) {      // tests shrink the ring so that a wrap costs a few launches, not thousands
         const long long v = std::atoll(e);
         if (v >= 4096) ring_cap_ = ((size_t)v + 255) & ~size_t(255);
@@ -946,6 +948,7 @@ struct Engine::BigDag {
     std::vector<Node*> roots;
     std::vector<Node*> order;       // all pending nodes of the component, operands before users
     std::vector<Node*> leaves;      // distinct materialised inputs, in discovery order (structural: equal for equal shapes)
+    std::vector<char> escapes;      // per node of the order: needed outside the component (a handle, or a consumer elsewhere)
     std::string sig;                // shape: per op {opcode, operand ids (16 bit), escapes?}
     uint64_t hash = 0;              // of sig
 };
@@ -1017,7 +1020,9 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
         nd->tmp_id = (int)i;
         big.sig.push_back((char)nd->opcode);
         for (int k = 0; k < 3; ++k) put16(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0);
-        big.sig.push_back((nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) ? 'x' : '.');      // needed outside the component
+        const bool escapes = nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses;                    // needed outside the component
+        big.escapes.push_back(escapes ? 1 : 0);
+        big.sig.push_back(escapes ? 'x' : '.');
     }
     uint64_t h = 0x9e3779b97f4a7c15ull;               // 8 bytes at a time (the signature has 8 bytes per node plus one)
     const char* p = big.sig.data();
@@ -1109,6 +1114,288 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
         }
 }
 
+// ---------------------------------------------------------------- rolled loops
+//
+// The scheduled order of a large component is often PERIODIC: the same few operations over one vector after another, each
+// iteration feeding the next through a value or two — the running factor sum over the LIBOR components of an Euler step, a
+// swap's backward induction over its periods.  Cut into launches of ≤ 12 inputs / 8 outputs such a stretch moves ≈ 1.5 vectors
+// per iteration and step and costs a launch every six iterations.  Rolled up it is ONE launch: the body of one iteration is
+// compiled (hiprtc) into a kernel that loops over the iterations, keeps the carried values in registers, loads each iteration's
+// inputs while it computes the previous one and stores each result the moment it is final; iteration count, vector pointers and
+// scalar operands come from the row table, so one kernel serves every component count.  Every operation is evaluated by the
+// same ueval<> functions in the same order per element as in the segmented launches: results are bit-identical, and until the
+// kernel is compiled (or with FMHIP_JIT=off / FMHIP_ROLL=0) the segmented launches run.
+
+static inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
+
+#define ROLL_TRACE(...) do { if (roll_trace) std::fprintf(stderr, __VA_ARGS__); } while (0)
+bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, std::string* source, int* elems_out)
+{
+    static const bool roll_trace = std::getenv("FMHIP_ROLL_TRACE") != nullptr;
+    const size_t n = g.order.size();
+    ROLL_TRACE("[fmhip roll] component of %zu nodes, %zu leaves\n", n, g.leaves.size());
+    const int MAX_PERIOD = 128, MIN_ITERATIONS = 5, GLOBAL_SPAN = MAX_PERIOD;      // an input of ONE iteration has all its uses less than a period apart
+    if (n < 48) return false;
+    std::vector<int32_t> first_use(g.leaves.size(), -1), last_leaf_use(g.leaves.size(), -1);
+    std::vector<uint32_t> last_use(n, 0);                       // largest consumer index; n = needed outside the component
+    for (size_t i = 0; i < n; ++i) {
+        if (g.escapes[i]) last_use[i] = (uint32_t)n;
+        for (int k = 0; k < g.order[i]->n_in; ++k) {
+            const int32_t o = operand[i][(size_t)k];
+            if (o < 0) { const size_t l = (size_t)(-1 - o); if (first_use[l] < 0) first_use[l] = (int32_t)i; last_leaf_use[l] = (int32_t)i; }
+            else if (last_use[(size_t)o] < (uint32_t)i) last_use[(size_t)o] = (uint32_t)i;
+        }
+    }
+    auto is_global = [&](size_t l) { return last_leaf_use[l] - first_use[l] >= GLOBAL_SPAN; };
+    // position-independent signature of every node: what it does, how far back its operands are, whether it escapes
+    std::vector<uint64_t> sig(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Node* nd = g.order[i];
+        uint64_t h = mix64(0x1234, (uint64_t)nd->opcode * 8 + (uint64_t)nd->n_in * 2 + (g.escapes[i] ? 1 : 0));
+        for (int k = 0; k < nd->n_in; ++k) {
+            const int32_t o = operand[i][(size_t)k];
+            if (o >= 0) h = mix64(h, 0x100000000ull + (uint64_t)((int64_t)i - o));
+            else { const size_t l = (size_t)(-1 - o); h = is_global(l) ? mix64(h, 0x200000000ull + l) : mix64(h, 0x300000000ull + (uint64_t)((int64_t)i - first_use[l])); }
+        }
+        sig[i] = h;
+    }
+    // the periodic stretch that covers the most nodes
+    size_t best_start = 0, best_cover = 0; int best_period = 0;
+    for (int P = 3; P <= MAX_PERIOD && (size_t)P * MIN_ITERATIONS <= n; ++P) {
+        size_t run_start = 0, run = 0;
+        for (size_t i = 0; i + (size_t)P <= n; ++i) {
+            const bool match = i + (size_t)P < n && sig[i] == sig[i + (size_t)P];
+            if (match) { if (run == 0) run_start = i; ++run; }
+            if (!match || i + (size_t)P + 1 >= n) {
+                if (run > 0) { const size_t cover = (run + (size_t)P) / (size_t)P * (size_t)P; if (cover > best_cover) { best_cover = cover; best_start = run_start; best_period = P; } }
+                run = 0;
+            }
+        }
+    }
+    ROLL_TRACE("[fmhip roll]   best period %d, start %zu, cover %zu\n", best_period, best_start, best_cover);
+    if (best_period == 0 || best_cover / (size_t)best_period < (size_t)MIN_ITERATIONS) return false;
+    const uint32_t P = (uint32_t)best_period;
+    // phase: any rotation of the period is periodic too; take the one with the fewest values crossing the iteration boundary
+    uint32_t best_phase = 0; size_t best_carried = SIZE_MAX;
+    for (uint32_t phase = 0; phase < P; ++phase) {
+        const size_t b = best_start + P + phase;                // second detected iteration: its predecessors exist
+        if (b + P > best_start + best_cover) break;
+        std::unordered_set<int32_t> crossing;
+        bool ok = true;
+        for (uint32_t q = 0; q < P && ok; ++q)
+            for (int k = 0; k < g.order[b + q]->n_in; ++k) {
+                const int32_t o = operand[b + q][(size_t)k];
+                if (o < 0) {                                    // an input of one iteration must not straddle the boundary either
+                    const size_t l = (size_t)(-1 - o);
+                    if (!is_global(l) && ((size_t)first_use[l] < b || (size_t)last_leaf_use[l] >= b + P)) { ok = false; break; }
+                    continue;
+                }
+                const int64_t d = (int64_t)(b + q) - o;
+                if (d > (int64_t)q) { if (d > (int64_t)q + P) { ok = false; break; } crossing.insert(o); }
+            }
+        if (ok && crossing.size() < best_carried) { best_carried = crossing.size(); best_phase = phase; }
+    }
+    ROLL_TRACE("[fmhip roll]   phase %u, %zu values cross the iteration boundary\n", best_phase, best_carried == SIZE_MAX ? (size_t)0 : best_carried);
+    if (best_carried == SIZE_MAX) return false;
+    const size_t begin = best_start + P + best_phase;
+    const size_t R = (best_start + best_cover - begin) / P;
+    if (R < (size_t)MIN_ITERATIONS - 1) return false;
+    const size_t end = begin + R * P;
+    // validate every iteration; collect the body's interface from the first one
+    std::vector<char> out_needed(P, 0), final_needed(P, 0);
+    for (size_t r = 0; r < R; ++r)
+        for (uint32_t q = 0; q < P; ++q) {
+            const size_t i = begin + r * P + q;
+            if (sig[i] != sig[begin + q]) { ROLL_TRACE("[fmhip roll]   aperiodic at iteration %zu position %u\n", r, q); return false; }
+            for (int k = 0; k < g.order[i]->n_in; ++k) {
+                const int32_t o = operand[i][(size_t)k];
+                if (o >= 0) { const int64_t d = (int64_t)i - o; if (d > (int64_t)q + P) { ROLL_TRACE("[fmhip roll]   operand further back than one iteration (iteration %zu position %u)\n", r, q); return false; } }
+                else {
+                    const size_t l = (size_t)(-1 - o);
+                    if (!is_global(l) && ((size_t)first_use[l] < begin + r * P || (size_t)last_leaf_use[l] >= begin + (r + 1) * P)) {   // an input of exactly one iteration
+                        ROLL_TRACE("[fmhip roll]   input used by more than one iteration (iteration %zu position %u, span %d)\n", r, q, last_leaf_use[l] - first_use[l]); return false; }
+                }
+            }
+            // consumers in the same and in the next iteration are served from registers; anybody later (or outside) needs the vector
+            const size_t reach = r + 1 < R ? begin + (r + 2) * P : end;
+            if (last_use[i] >= reach) { if (r + 1 == R && !g.escapes[i]) final_needed[q] = 1; else out_needed[q] = 1; }     // last iteration only: stored once, behind the loop
+        }
+    ro = BigPlan::Rolled();
+    ro.begin = (uint32_t)begin; ro.period = P; ro.iterations = (uint32_t)R;
+    std::vector<int> carried_index(P, -1), global_index(g.leaves.size(), -1);
+    std::vector<std::array<std::string, 3>> name(P);              // operand names of the body
+    bool library_math = false, uses_log = false;
+    int n_local_leaf = 0;
+    std::unordered_map<size_t, int> local_leaf;                      // leaf -> per-iteration input number (first iteration's leaves)
+    for (uint32_t q = 0; q < P; ++q) {
+        const size_t i = begin + q;
+        const Node* nd = g.order[i];
+        library_math |= nd->opcode == FMHIP_OP_POW_S || nd->opcode == FMHIP_OP_SIN || nd->opcode == FMHIP_OP_COS || nd->opcode == FMHIP_OP_EXP || nd->opcode == FMHIP_OP_LOG;
+        uses_log |= nd->opcode == FMHIP_OP_LOG && math_mode != FMHIP_MATH_FAST;
+        if (op_info(nd->opcode).scalar) ro.scal_pos.push_back(q);
+        if (out_needed[q]) ro.out_pos.push_back(q);
+        else if (final_needed[q]) ro.final_pos.push_back(q);
+        for (int k = 0; k < nd->n_in; ++k) {
+            const int32_t o = operand[i][(size_t)k];
+            if (o >= 0) {
+                const int64_t d = (int64_t)i - o;
+                if (d <= (int64_t)q) name[q][(size_t)k] = "v" + std::to_string(q - (uint32_t)d);
+                else {
+                    const uint32_t src = q + P - (uint32_t)d;
+                    if (carried_index[src] < 0) { carried_index[src] = (int)ro.carried.size(); ro.carried.push_back(src); }
+                    name[q][(size_t)k] = "c" + std::to_string(carried_index[src]);
+                }
+            } else {
+                const size_t l = (size_t)(-1 - o);
+                if (is_global(l)) {
+                    if (global_index[l] < 0) { global_index[l] = (int)ro.global_leaf.size(); ro.global_leaf.push_back((int32_t)l); }
+                    name[q][(size_t)k] = "g" + std::to_string(global_index[l]);
+                } else {
+                    auto it = local_leaf.find(l);
+                    if (it == local_leaf.end()) { it = local_leaf.emplace(l, n_local_leaf++).first; ro.leaf_in.push_back({ q, (uint32_t)k }); }
+                    name[q][(size_t)k] = "l" + std::to_string(it->second);
+                }
+            }
+        }
+    }
+    const size_t G = ro.global_leaf.size(), CI = ro.carried.size(), CO = ro.final_pos.size(), LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size();
+    ROLL_TRACE("[fmhip roll]   begin %zu, %zu iterations of %u: %zu global, %zu carried, %zu in, %zu out, %zu scalars\n", begin, R, P, G, CI, LI, LO, LS);
+    if (G > 8 || CI > 12 || CO > 12 || LI > 12 || LO > 12 || LO + CO == 0 || LS > 48) return false;
+    ro.row_words = (uint32_t)(G + CI + CO + R * (LI + LO) + (R * LS + 1) / 2);
+    // ---- the kernel
+    const int E = library_math ? 4 : 8;
+    *elems_out = E;
+    std::ostringstream o;
+    o << "#include \"fm_kernel_parts.hpp\"\n"
+      << "// rolled loop: period " << P << ", " << G << " global inputs, " << CI << " carried values, " << CO << " final values, per iteration " << LI << " inputs, " << LO << " outputs, " << LS << " scalars\n"
+      << "extern \"C\" __global__ void fm_jit_inline(const fm::DevRolledArgs A, const uint64_t* __restrict__ rows) {}\n"
+      << "extern \"C\" __global__ void __launch_bounds__(fm::FM_BLOCK) fm_jit_table(const fm::DevRolledArgs A, const uint64_t* __restrict__ rows)\n{\n"
+      << "    using namespace fm;\n    constexpr int E = " << E << ", T = E / FM_VEC;\n"
+      << "    const uint64_t* __restrict__ rowp = rows + (size_t)blockIdx.y * A.row_words;\n"
+      << "    const uint32_t R = A.iterations;\n    const int64_t n = A.n;\n"
+      << "    const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + " << (G + CI + CO) << " + (size_t)R * " << (LI + LO) << ");\n";
+    if (uses_log) o << "    log_table_init();\n";
+    o << "    const uint32_t tiles_per_block = (A.tiles_per_row + gridDim.x - 1u) / gridDim.x;\n"
+      << "    const uint32_t tile_begin = blockIdx.x * tiles_per_block;\n"
+      << "    const uint32_t tile_end = tile_begin + tiles_per_block < A.tiles_per_row ? tile_begin + tiles_per_block : A.tiles_per_row;\n"
+      << "    for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {\n"
+      << "        uint32_t i4[T], i4c[T]; bool lane_valid[T];\n"
+      << "        _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { i4[t] = (tile * T + t) * FM_BLOCK + threadIdx.x; lane_valid[t] = (int64_t)i4[t] * FM_VEC < n; i4c[t] = lane_valid[t] ? i4[t] : 0u; }\n";
+    auto load_into = [&](const std::string& dst, const std::string& ptr_expr, const char* indent) {
+        o << indent << "{ const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(" << ptr_expr << "); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = load_stream(p, i4c[t]); "
+          << dst << "[4 * t] = x.x; " << dst << "[4 * t + 1] = x.y; " << dst << "[4 * t + 2] = x.z; " << dst << "[4 * t + 3] = x.w; } }\n";
+    };
+    for (size_t k = 0; k < G; ++k) { o << "        float g" << k << "[E];\n"; load_into("g" + std::to_string(k), "rowp[" + std::to_string(k) + "]", "        "); }
+    for (size_t k = 0; k < CI; ++k) { o << "        float c" << k << "[E];\n"; load_into("c" + std::to_string(k), "rowp[" + std::to_string(G + k) + "]", "        "); }
+    for (size_t m = 0; m < LI; ++m)
+        o << "        f32x4 nx" << m << "[T];\n        { const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[" << (G + CI + CO + m)
+          << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) nx" << m << "[t] = load_stream(p, i4c[t]); }\n";
+    for (size_t k = 0; k < CO; ++k) o << "        float f" << k << "[E];\n";
+    o << "        for (uint32_t it = 0; it < R; ++it) {\n"
+      << "            const uint64_t* __restrict__ ip = rowp + " << (G + CI + CO) << " + (size_t)it * " << (LI + LO) << ";\n"
+      << "            const float* __restrict__ sc = scal + (size_t)it * " << LS << ";\n";
+    for (size_t m = 0; m < LI; ++m)
+        o << "            float l" << m << "[E];\n            _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { l" << m << "[4 * t] = nx" << m << "[t].x; l" << m << "[4 * t + 1] = nx" << m << "[t].y; l"
+          << m << "[4 * t + 2] = nx" << m << "[t].z; l" << m << "[4 * t + 3] = nx" << m << "[t].w; }\n";
+    if (LI > 0) {
+        o << "            if (it + 1u < R) {\n";                   // the next iteration's inputs travel while this one is computed
+        for (size_t m = 0; m < LI; ++m)
+            o << "                { const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(ip[" << (LI + LO + m) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) nx" << m << "[t] = load_stream(p, i4c[t]); }\n";
+        o << "            }\n";
+    }
+    int slot = 0;
+    for (uint32_t q = 0; q < P; ++q) {
+        const Node* nd = g.order[begin + q];
+        UVariant uv{};
+        if (!variant_for(nd->opcode, 0, &uv)) return false;
+        uint32_t uop = uv.uop;
+        if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
+        const std::string x0 = name[q][0], x1 = uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] + "[j]" : std::string("0.f"), x2 = uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] + "[j]" : std::string("0.f");
+        const std::string s_arg = op_info(nd->opcode).scalar ? "sc[" + std::to_string(slot++) + "]" : std::string("0.f");
+        o << "            float v" << q << "[E];\n";
+        if (uop == U_SQRT)
+            o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = " << x0 << "[j];\n            sqrt_all<E>(v" << q << ");\n";
+        else
+            o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = ueval<" << uop << "u>(" << x0 << "[j], " << x1 << ", " << x2 << ", " << s_arg << ");\n";
+    }
+    for (size_t m = 0; m < LO; ++m)
+        o << "            { gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(ip[" << (LI + m) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = { v" << ro.out_pos[m]
+          << "[4 * t], v" << ro.out_pos[m] << "[4 * t + 1], v" << ro.out_pos[m] << "[4 * t + 2], v" << ro.out_pos[m] << "[4 * t + 3] }; if (lane_valid[t]) store_stream(q, i4[t], x); } }\n";
+    for (size_t k = 0; k < CI; ++k)
+        o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) c" << k << "[j] = v" << ro.carried[k] << "[j];\n";
+    for (size_t k = 0; k < CO; ++k)
+        o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) f" << k << "[j] = v" << ro.final_pos[k] << "[j];\n";
+    o << "        }\n";
+    for (size_t k = 0; k < CO; ++k)                                  // values of the LAST iteration that somebody behind the loop reads
+        o << "        { gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(rowp[" << (G + CI + k) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = { f" << k
+          << "[4 * t], f" << k << "[4 * t + 1], f" << k << "[4 * t + 2], f" << k << "[4 * t + 3] }; if (lane_valid[t]) store_stream(q, i4[t], x); } }\n";
+    o << "    }\n}\n";
+    *source = o.str();
+    return true;
+}
+
+// One launch for the rolled stretch of every member of a group: row tables by index, launch, commit.
+void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count)
+{
+    const size_t G = ro.global_leaf.size(), CI = ro.carried.size(), CO = ro.final_pos.size(), LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size();
+    const size_t R = ro.iterations, P = ro.period, rw = ro.row_words;
+    const int64_t n = group[first].order[ro.begin]->n;
+    std::vector<uint64_t> table(count * rw, 0);
+    std::vector<Buffer*> out_bufs;
+    out_bufs.reserve(count * (R * LO + CO));
+    auto ptr_of = [](Node* nd) -> uint64_t {
+        if (!nd->buf) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "rolled loop reads a value that has not been computed");
+        return (uint64_t)(uintptr_t)nd->buf->ptr;
+    };
+    try {
+        for (size_t c = 0; c < count; ++c) {
+            BigDag& big = group[first + c];
+            uint64_t* row = table.data() + c * rw;
+            for (size_t k = 0; k < G; ++k) row[k] = ptr_of(big.leaves[(size_t)ro.global_leaf[k]]);
+            for (size_t k = 0; k < CI; ++k) row[G + k] = ptr_of(big.order[ro.begin - P + ro.carried[k]]);       // the iteration before the loop ran as ordinary launches
+            float* sc = reinterpret_cast<float*>(row + G + CI + CO + R * (LI + LO));
+            for (size_t r = 0; r < R; ++r) {
+                uint64_t* ip = row + G + CI + CO + r * (LI + LO);
+                const size_t base = ro.begin + r * P;
+                for (size_t m = 0; m < LI; ++m) ip[m] = ptr_of(big.order[base + ro.leaf_in[m].first]->in[ro.leaf_in[m].second]);
+                for (size_t m = 0; m < LO; ++m) { Buffer* b = new_buffer(n); out_bufs.push_back(b); ip[LI + m] = (uint64_t)(uintptr_t)b->ptr; }
+                for (size_t m = 0; m < LS; ++m) sc[r * LS + m] = (float)big.order[base + ro.scal_pos[m]]->scalar;
+            }
+            for (size_t k = 0; k < CO; ++k) { Buffer* b = new_buffer(n); out_bufs.push_back(b); row[G + CI + k] = (uint64_t)(uintptr_t)b->ptr; }    // after the per-iteration outputs, in this order
+        }
+        if (n > 0) {
+            const int64_t elems_per_pass = (int64_t)FM_BLOCK * ro.jit->elems;
+            const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
+            DevRolledArgs args{};
+            args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = (uint32_t)R;
+            const size_t table_bytes = table.size() * 8;
+            const size_t ring_off = ring_reserve(table_bytes);
+            std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
+            hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "rolled row table H2D");
+            const uint64_t* rows_arg = (const uint64_t*)((char*)ring_dev_ + ring_off);
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
+            void* params[] = { &args, &rows_arg };
+            hip_check(hipModuleLaunchKernel(ro.jit->fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch rolled kernel");
+            if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                              profile_tags_.push_back({ (int)(R * P), (int)(G + CI + R * LI), (int)(R * LO + CO), 0, (int)count, 2, n }); }
+            n_launches_++; n_jit_launches_++; n_rolled_launches_++;
+            n_ops_executed_ += (int64_t)(R * P) * (int64_t)count;
+            algorithmic_bytes_ += 4 * n * (int64_t)(G + CI + CO + R * (LI + LO)) * (int64_t)count;
+        }
+    } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
+    // commit (as run_dags): outputs become materialised vectors; their expressions (and the inner values) go away
+    size_t k = 0;
+    std::vector<Node*> outs;
+    outs.reserve(out_bufs.size());
+    for (size_t c = 0; c < count; ++c) {
+        for (size_t r = 0; r < R; ++r)
+            for (size_t m = 0; m < LO; ++m) { Node* nd = group[first + c].order[ro.begin + r * P + ro.out_pos[m]]; nd->buf = out_bufs[k++]; pend_erase(nd); outs.push_back(nd); }
+        for (size_t m = 0; m < CO; ++m) { Node* nd = group[first + c].order[ro.begin + (R - 1) * P + ro.final_pos[m]]; nd->buf = out_bufs[k++]; pend_erase(nd); outs.push_back(nd); }
+    }
+    for (Node* nd : outs) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
+}
+
 void Engine::run_big_group(std::vector<BigDag>& group) {
     HostTimer timer(HostProfile::RUN_BIG);
     BigDag& g0 = group[0];
@@ -1118,8 +1405,19 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
     if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
     const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
     if (planned != plan_cache_.end()) {
-        for (const BigPlan::Seg& seg : planned->second.segs)
+        BigPlan& plan = planned->second;
+        if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
+            plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
+        const bool rolled = plan.rolled.present && jit_mode != FMHIP_JIT_OFF && plan.rolled.jit && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::READY;
+        bool rolled_done = false;
+        for (const BigPlan::Seg& seg : plan.segs) {
+            if (rolled && seg.zone == 1) {              // the loop's stretch: one launch of the rolled kernel instead of its segments
+                if (!rolled_done) for (size_t off = 0; off < group.size(); off += max_batch) run_rolled(plan.rolled, group, off, std::min(max_batch, group.size() - off));
+                rolled_done = true;
+                continue;
+            }
             for (size_t off = 0; off < group.size(); off += max_batch) run_planned_segment(seg, group, off, std::min(max_batch, group.size() - off));
+        }
         return;
     }
     // First component of this shape: find the cuts (longest segment that fits one launch, again and again), run it through the
@@ -1129,14 +1427,32 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
     for (size_t i = 0; i < n_ops; ++i) index_of[g0.order[i]] = (int32_t)i;
     for (size_t i = 0; i < g0.leaves.size(); ++i) index_of[g0.leaves[i]] = -1 - (int32_t)i;
     BigPlan plan;
+    // A periodic stretch of the order becomes a rolled loop (one launch) as soon as its kernel is compiled; the segments cut
+    // below remain its fallback, with cuts forced at the loop's ends so that either form can run between them.
+    static const bool ROLL = [] { const char* e = std::getenv("FMHIP_ROLL"); return !(e && e[0] == '0'); }();
+    size_t zone_begin = n_ops, zone_end = n_ops;
+    if (ROLL) {
+        std::vector<std::array<int32_t, 3>> operand(n_ops);
+        for (size_t i = 0; i < n_ops; ++i)
+            for (int k = 0; k < g0.order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(g0.order[i]->in[k]);
+        std::string source; int elems = 0;
+        if (detect_loop(g0, operand, plan.rolled, &source, &elems)) {
+            if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
+            plan.rolled.present = true;
+            plan.rolled.source = source; plan.rolled.elems = elems;
+            if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit_.request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
+            zone_begin = plan.rolled.begin; zone_end = zone_begin + (size_t)plan.rolled.period * plan.rolled.iterations;
+        }
+    }
     size_t s = 0;
     while (s < n_ops) {
         size_t e = 0;
+        const size_t limit = s < zone_begin ? zone_begin : (s < zone_end ? zone_end : n_ops);      // a segment never crosses an end of the loop
         {
             // longest segment starting at s that fits one launch.  Inputs grow monotonically with the end; outputs and live
             // values do not: collect every end that passes the cheap checks, then take the largest one that also compiles.
             std::vector<size_t> cheap;
-            for (size_t cand = s + 1; cand <= n_ops && cand - s <= (size_t)FM_MAX_OPS; ++cand) {
+            for (size_t cand = s + 1; cand <= limit && cand - s <= (size_t)FM_MAX_OPS; ++cand) {
                 Dag d;
                 if (segment_dag(g0, s, cand, d)) cheap.push_back(cand);
                 else if ((int)d.leaves.size() > FM_MAX_IN) break;
@@ -1161,6 +1477,7 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
             for (Node* l : dags[0].leaves) seg.in.push_back(index_of.at(l));
             for (Node* o : dags[0].outs) seg.out.push_back(index_of.at(o));
             for (size_t i = s; i < e; ++i) if (op_info(g0.order[i]->opcode).scalar) seg.scal.push_back((int32_t)i);
+            seg.zone = s < zone_begin ? 0 : (s < zone_end ? 1 : 2);
             plan.segs.push_back(std::move(seg));
         }
         for (size_t off = 0; off < dags.size(); off += max_batch) {

@@ -12,6 +12,7 @@
 //   one launch per method (:539-557)                  op streams compiled to one launch (Program)
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <array>
 #include <chrono>
 #include <cstdint>
 #include <memory>
@@ -143,6 +144,7 @@ public:
     void jit_wait() { jit_.wait_idle(); }
     JitStats jit_stats() { return jit_.stats(); }
     int64_t jit_launches() const { return n_jit_launches_; }
+    int64_t rolled_launches() const { return n_rolled_launches_; }
     int64_t algorithmic_bytes() const { return algorithmic_bytes_; }
     Program* program(fmhip_program p);
     void program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
@@ -218,14 +220,31 @@ private:
     // the plan: no Dag, no strings, no hash lookups per segment (the general path cost ≈ 16 µs of host time per segment and
     // member, which made two-step groups of the LMM simulation host-bound).
     struct BigPlan {
-        struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; };
+        struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; int zone = 0; };    // zone: 0 before a rolled loop, 1 inside (its fallback), 2 behind
         std::vector<Seg> segs;
         std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
+        // A periodic stretch of the scheduled order — the same few operations over one component after another, each iteration
+        // feeding the next (a running sum) — as ONE launch of a kernel that loops over the iterations (runtime.cpp: rolled loops).
+        // Positions are offsets inside one iteration; the loop covers order[begin + r·period + q], r < iterations.
+        struct Rolled {
+            bool present = false;
+            std::shared_ptr<JitSlot> jit;                               // requested when the JIT tier is on (at discovery, or at the first later use)
+            std::string source; int elems = 0;                          // the kernel's source text (kept until it has been handed to the compiler)
+            uint32_t begin = 0, period = 0, iterations = 0, row_words = 0;
+            std::vector<int32_t> global_leaf;                           // indices into BigDag::leaves: inputs every iteration reads
+            std::vector<uint32_t> carried;                              // positions whose value of the PREVIOUS iteration is read
+            std::vector<std::pair<uint32_t, uint32_t>> leaf_in;         // (position, operand) of the first use of each per-iteration input
+            std::vector<uint32_t> out_pos, scal_pos;                    // positions stored per iteration; positions with a scalar operand
+            std::vector<uint32_t> final_pos;                            // positions whose value of the LAST iteration is stored behind the loop
+        } rolled;
     };
     bool build_big(const std::vector<Node*>& roots, BigDag& big);
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     void run_big_group(std::vector<BigDag>& group);
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count);
+    bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems);
+    void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
+    int64_t n_rolled_launches_ = 0;
     std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
     bool run_dags(std::vector<Dag>& dags);

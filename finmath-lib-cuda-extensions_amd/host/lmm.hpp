@@ -169,12 +169,15 @@ struct Backend {
     // batch b, and reads b's expectations afterwards — instead of idling the device at every batch boundary.
     std::function<std::function<std::vector<double>()>(const std::vector<RV>&)> averagesAsync;
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum); used when stepsPerLaunch == 1
-    // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  With 2, the
-    // engine's scheduler (runtime.cpp: build_big, consumers first) cuts the pending graph of two steps into launches of a few
-    // components x BOTH steps: the state between the two steps never touches HBM (1.5 instead of 2.4 vectors moved per
-    // component and step).  A group never spans a time index whose state a product reads (`keep`).  1 = one step at a time,
-    // flushed every `chunk` components (the scheme of round 1).  The arithmetic per path is the same either way.
-    int stepsPerLaunch = 2;
+    // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  The engine schedules
+    // the pending graph of the group component by component (runtime.cpp: build_big, consumers first), finds that the schedule is
+    // periodic — the same operations for one component after another, the running factor sums carried along — and runs the stretch
+    // as ONE launch of a rolled-loop kernel: the state between the steps of a group never touches HBM, every component is read once
+    // and written once per GROUP.  Until that kernel is compiled (and for the ragged first components) the graph runs as launches
+    // of a few components x all steps of the group.  A group never spans a time index whose state a product reads (`keep`).
+    // 1 = one step at a time, flushed every `chunk` components (the scheme of round 1).  The arithmetic per path is the same
+    // either way.  4 measured best (2 / 4 / 6 / 8: 3.25 / 3.17–3.25 / 3.23 / 3.22 s per calibration; segmented launches only: 4.0 s).
+    int stepsPerLaunch = 4;
     // Optional (lazily fusing back ends): replicate the PENDING expressions below `roots` once per entry of leafTo — copy c reads
     // leafTo[c][i] wherever the original reads leafFrom[i] and takes its scalar operands, in recording order, from (*scalars)[c]
     // (nullptr: the original's) — and return the copies of the roots (fmhip_graph_clone).  With it the parameter sets of a Jacobian

@@ -13,7 +13,7 @@ struct Options {
     int64_t pathOffset = 0; int evaluations = 1;
     int world = 1, rank = 0; std::string ncclIdFile; long long ncclNonce = 0;
     int chunk = 0;                                         // LIBOR components per fused launch; 0 = back end default
-    int stepsPerLaunch = 0;                                // Euler steps recorded per engine flush; 0 = back end default (2)
+    int stepsPerLaunch = 0;                                // Euler steps recorded per engine flush; 0 = back end default (4)
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     std::string brownian = "philox";                        // philox (counter-based, on the device) | mersenne (finmath's CPU generator through the factory)
     bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU

@@ -1,0 +1,89 @@
+"""Rolled loops (runtime.cpp): a periodic stretch of a large pending graph — the same operations over one vector after
+another, each iteration feeding the next — runs as ONE launch of a kernel that loops over the iterations, once that kernel is
+compiled; until then (and with the JIT tier off) the segmented launches run.  Both forms must give the same bits, which must
+be the oracle's."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LMM_HIP = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
+
+
+def scan_chain(factory_like, xs, shared, a, b):
+    """y_j = x_j + (running sum of x_k·a_k / (1 + shared·0.5))·b_j — a running sum carried from one iteration to the next."""
+    run = None
+    ys = []
+    for j, x in enumerate(xs):
+        t = x.v1s1("MULT_S", a[j]).v2s1("DISCOUNT", shared, 0.5)
+        run = t if run is None else run.v2s0("ADD", t)
+        ys.append(x.v2s1("ADDPRODUCT_VS", run, b[j]))
+    return ys
+
+
+def scan_chain_oracle(o, xs, shared, a, b):
+    run, ys = None, []
+    for j, x in enumerate(xs):
+        t = o.f_v2s1("DISCOUNT", o.f_v1s1("MULT_S", x, a[j]), shared, 0.5)
+        run = t if run is None else o.f_v2s0("ADD", run, t)
+        ys.append(o.f_v2s1("ADDPRODUCT_VS", x, run, b[j]))
+    return ys
+
+
+@pytest.mark.parametrize("n,iterations,members", [(30011, 70, 1), (4096, 90, 3), (1, 64, 2)])
+def test_rolled_loop_equals_segments_and_oracle(gpu, oracle, n, iterations, members):
+    rng = np.random.default_rng(n + iterations)
+    hosts = [[oracle.f_from_double(rng.uniform(0.5, 1.5, n)) for _ in range(iterations)] for _ in range(members)]
+    shared_h = oracle.f_from_double(rng.uniform(0.0, 1.0, n))
+    a = [[0.3 + 0.01 * j + 0.1 * m for j in range(iterations)] for m in range(members)]
+    b = [[1.0 - 0.005 * j for j in range(iterations)] for m in range(members)]
+    want = [scan_chain_oracle(oracle, hosts[m], shared_h, a[m], b[m]) for m in range(members)]
+    prev_fusion = gpu.set_fusion(True)
+    results, launches = {}, {}
+    try:
+        shared = gpu.DeviceVector.from_host(shared_h)
+        dev = [[gpu.DeviceVector.from_host(x) for x in row] for row in hosts]
+        for mode, name in ((gpu.JIT_OFF, "segments"), (gpu.JIT_SYNC, "discovery"), (gpu.JIT_SYNC, "rolled")):
+            prev_jit = gpu.set_jit(mode)
+            if name == "segments":
+                gpu.purge()                                           # forget plans made with another tier setting
+            try:
+                with gpu.holding():
+                    ys = [scan_chain(None, dev[m], shared, a[m], b[m]) for m in range(members)]
+                before = gpu.pool_stats().n_kernel_launches
+                gpu.flush()
+                launches[name] = gpu.pool_stats().n_kernel_launches - before
+                results[name] = [[y.to_float32() for y in row] for row in ys]
+                del ys
+            finally:
+                gpu.set_jit(prev_jit)
+    finally:
+        gpu.set_fusion(prev_fusion)
+    for name, res in results.items():
+        for m in range(members):
+            for j in range(iterations):
+                assert_bits_equal(res[m][j], want[m][j], f"{name}: member {m}, iteration {j}")
+    # the stretch of ≈ iterations·4 operations took a dozen launches as segments and takes a handful rolled
+    assert launches["rolled"] < launches["segments"] and launches["rolled"] <= 6, launches
+
+
+def run(*args, env=None):
+    out = subprocess.run([LMM_HIP, *map(str, args)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_lmm_objective_rolled_equals_segmented():
+    """The Euler steps of the LMM simulation as rolled loops (FMHIP_JIT=sync: compiled before first use) against the segmented
+    launches (FMHIP_ROLL=0): the 144 model volatilities must be the same doubles.  Three batches of 4 evaluations in lock-step:
+    the first meets every group shape for the first time (general path, the plan is written down), the others run from the plans."""
+    seg = run("--paths", 20000, "--mode", "evaluate", "--evaluations", 12, "--jacobian-batch", 4, env={"FMHIP_JIT": "sync", "FMHIP_ROLL": "0"})
+    rol = run("--paths", 20000, "--mode", "evaluate", "--evaluations", 12, "--jacobian-batch", 4, env={"FMHIP_JIT": "sync"})
+    assert seg["model_volatility"] == rol["model_volatility"]
+    assert rol["kernel_launches"] < 0.7 * seg["kernel_launches"]
