@@ -199,7 +199,7 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
     if world == 1:
         env = dict(os.environ, FMHIP_JIT="sync")
         for key, batch in (("replay_one_at_a_time", 1), ("replay_8_in_lock_step", 8)):
-            pj, _ = run([LMM_HIP, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", str(batch), "--profile"], env=env)
+            pj, _ = run([LMM_HIP, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", str(batch), "--warmup-evaluations", str(batch), "--profile"], env=env)
             lmm["roofline"][key] = {"achieved": pj["achieved_GBps"], "frac": pj["achieved_GBps"] / HBM_PEAK_GBS, "launches_per_evaluation": pj["profiled_launches"] / 8,
                                     "kernel_ms_per_evaluation": pj["kernel_ms_total"] / 8}
         if cpu_base:

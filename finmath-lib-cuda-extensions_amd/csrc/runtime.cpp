@@ -1263,7 +1263,10 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
     if (G > 8 || CI > 12 || CO > 12 || LI > 12 || LO > 12 || LO + CO == 0 || LS > 48) return false;
     ro.row_words = (uint32_t)(G + CI + CO + R * (LI + LO) + (R * LS + 1) / 2);
     // ---- the kernel
-    const int E = library_math ? 4 : 8;
+    // elements per lane: 8 keeps more bytes in flight per wave, 4 halves the registers (more waves per SIMD to overlap the loop's
+    // load → compute → store with each other); FMHIP_ROLL_ELEMS overrides for measurements
+    static const int ELEMS_ENV = [] { const char* e = std::getenv("FMHIP_ROLL_ELEMS"); const int v = e ? std::atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
+    const int E = ELEMS_ENV ? ELEMS_ENV : (library_math ? 4 : 8);
     *elems_out = E;
     std::ostringstream o;
     o << "#include \"fm_kernel_parts.hpp\"\n"

@@ -159,6 +159,11 @@ int main(int argc, char** argv) {
             };
         }
 
+        if (o.mode == "evaluate" && o.warmupEvaluations > 0) {       // untimed, unprofiled: what a calibration does in its first iteration
+            lmm::VolatilityModel vol;
+            (void)lmm::evaluateMany(m, std::vector<const lmm::VolatilityModel*>((size_t)o.warmupEvaluations, &vol), be);
+            check(fmhip_jit_wait());
+        }
         fmhip_pool_stats_t s0; check(fmhip_pool_stats(&s0));
         int64_t bytes0 = 0; check(fmhip_traffic_stats(&bytes0, nullptr));
         if (o.profile) check(fmhip_profile_enable(1));

@@ -11,6 +11,8 @@ namespace fmhost { namespace lmm {
 struct Options {
     int64_t paths = 10000; int64_t seed = 31415; int maxIterations = 200; std::string mode = "calibrate"; bool verbose = false;
     int64_t pathOffset = 0; int evaluations = 1;
+    int warmupEvaluations = 0;                             // mode evaluate: parameter sets evaluated once (in one lock-step batch) BEFORE statistics and profiling start —
+                                                           // the first batch meets every graph shape for the first time (plans are written down, kernels compiled)
     int world = 1, rank = 0; std::string ncclIdFile; long long ncclNonce = 0;
     int chunk = 0;                                         // LIBOR components per fused launch; 0 = back end default
     int stepsPerLaunch = 0;                                // Euler steps recorded per engine flush; 0 = back end default (4)
@@ -28,6 +30,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--max-iterations") o.maxIterations = std::atoi(next());
         else if (a == "--mode") o.mode = next();                  // calibrate | evaluate
         else if (a == "--evaluations") o.evaluations = std::atoi(next());
+        else if (a == "--warmup-evaluations") o.warmupEvaluations = std::atoi(next());
         else if (a == "--path-offset") o.pathOffset = std::atoll(next());
         else if (a == "--world") o.world = std::atoi(next());
         else if (a == "--rank") o.rank = std::atoi(next());
