@@ -17,7 +17,12 @@ python3 $GRAFT_REPO_ROOT/benchmarks/hbm_traffic_summary.py $OUT/pmc_fetch $OUT/p
 L=$GRAFT_REPO_ROOT/finmath-lib-cuda-extensions_amd/bin/lmm_hip
 export FMHIP_JIT=sync
 $L --paths 1000000 --mode evaluate --evaluations 8 --jacobian-batch 8 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_stats -o lmm -- $L --paths 1000000 --mode evaluate --evaluations 16 --jacobian-batch 8 > $OUT/lmm_profiled_line.json 2> $OUT/lmm_stats.err
+# 16 evaluations in lock-step batches of 8 behind one untimed batch (the first batch meets every graph shape for the first time)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_stats -o lmm -- $L --paths 1000000 --mode evaluate --evaluations 16 --jacobian-batch 8 --warmup-evaluations 8 > $OUT/lmm_profiled_line.json 2> $OUT/lmm_stats.err
+unset FMHIP_JIT
+# the whole calibration (621 evaluations), warm code-object cache
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_calib_stats -o calib -- $L --paths 1000000 --mode calibrate --max-iterations 12 > $OUT/lmm_calib_line.json 2> $OUT/lmm_calib_stats.err
+export FMHIP_JIT=sync
 unset FMHIP_JIT
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/bm_write -o bm -- python3 $GRAFT_REPO_ROOT/benchmarks/config3_heston.py > /dev/null 2> $OUT/bm_write.err
 grep -h fm_bm_kernel $OUT/bm_write/*counter_collection.csv | head -3
