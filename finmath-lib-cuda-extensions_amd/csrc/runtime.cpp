@@ -591,7 +591,7 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
     // (≈10 ms of device time: a compilation costs ≈0.2 s of one background host core); explicit programs at creation.
     if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
-        p->interpreted_work += (double)n * batch * p->n_ops;
+        p->interpreted_work += (double)n * batch * std::max(1, p->n_ops);       // (the stand-alone reduction has no ops: it counts as one)
         if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
     } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
         p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
