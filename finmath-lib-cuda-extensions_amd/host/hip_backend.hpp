@@ -1,0 +1,83 @@
+// hip_backend.hpp — how the native Monte-Carlo drivers (lmm_hip, lmm_smile_hip) talk to the engine beyond the RandomVariable
+// interface: flush / hold of the lazy front-end, graph replication, batched and enqueued expectations.  C-ABI calls only.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include "lmm.hpp"
+
+namespace fmhost {
+
+// chunk / stepsPerLaunch / jacobianBatch: 0 = the back end's default
+inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const BrownianMotion* brownianMotion, int chunk = 0, int stepsPerLaunch = 0, int jacobianBatch = 0) {
+    lmm::Backend be;
+    be.factory = factory;
+    be.brownianMotion = brownianMotion;
+    be.flush = [] { check(fmhip_flush()); };
+    if (!(std::getenv("FMHIP_LMM_HOLD") && std::getenv("FMHIP_LMM_HOLD")[0] == '0'))       // =0: measurement of the effect only
+        be.hold = [](bool h) { check(fmhip_fusion_hold(h ? 1 : 0, nullptr)); };
+    if (chunk > 0) be.chunk = chunk;
+    if (stepsPerLaunch > 0) be.stepsPerLaunch = stepsPerLaunch;
+    be.jacobianBatch = jacobianBatch > 0 ? jacobianBatch : 8;   // default: 8 finite-difference bumps in lock-step (≈ 13 GB of state each at 1 M paths)
+    if (!(std::getenv("FMHIP_LMM_CLONE") && std::getenv("FMHIP_LMM_CLONE")[0] == '0')) {  // =0: every parameter set recorded by hand (A/B measurement)
+        auto handleOf = [](const RV& x) {
+            auto p = dynamic_cast<const RandomVariableHip*>(x.get());
+            if (!p || p->isDeterministic()) throw std::runtime_error("graph replication over a value that is not a device vector");
+            return p->deviceVector().handle();
+        };
+        be.clone = [handleOf](const std::vector<RV>& roots, const std::vector<RV>& leafFrom, const std::vector<std::vector<RV>>& leafTo,
+                              const std::vector<std::vector<double>>* scalars) {
+            const int nRoots = (int)roots.size(), nMap = (int)leafFrom.size(), nCopies = (int)leafTo.size();
+            std::vector<fmhip_vec> r, lf, lt, out((size_t)nRoots * nCopies);
+            for (const RV& x : roots) r.push_back(handleOf(x));
+            for (const RV& x : leafFrom) lf.push_back(handleOf(x));
+            for (const auto& row : leafTo) { if ((int)row.size() != nMap) throw std::runtime_error("graph replication: ragged operand map"); for (const RV& x : row) lt.push_back(handleOf(x)); }
+            std::vector<double> sc;
+            int nScalars = 0;
+            if (scalars) { nScalars = (int)(*scalars)[0].size(); for (const auto& row : *scalars) { if ((int)row.size() != nScalars) throw std::runtime_error("graph replication: ragged scalar lists"); sc.insert(sc.end(), row.begin(), row.end()); } }
+            check(fmhip_graph_clone(r.data(), nRoots, nCopies, lf.data(), lt.data(), nMap, scalars ? sc.data() : nullptr, nScalars, out.data()));
+            std::vector<std::vector<RV>> copies((size_t)nCopies);
+            for (int c = 0; c < nCopies; ++c)
+                for (int k = 0; k < nRoots; ++k)
+                    copies[(size_t)c].push_back(RandomVariableHip::of(roots[(size_t)k]->getFiltrationTime(), DeviceVector(out[(size_t)c * nRoots + k]), roots[(size_t)k]->size()));
+            return copies;
+        };
+        be.recordedScalars = [handleOf](const std::vector<RV>& roots) {
+            std::vector<fmhip_vec> r;
+            for (const RV& x : roots) r.push_back(handleOf(x));
+            int n = 0;
+            check(fmhip_graph_scalars(r.data(), (int)r.size(), nullptr, 0, &n));
+            std::vector<double> sc((size_t)n);
+            check(fmhip_graph_scalars(r.data(), (int)r.size(), sc.data(), n, &n));
+            return sc;
+        };
+    }
+    be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
+    be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
+    if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))    // =0: every batch's expectations read before the next batch is recorded (A/B)
+        be.averagesAsync = [](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
+            std::vector<fmhip_vec> h;
+            int64_t n = 0;
+            for (const RV& x : v) {
+                auto p = dynamic_cast<const RandomVariableHip*>(x.get());
+                if (!p || p->isDeterministic()) { const std::vector<double> now = getAverages(v); return [now] { return now; }; }      // not all device vectors: no pipelining
+                h.push_back(p->deviceVector().handle()); n = p->size();
+            }
+            const int count = (int)h.size();
+            fmhip_vec buf = 0;
+            check(fmhip_vec_create_uninitialized((int64_t)count * 8, &buf));     // count x {Σ, Σ², min, max} doubles, written by the reduction launch
+            void* dev = nullptr; check(fmhip_vec_device_ptr(buf, &dev));
+            check(fmhip_reduce_moments_batch_device(h.data(), count, nullptr, dev));       // enqueued; nobody waits
+            auto owner = std::make_shared<DeviceVector>(buf);
+            return [owner, count, n] {
+                std::vector<float> raw((size_t)count * 8);
+                check(fmhip_vec_read_float(owner->handle(), raw.data(), (int64_t)raw.size()));     // the only synchronisation of the evaluation
+                std::vector<double> out((size_t)count);
+                for (int k = 0; k < count; ++k) { double s; std::memcpy(&s, &raw[(size_t)k * 8], 8); out[(size_t)k] = s / (double)n; }
+                return out;
+            };
+        };
+    return be;
+}
+
+} // namespace fmhost
