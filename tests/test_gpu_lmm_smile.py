@@ -42,7 +42,9 @@ def test_objective_evaluation_identical_to_cpu_twin(brownian):
 
 
 def test_lock_step_batch_and_rolled_steps_change_nothing():
-    one = run(SMILE_HIP, "--paths", 20000, "--mode", "evaluate", env={"FMHIP_JIT": "sync"})
+    # two evaluations: the first meets every step's graph shape for the first time (segmented launches, the rolled kernel is
+    # compiled), the second runs the rolled kernels; the reported launch count and volatilities are the last evaluation's
+    one = run(SMILE_HIP, "--paths", 20000, "--mode", "evaluate", "--evaluations", 2, env={"FMHIP_JIT": "sync"})
     batch = run(SMILE_HIP, "--paths", 20000, "--mode", "evaluate", "--evaluations", 8, "--jacobian-batch", 8, env={"FMHIP_JIT": "sync"})
     unrolled = run(SMILE_HIP, "--paths", 20000, "--mode", "evaluate", env={"FMHIP_ROLL": "0"})
     lazy = run(SMILE_HIP, "--paths", 20000, "--mode", "evaluate", "--lazy-horizon")
