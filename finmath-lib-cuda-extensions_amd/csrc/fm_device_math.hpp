@@ -312,6 +312,63 @@ __device__ __forceinline__ void sqrt_all(float (&a)[E]) {
 }
 __device__ __forceinline__ float sqrt_f(float a) { float v[1] = { a }; sqrt_all<1>(v); return v[0]; }
 
+// ---- IEEE 754 division, two elements at a time -----------------------------------------------------------------------------
+// The correctly rounded fp32 quotient is unique, so every correct implementation is interchangeable bit for bit.  This one is the
+// compiler's own expansion of `a / b` (LLVM AMDGPU LowerFDIV32 with denormals on: div_scale x2, rcp, one Newton step on the
+// reciprocal, quotient, two residual corrections, div_fmas, div_fixup) with its six multiply-add steps issued as PACKED
+// instructions (v_pk_fma_f32 / v_pk_mul_f32: two elements per issue slot).  Left to itself the compiler packs the additions and
+// multiplications of neighbouring elements but expands every division in scalar form: 14 issue slots per quotient, 11 this way.
+// The LMM drift δλ/(1 + δL) makes the four-step simulation kernels VALU-bound; measured on the model's Euler
+// step: 0.426 → 0.376 ns per element and SIMD, 0 differences to `a / b` on 2^26 pairs incl. denormals and specials
+// (benchmarks/div_packed.hip).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 div_pair(f32x2 a, f32x2 b) {
+    bool n0, n1, d0, d1;
+    f32x2 ds, ns, y;
+    ds.x = __builtin_amdgcn_div_scalef(a.x, b.x, false, &d0);
+    ds.y = __builtin_amdgcn_div_scalef(a.y, b.y, false, &d1);
+    ns.x = __builtin_amdgcn_div_scalef(a.x, b.x, true, &n0);
+    ns.y = __builtin_amdgcn_div_scalef(a.y, b.y, true, &n1);
+    y.x = __builtin_amdgcn_rcpf(ds.x);
+    y.y = __builtin_amdgcn_rcpf(ds.y);
+    const f32x2 one = { 1.0f, 1.0f };
+    const f32x2 nd = -ds;
+    const f32x2 e = __builtin_elementwise_fma(nd, y, one);
+    const f32x2 y1 = __builtin_elementwise_fma(e, y, y);
+    const f32x2 q0 = ns * y1;
+    const f32x2 r0 = __builtin_elementwise_fma(nd, q0, ns);
+    const f32x2 q1 = __builtin_elementwise_fma(r0, y1, q0);
+    const f32x2 r1 = __builtin_elementwise_fma(nd, q1, ns);
+    f32x2 q;
+    q.x = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r1.x, y1.x, q1.x, n0), b.x, a.x);
+    q.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r1.y, y1.y, q1.y, n1), b.y, a.y);
+    return q;
+}
+// E elements of a dividing micro-op (same results as ueval<CODE> element by element); r1 / r2: operand registers or nullptr
+template <uint32_t CODE, int E>
+__device__ __forceinline__ void ueval_div_all(float (&out)[E], const float (&acc)[E], const float* r1, const float* r2, float s) {
+    static_assert(E % 2 == 0 && fm_uop_divides(CODE), "pairs of elements of a dividing micro-op");
+#pragma unroll
+    for (int j = 0; j < E; j += 2) {
+        const f32x2 a = { acc[j], acc[j + 1] };
+        f32x2 x = { 0.f, 0.f }, y = { 0.f, 0.f };
+        if (r1) { x.x = r1[j]; x.y = r1[j + 1]; }
+        if (r2) { y.x = r2[j]; y.y = r2[j + 1]; }
+        const f32x2 sv = { s, s }, one = { 1.0f, 1.0f };
+        f32x2 q;
+        if constexpr (CODE == U_INVERT)          q = div_pair(one, a);
+        else if constexpr (CODE == U_DIV_S)      q = div_pair(a, sv);
+        else if constexpr (CODE == U_VID_S)      q = div_pair(sv, a);
+        else if constexpr (CODE == U_DIV)        q = div_pair(a, x);
+        else if constexpr (CODE == U_VID)        q = div_pair(x, a);
+        else if constexpr (CODE == U_DISCOUNT_A) { const f32x2 p = x * sv; q = div_pair(a, one + p); }
+        else if constexpr (CODE == U_DISCOUNT_B) { const f32x2 p = a * sv; q = div_pair(x, one + p); }
+        else if constexpr (CODE == U_ADDRATIO_A) q = a + div_pair(x, y);
+        else                                     q = a - div_pair(x, y);
+        out[j] = q.x; out[j + 1] = q.y;
+    }
+}
+
 // One element of one micro-op (fm_program.h: UOp), micro-op known at compile time: the interpreter switches
 // once per instruction on the wave-uniform code and evaluates all of a thread's elements with ueval<CODE>.
 //   acc = accumulator, r1/r2 = fetched register operands, s = narrowed scalar.

@@ -58,6 +58,12 @@ constexpr int fm_uop_operands(uint32_t code) {
          : (code >= U_ADDPRODUCT_A && code <= U_CHOOSE_N) ? 2 : 0;
 }
 
+// The micro-ops that contain a division: the specialised kernels evaluate them two elements at a time (fm_device_math.hpp: ueval_div_all).
+constexpr bool fm_uop_divides(uint32_t code) {
+    return code == U_INVERT || code == U_DIV_S || code == U_VID_S || code == U_DIV || code == U_VID || code == U_DISCOUNT_A || code == U_DISCOUNT_B ||
+           code == U_ADDRATIO_A || code == U_SUBRATIO_A;
+}
+
 // Instruction word: code[0:7] r1[8:11] r2[12:15] store[16:19] scalar_slot[24:31].
 // Every micro-op writes A to R[store]; the LAST register of the file is a dummy that is never allocated ("no
 // store") — an unconditional write is cheaper for the compiler than a conditional one (see the kernel).

@@ -1318,6 +1318,9 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
         o << "            float v" << q << "[E];\n";
         if (uop == U_SQRT)
             o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = " << x0 << "[j];\n            sqrt_all<E>(v" << q << ");\n";
+        else if (fm_uop_divides(uop))
+            o << "            ueval_div_all<" << uop << "u, E>(v" << q << ", " << x0 << ", " << (uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] : std::string("nullptr")) << ", "
+              << (uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] : std::string("nullptr")) << ", " << s_arg << ");\n";
         else
             o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = ueval<" << uop << "u>(" << x0 << "[j], " << x1 << ", " << x2 << ", " << s_arg << ");\n";
     }

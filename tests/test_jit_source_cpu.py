@@ -39,3 +39,37 @@ def test_source_of_a_bad_description_is_an_error():
     p.output(1)
     with pytest.raises(fm.FmhipError):
         p.source()
+
+
+def build_dividing(fm):
+    p = fm.Program(3)
+    a = p.op("DIV", 0, 1)
+    b = p.op("DISCOUNT", a, 2, s=0.5)
+    c = p.op("VID_S", p.op("INVERT", b), s=3.0)
+    d = p.op("SUBRATIO", p.op("ADDRATIO", c, 0, 1), 2, 1)
+    e = p.op("DIV_S", d, s=3.0)                                          # not a power of two: stays a division
+    p.output(e)
+    return p
+
+
+def test_divisions_are_evaluated_in_pairs_and_the_source_compiles(tmp_path):
+    """Micro-ops with a division go through ueval_div_all (IEEE division with packed multiply-adds, fm_device_math.hpp); the
+    generated translation unit must compile for gfx950 against the device headers (hipcc cross-compiles without a GPU)."""
+    import shutil
+    import subprocess
+    fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+    src = build_dividing(fm).source()
+    assert src.count("ueval_div_all<") == 2 * 7
+    assert " / " not in src.split("fm_jit_inline", 1)[1].replace("E / FM_VEC", "").replace("- 1u) / gridDim.x", "").replace("- 1u) / tile_step", "")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc")
+    f = tmp_path / "dividing.hip"
+    f.write_text(src)
+    csrc = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "csrc")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                          "-I", csrc, "--cuda-device-only", "-S", "-o", str(tmp_path / "dividing.s"), str(f)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    asm = (tmp_path / "dividing.s").read_text()
+    assert "v_pk_fma_f32" in asm and "v_div_fixup_f32" in asm
