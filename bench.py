@@ -57,18 +57,56 @@ def build_stream_s(fm):
     return p.compile()
 
 
+_LCG_A, _LCG_C, _LCG_MASK = 0x5DEECE66D, 0xB, (1 << 48) - 1
+_LCG_TABLE = {}
+
+
+def java_random_doubles(seed, count, skip=0):
+    """`new java.util.Random(seed)`: the doubles number skip … skip+count-1 of its nextDouble() stream (published specification:
+    48-bit LCG s ← s·0x5DEECE66D + 0xB, nextDouble = ((next(26) << 27) + next(27))·2⁻⁵³).  Vectorised: the state k
+    steps ahead is A_k·s + C_k (mod 2⁴⁸); uint64 arithmetic wraps mod 2⁶⁴, of which 2⁴⁸ is a divisor."""
+    import numpy as np
+    def jump(k):                                   # (A_k, C_k) by square-and-multiply on the affine map
+        a, c, A, C = _LCG_A, _LCG_C, 1, 0
+        while k:
+            if k & 1:
+                A, C = (A * a) & _LCG_MASK, (C * a + c) & _LCG_MASK
+            a, c = (a * a) & _LCG_MASK, (c * a + c) & _LCG_MASK
+            k >>= 1
+        return A, C
+    m = 2 * count                                  # two draws per double
+    if _LCG_TABLE.get("m") != m:
+        A = np.empty(m, dtype=np.uint64); C = np.empty(m, dtype=np.uint64)
+        A[0], C[0] = _LCG_A, _LCG_C                # entry i: i+1 steps ahead
+        filled = 1
+        while filled < m:                          # doubling: steps filled+1 … 2·filled = (steps 1 … filled) after `filled` steps
+            k = min(filled, m - filled)
+            Ak, Ck = jump(filled)
+            A[filled:filled + k] = A[:k] * np.uint64(Ak)
+            C[filled:filled + k] = C[:k] * np.uint64(Ak) + np.uint64(Ck)
+            filled += k
+        _LCG_TABLE.update(m=m, A=A, C=C)
+    A, C = _LCG_TABLE["A"], _LCG_TABLE["C"]
+    s0 = (seed ^ _LCG_A) & _LCG_MASK
+    As, Cs = jump(2 * skip)
+    start = np.uint64((As * s0 + Cs) & _LCG_MASK)
+    states = (A * start + C) & np.uint64(_LCG_MASK)
+    hi = (states[0::2] >> np.uint64(22)).astype(np.float64)      # next(26)
+    lo = (states[1::2] >> np.uint64(21)).astype(np.float64)      # next(27)
+    return (hi * float(1 << 27) + lo) * (1.0 / float(1 << 53))
+
+
 def synthetic_inputs(fm, batch, n, rank):
-    """Uniform [0,1) (+0.5 for y, z) generated ON the device from the Philox stream: BrownianMotionHip gives N(0,dt)
-    vectors; a fused program maps them to the ranges config 2 asks for.  Path offset = rank·n (distinct blocks)."""
-    bm = fm.BrownianMotionHip(fm.TimeDiscretization(0.0, batch, 1.0), 3, n, 31415, path_offset=rank * n)
+    """x, y, z from java.util.Random seeds 31415 / 27182 / 16180, uniform [0,1) (+0.5 for y and z),
+    narrowed to fp32 as the factory does and uploaded once; triple b of rank r is the block [(r·batch + b)·n, +n) of each stream."""
+    import numpy as np
     rows = []
     for b in range(batch):
-        g = [bm.getBrownianIncrement(b, f) for f in range(3)]
-        x = g[0].mult(0.25).add(0.5).cap(1.0).floor(0.0)
-        y = g[1].mult(0.25).add(1.0).cap(1.5).floor(0.5)
-        z = g[2].mult(0.25).add(1.0).cap(1.5).floor(0.5)
-        rows.append([x.realizations, y.realizations, z.realizations])
-    del bm
+        skip = (rank * batch + b) * n
+        x = java_random_doubles(31415, n, skip).astype(np.float32)
+        y = (java_random_doubles(27182, n, skip) + 0.5).astype(np.float32)
+        z = (java_random_doubles(16180, n, skip) + 0.5).astype(np.float32)
+        rows.append([fm.DeviceVector.from_host(x), fm.DeviceVector.from_host(y), fm.DeviceVector.from_host(z)])
     return rows
 
 
@@ -117,6 +155,8 @@ def cpu_baseline(target_seconds=8.0, all_cores_seconds=6.0):
         pf, tf = timed(pass_float, target_seconds)
         return {"value": N_OPS * n * pf / tf}
     pf, tf = timed(pass_float, target_seconds)
+    avg, var, mn, mx = pass_float()                # the checker's moments of w for triple 0 = the GPU's first triple (same LCG blocks)
+    result["twin_moments_triple0"] = {"average": avg, "variance": var, "min": mn, "max": mx}
     result["float_twin"] = {"value": N_OPS * n * pf / tf, "unit": "path-ops/s", "cores": 1, "kind": "port",
                             "sample": f"{pf} passes in {tf:.1f} s on the C restatement of the reference's RandomVariableFromFloatArray"}
     if all_cores_seconds > 0:
@@ -414,6 +454,7 @@ def main():
         comb = partials[last].view(B, 4)
     mean_w = float((comb[:, 0] / (world * n)).mean().item())
     assert np.isfinite(mean_w)
+    m0 = [float(v) for v in comb[0].tolist()]      # {sum, sumsq about 0, min, max} of w for triple 0
 
     # cross-check: one event pair per launch (what a tracing profiler sees), separate short pass right after the timed region
     fm.profile_enable(True)
@@ -480,6 +521,8 @@ def main():
             "config": {"workload": "RandomVariableHipFactory 1M-path elementwise+reduction microbench: stream S "
                                    "(12 fused path-ops, 3 inputs, 1 output) + fused {sum,sumsq,min,max}, "
                                    f"batch of {B} independent (x,y,z) triples per launch",
+                       "inputs": "x, y, z = java.util.Random(31415 / 27182 / 16180).nextDouble() (+0.5 for y, z), narrowed to fp32 "
+                                 "(SURVEY.md 8d config 2); triple b of rank r = block (r*batch + b) of each stream",
                        "paths_per_gpu": n, "batch": B, "ops_per_path": N_OPS,
                        "parallelism": f"path-shard x{world}" if world > 1 else "single GPU",
                        "device": dev_name, "compute_units": cus},
@@ -510,6 +553,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            # parity in the run itself: the timed kernel's expectations for triple 0 against the CPU twin on the same inputs
+            tw = line["cpu_baseline"].pop("twin_moments_triple0")
+            gpu_avg = m0[0] / n
+            line["parity_triple0"] = {"gpu": {"average": gpu_avg, "min": m0[2], "max": m0[3]}, "cpu_twin": tw,
+                                      "average_rel_diff": abs(gpu_avg - tw["average"]) / abs(tw["average"]),
+                                      "min_max_identical": m0[2] == tw["min"] and m0[3] == tw["max"],
+                                      "ok": abs(gpu_avg - tw["average"]) <= 1e-12 * abs(tw["average"]) and m0[2] == tw["min"] and m0[3] == tw["max"]}
         if lmm is not None:
             line["lmm"] = lmm
         print(json.dumps(line), file=json_out, flush=True)

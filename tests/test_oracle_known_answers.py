@@ -109,3 +109,21 @@ def test_normal_generator_z_scores_over_many_streams():
     assert np.abs(zm).max() < 4.5 and np.abs(zv).max() < 4.5
     assert 0.7 < (zm ** 2).mean() < 1.3 and 0.7 < (zv ** 2).mean() < 1.3
     assert abs(zm.mean()) < 0.3 and abs(zv.mean()) < 0.3
+
+
+def test_bench_input_generator_is_java_util_random():
+    """bench.py draws its inputs itself (the product side may not use the oracle): its vectorised java.util.Random must be the
+    stream the oracle's sequential restatement gives, at the start and at a block offset (SURVEY.md §8d config 2 seeds)."""
+    import importlib.util
+    import os
+    import numpy as np
+    import oracle
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for seed in (31415, 27182, 16180):
+        want = oracle.java_random_doubles(seed, 30000)
+        assert np.array_equal(bench.java_random_doubles(seed, 10000), want[:10000])
+        assert np.array_equal(bench.java_random_doubles(seed, 10000, skip=20000), want[20000:])
+        assert np.array_equal(bench.java_random_doubles(seed, 7, skip=12345), want[12345:12352])
+    assert abs(bench.java_random_doubles(31415, 100000).mean() - 0.5) < 0.005
