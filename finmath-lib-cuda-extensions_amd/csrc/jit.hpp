@@ -19,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include "fm_program.h"
 
@@ -46,6 +47,32 @@ JitShape jit_shape(const DevProgramArgs& proto);
 // Source text of the specialised kernel pair of a program (deterministic: it doubles as the cache key).
 std::string jit_generate_source(const DevProgramArgs& proto);
 
+// Kernel pack: programs of known workloads, compiled at BUILD time (hiprtc needs no device) into <library directory>/jit_pack, a
+// read-only second level behind the user's code-object cache — a fresh machine starts those workloads on specialised kernels
+// instead of spending its first seconds on the interpreter tier while ~25 kernels compile one after the other (hiprtc
+// serialises concurrent compilations).  A pack entry is the one-line description of a program (everything the source generator
+// reads); FMHIP_JIT_RECORD=<file> appends the description of every program a run asks the tier for (csrc/kernel_pack.txt is
+// such a recording, benchmarks/record_kernel_pack.sh makes it).  An entry that no longer matches what the engine generates is
+// simply never looked up.
+std::string jit_describe(const DevProgramArgs& proto);
+bool jit_parse_description(const std::string& line, DevProgramArgs& proto);
+
+// Body of a rolled loop (runtime.cpp: detect_loop): everything the source of its kernel depends on.  Operand names: v<q> = value of
+// position q of this iteration, c<k> = k-th value carried over from the previous iteration, g<k> = k-th loop-invariant input vector,
+// l<m> = m-th input vector of this iteration.  Iteration count, pointers and scalar operands are run-time arguments (fm_program.h).
+struct RolledBody {
+    int elems = 8; bool uses_log = false;
+    uint32_t globals = 0, inputs = 0;
+    std::vector<uint32_t> carried, final_pos, out_pos;                 // positions whose value is carried / stored once behind the loop / stored every iteration
+    struct Op { uint32_t uop; std::string x0, x1, x2; bool scalar; };  // x1 / x2 empty: the micro-op does not read them
+    std::vector<Op> ops;
+};
+std::string jit_generate_rolled_source(const RolledBody& body);
+std::string jit_describe(const RolledBody& body);
+bool jit_parse_description(const std::string& line, RolledBody& body);
+// Compiles `source` for gfx950 WITHOUT a device and stores the code object under `dir` with the key the run-time lookup uses.
+bool jit_precompile(const std::string& source, const std::string& dir, std::string* log);
+
 class Jit {
 public:
     ~Jit() { quiesce(); }                                       // static destruction: join only, no HIP calls (fmhip_shutdown unloads)
@@ -56,6 +83,7 @@ public:
     std::shared_ptr<JitSlot> request(const DevProgramArgs& proto, bool sync);
     // The same for a kernel pair given as source text (rolled loops, runtime.cpp): `elems` = elements per lane and pass.
     std::shared_ptr<JitSlot> request_source(std::string source, int elems, bool sync);
+    void record(const std::string& description);              // FMHIP_JIT_RECORD: one line per kernel asked for (kernel pack)
     void wait_idle();                                          // until the queue is drained
     JitStats stats();
 private:

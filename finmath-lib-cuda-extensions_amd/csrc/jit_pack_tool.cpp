@@ -1,0 +1,35 @@
+// jit_pack_tool — build-time compiler of the kernel pack (jit.hpp): reads program and rolled-loop descriptions (csrc/kernel_pack.txt), generates
+// each program's specialised-kernel source exactly as the run-time tier does, compiles it with hiprtc (no device needed) and
+// stores the code object where Jit::compile looks behind the user's cache.     usage: jit_pack_tool <descriptions> <output dir>
+#include <chrono>
+#include <cstdio>
+#include <fstream>
+#include <set>
+#include <string>
+#include "jit.hpp"
+
+int main(int argc, char** argv)
+{
+    if (argc != 3) { std::fprintf(stderr, "usage: %s <descriptions> <output dir>\n", argv[0]); return 2; }
+    std::ifstream in(argv[1]);
+    if (!in) { std::fprintf(stderr, "jit_pack_tool: cannot read %s\n", argv[1]); return 2; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::set<std::string> seen;
+    std::string line;
+    int compiled = 0, failed = 0, lineno = 0;
+    while (std::getline(in, line)) {
+        ++lineno;
+        if (line.empty() || line[0] == '#' || !seen.insert(line).second) continue;
+        fm::DevProgramArgs proto;
+        fm::RolledBody body;
+        std::string source, log;
+        if (fm::jit_parse_description(line, proto)) source = fm::jit_generate_source(proto);
+        else if (fm::jit_parse_description(line, body)) source = fm::jit_generate_rolled_source(body);
+        else { std::fprintf(stderr, "jit_pack_tool: %s:%d is not a kernel description\n", argv[1], lineno); ++failed; continue; }
+        if (fm::jit_precompile(source, argv[2], &log)) ++compiled;
+        else { std::fprintf(stderr, "jit_pack_tool: %s:%d does not compile: %s\n", argv[1], lineno, log.c_str()); ++failed; }
+    }
+    std::printf("kernel pack: %d programs compiled into %s in %.1f s%s\n", compiled, argv[2], std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                failed ? " (FAILURES above)" : "");
+    return failed ? 1 : 0;
+}

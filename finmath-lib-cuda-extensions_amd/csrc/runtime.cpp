@@ -1268,75 +1268,20 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
     static const int ELEMS_ENV = [] { const char* e = std::getenv("FMHIP_ROLL_ELEMS"); const int v = e ? std::atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
     const int E = ELEMS_ENV ? ELEMS_ENV : (library_math ? 4 : 8);
     *elems_out = E;
-    std::ostringstream o;
-    o << "#include \"fm_kernel_parts.hpp\"\n"
-      << "// rolled loop: period " << P << ", " << G << " global inputs, " << CI << " carried values, " << CO << " final values, per iteration " << LI << " inputs, " << LO << " outputs, " << LS << " scalars\n"
-      << "extern \"C\" __global__ void fm_jit_inline(const fm::DevRolledArgs A, const uint64_t* __restrict__ rows) {}\n"
-      << "extern \"C\" __global__ void __launch_bounds__(fm::FM_BLOCK) fm_jit_table(const fm::DevRolledArgs A, const uint64_t* __restrict__ rows)\n{\n"
-      << "    using namespace fm;\n    constexpr int E = " << E << ", T = E / FM_VEC;\n"
-      << "    const uint64_t* __restrict__ rowp = rows + (size_t)blockIdx.y * A.row_words;\n"
-      << "    const uint32_t R = A.iterations;\n    const int64_t n = A.n;\n"
-      << "    const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + " << (G + CI + CO) << " + (size_t)R * " << (LI + LO) << ");\n";
-    if (uses_log) o << "    log_table_init();\n";
-    o << "    const uint32_t tiles_per_block = (A.tiles_per_row + gridDim.x - 1u) / gridDim.x;\n"
-      << "    const uint32_t tile_begin = blockIdx.x * tiles_per_block;\n"
-      << "    const uint32_t tile_end = tile_begin + tiles_per_block < A.tiles_per_row ? tile_begin + tiles_per_block : A.tiles_per_row;\n"
-      << "    for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {\n"
-      << "        uint32_t i4[T], i4c[T]; bool lane_valid[T];\n"
-      << "        _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { i4[t] = (tile * T + t) * FM_BLOCK + threadIdx.x; lane_valid[t] = (int64_t)i4[t] * FM_VEC < n; i4c[t] = lane_valid[t] ? i4[t] : 0u; }\n";
-    auto load_into = [&](const std::string& dst, const std::string& ptr_expr, const char* indent) {
-        o << indent << "{ const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(" << ptr_expr << "); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = load_stream(p, i4c[t]); "
-          << dst << "[4 * t] = x.x; " << dst << "[4 * t + 1] = x.y; " << dst << "[4 * t + 2] = x.z; " << dst << "[4 * t + 3] = x.w; } }\n";
-    };
-    for (size_t k = 0; k < G; ++k) { o << "        float g" << k << "[E];\n"; load_into("g" + std::to_string(k), "rowp[" + std::to_string(k) + "]", "        "); }
-    for (size_t k = 0; k < CI; ++k) { o << "        float c" << k << "[E];\n"; load_into("c" + std::to_string(k), "rowp[" + std::to_string(G + k) + "]", "        "); }
-    for (size_t m = 0; m < LI; ++m)
-        o << "        f32x4 nx" << m << "[T];\n        { const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(rowp[" << (G + CI + CO + m)
-          << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) nx" << m << "[t] = load_stream(p, i4c[t]); }\n";
-    for (size_t k = 0; k < CO; ++k) o << "        float f" << k << "[E];\n";
-    o << "        for (uint32_t it = 0; it < R; ++it) {\n"
-      << "            const uint64_t* __restrict__ ip = rowp + " << (G + CI + CO) << " + (size_t)it * " << (LI + LO) << ";\n"
-      << "            const float* __restrict__ sc = scal + (size_t)it * " << LS << ";\n";
-    for (size_t m = 0; m < LI; ++m)
-        o << "            float l" << m << "[E];\n            _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { l" << m << "[4 * t] = nx" << m << "[t].x; l" << m << "[4 * t + 1] = nx" << m << "[t].y; l"
-          << m << "[4 * t + 2] = nx" << m << "[t].z; l" << m << "[4 * t + 3] = nx" << m << "[t].w; }\n";
-    if (LI > 0) {
-        o << "            if (it + 1u < R) {\n";                   // the next iteration's inputs travel while this one is computed
-        for (size_t m = 0; m < LI; ++m)
-            o << "                { const gfloat4* __restrict__ p = reinterpret_cast<const gfloat4*>(ip[" << (LI + LO + m) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) nx" << m << "[t] = load_stream(p, i4c[t]); }\n";
-        o << "            }\n";
-    }
-    int slot = 0;
+    RolledBody body;
+    body.elems = E; body.uses_log = uses_log; body.globals = (uint32_t)G; body.inputs = (uint32_t)LI;
+    body.carried = ro.carried; body.final_pos = ro.final_pos; body.out_pos = ro.out_pos;
     for (uint32_t q = 0; q < P; ++q) {
         const Node* nd = g.order[begin + q];
         UVariant uv{};
         if (!variant_for(nd->opcode, 0, &uv)) return false;
         uint32_t uop = uv.uop;
         if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
-        const std::string x0 = name[q][0], x1 = uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] + "[j]" : std::string("0.f"), x2 = uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] + "[j]" : std::string("0.f");
-        const std::string s_arg = op_info(nd->opcode).scalar ? "sc[" + std::to_string(slot++) + "]" : std::string("0.f");
-        o << "            float v" << q << "[E];\n";
-        if (uop == U_SQRT)
-            o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = " << x0 << "[j];\n            sqrt_all<E>(v" << q << ");\n";
-        else if (fm_uop_divides(uop))
-            o << "            ueval_div_all<" << uop << "u, E>(v" << q << ", " << x0 << ", " << (uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] : std::string("nullptr")) << ", "
-              << (uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] : std::string("nullptr")) << ", " << s_arg << ");\n";
-        else
-            o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) v" << q << "[j] = ueval<" << uop << "u>(" << x0 << "[j], " << x1 << ", " << x2 << ", " << s_arg << ");\n";
+        body.ops.push_back({ uop, name[q][0], uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] : std::string(), uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] : std::string(),
+                             op_info(nd->opcode).scalar });
     }
-    for (size_t m = 0; m < LO; ++m)
-        o << "            { gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(ip[" << (LI + m) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = { v" << ro.out_pos[m]
-          << "[4 * t], v" << ro.out_pos[m] << "[4 * t + 1], v" << ro.out_pos[m] << "[4 * t + 2], v" << ro.out_pos[m] << "[4 * t + 3] }; if (lane_valid[t]) store_stream(q, i4[t], x); } }\n";
-    for (size_t k = 0; k < CI; ++k)
-        o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) c" << k << "[j] = v" << ro.carried[k] << "[j];\n";
-    for (size_t k = 0; k < CO; ++k)
-        o << "            _Pragma(\"unroll\") for (int j = 0; j < E; ++j) f" << k << "[j] = v" << ro.final_pos[k] << "[j];\n";
-    o << "        }\n";
-    for (size_t k = 0; k < CO; ++k)                                  // values of the LAST iteration that somebody behind the loop reads
-        o << "        { gfloat4* __restrict__ q = reinterpret_cast<gfloat4*>(rowp[" << (G + CI + k) << "]); _Pragma(\"unroll\") for (int t = 0; t < T; ++t) { const f32x4 x = { f" << k
-          << "[4 * t], f" << k << "[4 * t + 1], f" << k << "[4 * t + 2], f" << k << "[4 * t + 3] }; if (lane_valid[t]) store_stream(q, i4[t], x); } }\n";
-    o << "    }\n}\n";
-    *source = o.str();
+    jit_.record(jit_describe(body));
+    *source = jit_generate_rolled_source(body);
     return true;
 }
 

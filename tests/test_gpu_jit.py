@@ -1,10 +1,14 @@
 """Execution tiers (include/fmhip.h "execution tiers"): every compiled program runs either on the bytecode interpreter
 kernel or on a specialised kernel generated from its op stream and compiled with hiprtc.  The two tiers must be
 BIT-IDENTICAL (outputs and fused moments), and both equal to the oracle."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import assert_bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -251,3 +255,25 @@ def test_traffic_statistics_count_algorithmic_bytes(gpu, oracle):
         assert b2 - b1 == 4 * n
     finally:
         gpu.set_jit(prev)
+
+
+def test_kernel_pack_serves_a_cold_machine(tmp_path):
+    """A machine that has never run the engine (empty code-object cache) must find the kernels of the LMM calibration in the
+    build-time pack (lib/jit_pack) instead of compiling them while the calibration runs on the interpreter tier."""
+    import json
+    import subprocess
+    lmm = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
+    env = dict(os.environ, FMHIP_JIT_CACHE_DIR=str(tmp_path / "cache"), FMHIP_JIT="auto")
+    out = subprocess.run([lmm, "--paths", "200000", "--mode", "evaluate", "--evaluations", "24", "--jacobian-batch", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert r["specialised_kernels"] >= 4 and r["specialisations_from_disk_cache"] >= 1          # the user cache was empty: these came from the pack
+    if r["specialisations_from_disk_cache"] < r["specialised_kernels"]:
+        pytest.skip(f"kernel pack is stale: {r['specialised_kernels'] - r['specialisations_from_disk_cache']} of {r['specialised_kernels']} kernels "
+                    "were compiled at run time — re-record csrc/kernel_pack.txt with benchmarks/record_kernel_pack.sh")
+    off = subprocess.run([lmm, "--paths", "200000", "--mode", "evaluate", "--evaluations", "24", "--jacobian-batch", "8"], capture_output=True, text=True, timeout=600,
+                         env=dict(env, FMHIP_JIT_CACHE_DIR=str(tmp_path / "cache2"), FMHIP_JIT_PACK_DIR="off"))
+    assert off.returncode == 0, off.stderr
+    q = json.loads(off.stdout.strip().splitlines()[-1])
+    assert q["specialisations_from_disk_cache"] == 0
+    assert q["model_volatility"] == r["model_volatility"]                                          # same kernels either way

@@ -73,3 +73,21 @@ def test_divisions_are_evaluated_in_pairs_and_the_source_compiles(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     asm = (tmp_path / "dividing.s").read_text()
     assert "v_pk_fma_f32" in asm and "v_div_fixup_f32" in asm
+
+
+def test_kernel_pack_is_built_from_its_descriptions():
+    """csrc/kernel_pack.txt (program and rolled-loop descriptions of the flagship workloads) is compiled at build time, without a
+    device, into lib/jit_pack — one code object per distinct description (the build fails on an entry that does not parse or compile)."""
+    pkg = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd")
+    with open(os.path.join(pkg, "csrc", "kernel_pack.txt")) as fh:
+        lines = {ln.strip() for ln in fh if ln.strip() and not ln.startswith("#")}
+    assert len(lines) >= 20 and all(ln.startswith(("program variant ", "rolled elems ")) for ln in lines)
+    assert sum(ln.startswith("rolled ") for ln in lines) >= 4
+    pack = os.path.join(pkg, "lib", "jit_pack")
+    if not os.path.isdir(pack):
+        import __graft_entry__
+        __graft_entry__.build()
+    objects = [f for f in os.listdir(pack) if f.endswith(".co")]
+    assert len(objects) == len(lines)
+    with open(os.path.join(pack, objects[0]), "rb") as fh:
+        assert fh.read(8) == b"FMJITCO1"                                # the cache's own container (jit.cpp: cache_store)
