@@ -51,7 +51,7 @@ template <int V> __device__ __forceinline__ float sqrt_variant(float x) {
 
 struct BodyBase   { static __device__ __forceinline__ float f(float a) { return a * 0.99f + 0.01f; } };
 struct BodyExp    { static __device__ __forceinline__ float f(float a) { return exp_f(a) * 0.25f; } };
-struct BodyLog    { static __device__ __forceinline__ float f(float a) { return log_f(a) + 2.0f; } };
+struct BodyLog    { static __device__ __forceinline__ float f(float a) { return log_f<true>(a) + 2.0f; } };
 struct BodySqrt   { static __device__ __forceinline__ float f(float a) { return sqrt_f(a) + 1.0f; } };
 struct BodySqrt1  { static __device__ __forceinline__ float f(float a) { return sqrt_variant<1>(a) + 1.0f; } };
 struct BodySqrt2  { static __device__ __forceinline__ float f(float a) { return sqrt_variant<2>(a) + 1.0f; } };

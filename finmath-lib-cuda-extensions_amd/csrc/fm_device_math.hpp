@@ -129,10 +129,13 @@ __device__ __forceinline__ void log_table_init() {
     log_table_commit(v);
 }
 
+// SPECIALS: true = the result for zero / negative / infinite / NaN arguments is selected here (v_log_f32 of the mantissa: a
+// quarter-rate instruction, 4 issue slots of the 25, for arguments that hardly ever occur); false = the caller handles them
+// (log_all: one wave-uniform branch for a group of elements).
+template <bool SPECIALS = true>
 __device__ __forceinline__ float log_f(float a) {
     const float m32 = __builtin_amdgcn_frexp_mantf(a);             // [0.5, 1), sign of a; ±0, ±inf, NaN pass through
     const int e = __builtin_amdgcn_frexp_expf(a);
-    const float lg = __builtin_amdgcn_logf(m32);                    // used only for the special cases below
     const uint32_t cb = (__float_as_uint(m32) + 0x4000u) & 0xffff8000u;     // nearest grid point: 8 mantissa bits, may be 1.0
     // byte offset of the 32-byte entry = index·32, index = bits 15…23 of cb (0 … 255: exponent of [0.5,1); 256: c = 1.0).
     // Special arguments (discarded below) may index past the table: LDS reads have no side effects.
@@ -155,8 +158,27 @@ __device__ __forceinline__ float log_f(float a) {
     const double res = hi + (lo + lp);
     // class mask: sNaN|qNaN|-inf|-normal|-denormal|-0|+0|+inf = everything except +denormal (0x080) and +normal (0x100).
     // For those arguments log2 of the MANTISSA (negative → NaN, ±0 → -inf, +inf → +inf, NaN → NaN) is exactly the IEEE result.
-    const bool special = __builtin_amdgcn_classf(a, 0x27f);
-    return special ? lg : (float)res;
+    if constexpr (SPECIALS) {
+        const float lg = __builtin_amdgcn_logf(m32);
+        return __builtin_amdgcn_classf(a, 0x27f) ? lg : (float)res;
+    } else
+        return (float)res;
+}
+__device__ __forceinline__ bool log_special(float a) { return __builtin_amdgcn_classf(a, 0x27f); }
+// G elements at once (the specialised kernels): the main path for all of them, ONE wave-uniform test for special arguments
+template <int G>
+__device__ __forceinline__ void log_all(float* a) {
+    float y[G];
+    bool special = false;
+#pragma unroll
+    for (int j = 0; j < G; ++j) { y[j] = log_f<false>(a[j]); special = special || log_special(a[j]); }
+    if (__builtin_amdgcn_ballot_w64(special) != 0ull) {     // rare; the volatile asm keeps the compiler from if-converting the block
+        asm volatile("; log: zero, negative, infinite or NaN argument in this wave");
+#pragma unroll
+        for (int j = 0; j < G; ++j) y[j] = log_special(a[j]) ? __builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(a[j])) : y[j];
+    }
+#pragma unroll
+    for (int j = 0; j < G; ++j) a[j] = y[j];
 }
 
 // ---- FAST math mode (fmhip_set_math_mode(FMHIP_MATH_FAST)): exp and log on the hardware transcendental unit
@@ -378,7 +400,7 @@ __device__ __forceinline__ float ueval(float acc, float r1, float r2, float s) {
     else if constexpr (CODE == U_SQUARED)   return acc * acc;                                   // twin :875
     else if constexpr (CODE == U_SQRT)      return sqrt_f(acc);                                 // twin :890
     else if constexpr (CODE == U_EXP)       return exp_f(acc);                                  // twin :905
-    else if constexpr (CODE == U_LOG)       return log_f(acc);                                  // twin :920
+    else if constexpr (CODE == U_LOG)       return log_f<true>(acc);                                  // twin :920
     else if constexpr (CODE == U_EXP_FAST)  return exp_fast(acc);
     else if constexpr (CODE == U_LOG_FAST)  return log_fast(acc);
     else if constexpr (CODE == U_INVERT)    return 1.0f / acc;                                  // twin :1296

@@ -25,8 +25,9 @@ def test_generated_source_shape():
     assert "fm_jit_inline" in src and "fm_jit_table" in src
     assert '#include "fm_kernel_parts.hpp"' in src
     assert "red_accumulate<E>" in src and "block_combine<1>" in src     # the interpreter's own reduction code
-    assert src.count("ueval<") == 2 * 9                                 # LDA + 8 micro-ops (DIV_S by 2 became MULT_S; CHOOSE reuses t) …
-    assert src.count("sqrt_all<E>(a)") == 2                             # … and sqrt, whose E elements share one special-case branch
+    assert src.count("ueval<") == 2 * 8                                 # LDA + 7 micro-ops (DIV_S by 2 became MULT_S; CHOOSE reuses t) …
+    assert src.count("sqrt_all<E>(a)") == 2                             # … sqrt, whose E elements share one special-case branch …
+    assert src.count("log_all<4>(a + g)") == 2                          # … and log, likewise, in groups of four (bounded live fp64 temporaries)
     # deterministic: the text is the cache key of the compiled kernel
     assert src == build(fm).source()
 
