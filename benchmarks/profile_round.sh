@@ -22,8 +22,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_stats -o lmm --
 unset FMHIP_JIT
 # the whole calibration (621 evaluations), warm code-object cache
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_calib_stats -o calib -- $L --paths 1000000 --mode calibrate --max-iterations 12 > $OUT/lmm_calib_line.json 2> $OUT/lmm_calib_stats.err
-export FMHIP_JIT=sync
-unset FMHIP_JIT
+# the reference's smile calibration at its larger published path count (context workload)
+S=$GRAFT_REPO_ROOT/finmath-lib-cuda-extensions_amd/bin/lmm_smile_hip
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/smile_stats -o smile -- $S --paths 163840 > $OUT/smile_line.json 2> $OUT/smile_stats.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/bm_write -o bm -- python3 $GRAFT_REPO_ROOT/benchmarks/config3_heston.py > /dev/null 2> $OUT/bm_write.err
 grep -h fm_bm_kernel $OUT/bm_write/*counter_collection.csv | head -3
 cd $GRAFT_REPO_ROOT
