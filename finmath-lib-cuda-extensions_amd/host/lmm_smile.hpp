@@ -199,12 +199,14 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
         logScaling[k] = be.brownianMotion->getRandomVariableForConstant(0.0);
         scalingNow[k] = logScaling[k]->exp();
     }
+    static bool cloneUsable = true;                                     // cleared if the engine's recording ever disagrees with scalarsOf below
+    static int cloneChecks = 0;
     for (int i = 0; i < lastTimeIndex; ++i) {
         const double t = td.getTime(i), dt = td.getTimeStep(i);
         RV dW[F + 1];
         for (int f = 0; f <= F; ++f) dW[f] = be.brownianMotion->getBrownianIncrement(i, f);
         be.hold(true);
-        for (size_t k = 0; k < K; ++k) {
+        auto recordStep = [&](size_t k) {
             const CovarianceModel& cov = *models[k];
             auto& cur = sims[k].libor[(size_t)i];
             auto& nxt = sims[k].libor[(size_t)i + 1];
@@ -233,7 +235,57 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
             const RV step = dW[0]->mult(rho * nu)->add(-0.5 * nu * nu * dt)->addProduct(dW[F], std::sqrt(std::max(0.0, 1.0 - rho * rho)) * nu);
             logScaling[k] = logScaling[k]->add(step);
             scalingNow[k] = logScaling[k]->exp();
+        };
+        // the scalar operands recordStep passes, in its order (every value of the state is a vector from time index 2 on)
+        auto scalarsOf = [&](const CovarianceModel& cov) {
+            std::vector<double> sc;
+            for (int j = i + 1; j < n; ++j) {
+                sc.push_back(delta); sc.push_back(1.0); sc.push_back(delta);                          // constant.discount(L, δ) = L·δ → +1 → δ/·
+                sc.push_back(1.0 - cov.displacement()); sc.push_back(cov.displacement() * m.forward(j));
+                for (int f = 0; f < F; ++f) sc.push_back(cov.loading(t, td.getTime(j), j, f));
+                sc.push_back(dt);
+            }
+            sc.push_back(delta);                                                                      // accrue(L_i, δ)
+            const double nu = cov.nu(), rho = cov.rho();
+            sc.push_back(rho * nu); sc.push_back(-0.5 * nu * nu * dt); sc.push_back(std::sqrt(std::max(0.0, 1.0 - rho * rho)) * nu);
+            return sc;
+        };
+        // Parameter sets 1 … K-1 of a lock-step batch are REPLICAS of set 0's pending step (Backend::clone: ≈ 50 ns per operation
+        // instead of a method call through the mirror classes, a handle and a release): same shape, other operands and scalars.
+        bool recorded = false;
+        if (K > 1 && be.clone && cloneUsable && i >= 2) {
+            recorded = true;
+            std::vector<RV> leafFrom;
+            for (int j = i; j < n; ++j) leafFrom.push_back(sims[0].libor[(size_t)i][(size_t)j]);
+            leafFrom.push_back(sims[0].numeraire[(size_t)i]); leafFrom.push_back(logScaling[0]); leafFrom.push_back(scalingNow[0]);
+            recordStep(0);
+            std::vector<RV> roots;
+            for (int j = i + 1; j < n; ++j) roots.push_back(sims[0].libor[(size_t)i + 1][(size_t)j]);
+            roots.push_back(sims[0].numeraire[(size_t)i + 1]); roots.push_back(logScaling[0]); roots.push_back(scalingNow[0]);
+            if (cloneChecks < 48 && be.recordedScalars) { ++cloneChecks; if (be.recordedScalars(roots) != scalarsOf(*models[0])) cloneUsable = false; }
+            if (cloneUsable) {
+                std::vector<std::vector<RV>> leafTo(K - 1);
+                std::vector<std::vector<double>> scalars(K - 1);
+                for (size_t k = 1; k < K; ++k) {
+                    for (int j = i; j < n; ++j) leafTo[k - 1].push_back(sims[k].libor[(size_t)i][(size_t)j]);
+                    leafTo[k - 1].push_back(sims[k].numeraire[(size_t)i]); leafTo[k - 1].push_back(logScaling[k]); leafTo[k - 1].push_back(scalingNow[k]);
+                    scalars[k - 1] = scalarsOf(*models[k]);
+                }
+                const std::vector<std::vector<RV>> copies = be.clone(roots, leafFrom, leafTo, &scalars);
+                for (size_t k = 1; k < K; ++k) {
+                    auto& nxt = sims[k].libor[(size_t)i + 1];
+                    nxt.resize((size_t)n);
+                    for (int j = 0; j <= i && j < n; ++j) nxt[(size_t)j] = sims[k].libor[(size_t)i][(size_t)j];
+                    size_t r = 0;
+                    for (int j = i + 1; j < n; ++j) nxt[(size_t)j] = copies[k - 1][r++];
+                    sims[k].numeraire[(size_t)i + 1] = copies[k - 1][r++];
+                    logScaling[k] = copies[k - 1][r++];
+                    scalingNow[k] = copies[k - 1][r++];
+                }
+            } else
+                for (size_t k = 1; k < K; ++k) recordStep(k);
         }
+        if (!recorded) for (size_t k = 0; k < K; ++k) recordStep(k);
         if (!keep[(size_t)i]) for (size_t k = 0; k < K; ++k) { sims[k].libor[(size_t)i].clear(); sims[k].libor[(size_t)i].shrink_to_fit(); }
         be.hold(false);
         be.flush();
@@ -306,8 +358,24 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<Pa
     const auto t1 = clk::now();
     std::vector<std::vector<RV>> values(K);
     be.hold(true);
-    for (size_t k = 0; k < K; ++k)
-        for (const Product& s : m.products) if (s.valid) values[k].push_back(swaptionValue(m, sims[k], s));
+    if (K > 1 && be.clone) {
+        // the payoff chains read the kept states and carry the same scalars for every parameter set: record set 0, replicate
+        for (const Product& s : m.products) if (s.valid) values[0].push_back(swaptionValue(m, sims[0], s));
+        std::vector<RV> leafFrom;
+        std::vector<std::vector<RV>> leafTo(K - 1);
+        for (int e = 0; e <= h.lastIndex; ++e) {
+            if (!h.keep[(size_t)e]) continue;
+            for (size_t k = 0; k < K; ++k) {
+                std::vector<RV>& dst = k == 0 ? leafFrom : leafTo[k - 1];
+                for (int j = e; j < m.numberOfLibors(); ++j) dst.push_back(sims[k].libor[(size_t)e][(size_t)j]);
+                dst.push_back(sims[k].numeraire[(size_t)e]);
+            }
+        }
+        const std::vector<std::vector<RV>> copies = be.clone(values[0], leafFrom, leafTo, nullptr);
+        for (size_t k = 1; k < K; ++k) values[k] = copies[k - 1];
+    } else
+        for (size_t k = 0; k < K; ++k)
+            for (const Product& s : m.products) if (s.valid) values[k].push_back(swaptionValue(m, sims[k], s));
     be.hold(false);
     be.flush();
     std::vector<std::function<std::vector<double>()>> expectations;
