@@ -292,6 +292,7 @@ def main():
     ap.add_argument("--workload", choices=["both", "stream", "lmm"], default="both")
     ap.add_argument("--sustained-seconds", type=float, default=2.5, help="length of the sustained leg (back-to-back launches); 0 = skip")
     ap.add_argument("--lmm-iterations", type=int, default=12)
+    ap.add_argument("--exchange-every", type=int, default=8, help="N > 1: steps whose expectation partials travel in one all-gather")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
@@ -345,9 +346,13 @@ def main():
 
     ext_stream = torch.cuda.ExternalStream(fm.stream_ptr(), device=torch.device("cuda", local_rank))
     dev = f"cuda:{local_rank}"
-    # Two sets of expectation buffers: while the partials of step k travel (RCCL, on its own stream), step k+1 computes.
-    partials = [torch.zeros(B * 4, dtype=torch.float64, device=dev) for _ in range(2)]
-    gathers = [torch.zeros(world * B * 4, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
+    # Expectation buffers: G consecutive steps write their B x {Σ, Σ², min, max} partials into the G slots of a bank; a full bank
+    # travels in ONE all-gather (RCCL, on its own stream) while the steps of the other bank compute.  Why G > 1: the exchange needs an
+    # event on the runtime stream, and on this platform an event between two launches costs 13-19 µs of device time (compare
+    # roofline.avg_kernel_us_one_event_pair_per_launch) — per step that is 7-10 % of a 180 µs launch, per 8 steps 1 %.
+    G = max(1, args.exchange_every) if use_dist else 1
+    partials = [torch.zeros(G * B * 4, dtype=torch.float64, device=dev) for _ in range(2)]
+    gathers = [torch.zeros(world * G * B * 4, dtype=torch.float64, device=dev) for _ in range(2)] if use_dist else None
     partial = partials[0]
     comm_stream = torch.cuda.Stream(device=dev) if use_dist else None
     computed = [torch.cuda.Event() for _ in range(2)] if use_dist else None
@@ -356,26 +361,36 @@ def main():
     rccl_events = []                     # (begin, end) on the collective stream, one pair per all-gather of the timed region
     timing_rccl = [False]
 
+    def exchange(bank):
+        # the single exchange of the path: expectation partials of all ranks, overlapped with the steps of the other bank
+        computed[bank].record(ext_stream)
+        comm_stream.wait_event(computed[bank])
+        with torch.cuda.stream(comm_stream):
+            if timing_rccl[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(comm_stream)
+            dist.all_gather_into_tensor(gathers[bank], partials[bank])
+            if timing_rccl[0]:
+                e1.record(comm_stream)
+                rccl_events.append((e0, e1))
+            gathered_ev[bank] = torch.cuda.Event()
+            gathered_ev[bank].record(comm_stream)
+
     def step():
         # one launch: 12 ops over B triples + fused reductions; moments stay on the device
-        k = step_no[0] & 1
+        bank, slot = (step_no[0] // G) & 1, step_no[0] % G
         step_no[0] += 1
-        if use_dist and gathered_ev[k] is not None and not gathered_ev[k].query():
-            ext_stream.wait_event(gathered_ev[k])            # the buffer pair of step k-2 has not been sent yet (rare): order after it
-        prog.run_into(rows, out_rows, want_moments=False, device_moments=partials[k].data_ptr())
-        if use_dist:                     # the single exchange: expectation partials of all ranks, overlapped with the next step
-            computed[k].record(ext_stream)
-            comm_stream.wait_event(computed[k])
-            with torch.cuda.stream(comm_stream):
-                if timing_rccl[0]:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(comm_stream)
-                dist.all_gather_into_tensor(gathers[k], partials[k])
-                if timing_rccl[0]:
-                    e1.record(comm_stream)
-                    rccl_events.append((e0, e1))
-                gathered_ev[k] = torch.cuda.Event()
-                gathered_ev[k].record(comm_stream)
+        if use_dist and slot == 0 and gathered_ev[bank] is not None and not gathered_ev[bank].query():
+            ext_stream.wait_event(gathered_ev[bank])         # this bank's previous content has not been sent yet (rare): order after it
+        prog.run_into(rows, out_rows, want_moments=False, device_moments=partials[bank].data_ptr() + slot * B * 32)
+        if use_dist and slot == G - 1:
+            exchange(bank)
+
+    def finish_exchange():
+        # a bank that the last steps filled only partly travels too: every timed step's expectations are exchanged inside the timed region
+        if use_dist and step_no[0] % G != 0:
+            exchange((step_no[0] // G) & 1)
+            step_no[0] += G - step_no[0] % G
 
     def barrier_sync():
         fm.synchronize()                 # this rank's work (runtime stream + collective stream) is done …
@@ -386,6 +401,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish_exchange()
     fm.jit_wait()                        # steady state: the background compilation of the specialised kernel has finished
     tier, jit_vgprs = prog.tier()
     # Sustained leg, BEFORE the timed region: >= 2 s of back-to-back launches of the headline program, timed in chunks of 50
@@ -415,6 +431,7 @@ def main():
         for _ in range(args.warmup):     # the W warm-up steps of the contract, directly in front of the timed region
             step()
     step()
+    finish_exchange()
     barrier_sync()
     # HIP events on the RUNTIME stream (the stream the kernel is launched on) around the timed region: device time of the K
     # back-to-back launches, gaps included — the live figure behind roofline.achieved
@@ -424,6 +441,7 @@ def main():
     ev_begin.record(ext_stream)
     for _ in range(args.steps):
         step()
+    finish_exchange()
     ev_end.record(ext_stream)
     barrier_sync()
     elapsed = time.perf_counter() - t0
@@ -441,17 +459,17 @@ def main():
         per_gpu_kernel_s = [float(v) for v in everyone.tolist()]
         lat_ms = [a.elapsed_time(b) for a, b in rccl_events]
         rccl = {"calls": len(lat_ms), "summed_latency_ms": float(sum(lat_ms)), "max_latency_ms": float(max(lat_ms)) if lat_ms else 0.0,
-                "bytes_per_rank_and_call": B * 32,
-                "what": "one all-gather of the B x {sum, sumsq, min, max} fp64 expectation partials per step, on its own stream, overlapped "
-                        "with the next step's launch; latency = device time of the collective (HIP events on that stream, rank 0)"}
+                "bytes_per_rank_and_call": G * B * 32, "steps_per_call": G,
+                "what": f"one all-gather of the B x {{sum, sumsq, min, max}} fp64 expectation partials of {G} consecutive steps, on its own stream, "
+                        "overlapped with the following steps; latency = device time of the collective (HIP events on that stream, rank 0)"}
 
     # combined expectations (sanity: finite, and identical on every rank by construction)
     par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
-    last = (step_no[0] - 1) & 1
+    last_bank = ((step_no[0] - 1) // G) & 1       # the bank of the last exchange; slot 0 of it was written by a timed step
     if use_dist:
-        comb = par.combine_moments(gathers[last].view(world, B, 4))
+        comb = par.combine_moments(gathers[last_bank].view(world, G, B, 4)[:, 0].contiguous())
     else:
-        comb = partials[last].view(B, 4)
+        comb = partials[last_bank].view(G, B, 4)[0]
     mean_w = float((comb[:, 0] / (world * n)).mean().item())
     assert np.isfinite(mean_w)
     m0 = [float(v) for v in comb[0].tolist()]      # {sum, sumsq about 0, min, max} of w for triple 0
