@@ -107,8 +107,8 @@ int fmhip_fusion_hold(int hold, int* previous) {
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
-        if (previous) *previous = e.fusion_hold ? 1 : 0;
-        e.fusion_hold = hold != 0;
+        if (previous) *previous = e.fusion_hold;
+        e.fusion_hold = hold == 2 ? 2 : (hold != 0 ? 1 : 0);
     });
 }
 int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,

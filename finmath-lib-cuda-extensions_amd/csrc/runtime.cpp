@@ -708,6 +708,8 @@ static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is
                                        // recording of the next methods, and that path is host-bound
 
 void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
+static const size_t FUSION_SOFT_CAP = 32768;
+static size_t FUSION_MAX_PENDING = [] { const char* e = std::getenv("FMHIP_FUSION_MAX_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)0; }();   // 0 = off
 
 fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
     HostTimer timer(HostProfile::CALL);
@@ -730,6 +732,10 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     if (!fusion || (w > FUSION_MAX_WEIGHT && !fusion_hold)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
+    } else if ((FUSION_MAX_PENDING && !fusion_hold && n_pending_ > FUSION_MAX_PENDING) || (fusion_hold == 2 && n_pending_ > FUSION_SOFT_CAP)) {
+        const fmhip_vec id = nd->id;
+        flush_all();
+        return id;
     }
     return nd->id;
 }

@@ -123,7 +123,8 @@ public:
     // ops
     fmhip_vec call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar);
     bool fusion = false;
-    bool fusion_hold = false;               // fmhip_fusion_hold: no execution on the engine's own accord
+    int fusion_hold = 0;                    // fmhip_fusion_hold: 1 = no execution on the engine's own accord; 2 = the same, but everything pending is
+                                            // executed once more than FUSION_SOFT_CAP operations wait (a hold somebody may forget to lift)
     int math_mode = FMHIP_MATH_EXACT;
     void flush_all();
     void materialize(const std::vector<Node*>& targets);
@@ -173,9 +174,10 @@ private:
     int64_t next_id_ = 1;
     std::unordered_map<int64_t, Node*> nodes_;
     Node pending_head_;                                          // circular list of the nodes without storage (lazy expressions)
-    void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; }
-    void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr; }
-    void pend_clear() { pending_head_.pend_prev = pending_head_.pend_next = &pending_head_; }
+    void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; ++n_pending_; }
+    void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr; --n_pending_; }
+    void pend_clear() { pending_head_.pend_prev = pending_head_.pend_next = &pending_head_; n_pending_ = 0; }
+    size_t n_pending_ = 0;                      // nodes on the pending list
     std::vector<Node*> node_pool_;                               // recycled Node objects
     std::unordered_map<int64_t, Program*> programs_;
     std::unordered_map<std::string, Program*> program_cache_;    // lazy front-end, keyed by structure

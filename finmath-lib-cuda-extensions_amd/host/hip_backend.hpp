@@ -13,7 +13,10 @@ inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const B
     lmm::Backend be;
     be.factory = factory;
     be.brownianMotion = brownianMotion;
-    be.flush = [] { check(fmhip_flush()); };
+    // FMHIP_LMM_FLUSH=0 (with FMHIP_LMM_HOLD=0, FMHIP_LMM_CLONE=0, FMHIP_LMM_ASYNC=0, --jacobian-batch 1): a caller that gives the
+    // engine no hints at all — what finmath-lib's own Euler scheme and optimizer would look like through the Java interface
+    if (!(std::getenv("FMHIP_LMM_FLUSH") && std::getenv("FMHIP_LMM_FLUSH")[0] == '0'))
+        be.flush = [] { check(fmhip_flush()); };
     if (!(std::getenv("FMHIP_LMM_HOLD") && std::getenv("FMHIP_LMM_HOLD")[0] == '0'))       // =0: measurement of the effect only
         be.hold = [](bool h) { check(fmhip_fusion_hold(h ? 1 : 0, nullptr)); };
     if (chunk > 0) be.chunk = chunk;

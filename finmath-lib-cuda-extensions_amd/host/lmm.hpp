@@ -188,6 +188,9 @@ struct Backend {
                                                const std::vector<std::vector<double>>* scalars)> clone;
     std::function<std::vector<double>(const std::vector<RV>& roots)> recordedScalars;
     int jacobianBatch = 1;                  // finite-difference bumps evaluated in lock-step (rows of the same launches)
+    // true: every time step's state keeps its handle until the evaluation is over, as finmath-lib's Euler scheme stores the whole
+    // discretised process (80 x 80 vectors, SURVEY.md §8d config 4: 25.6 GB) — measurement of a caller that knows nothing about the engine
+    bool keepAllStates = false;
 };
 
 // Simulates SEVERAL parameter sets in lock-step (same Brownian increments = common random numbers): the operations of
@@ -358,7 +361,7 @@ inline PendingValuations evaluateManyBegin(const Market& m, const std::vector<co
     const long long l0 = be.launches();
     std::vector<char> keep((size_t)lastIndex + 1, 0);                // states read by SwaptionSimple: the exercise dates
     for (const Swaption& s : m.swaptions) keep[(size_t)m.timeDiscretization.getTimeIndex(s.exercise)] = 1;
-    const std::vector<Simulation> sims = simulateMany(m, vols, be, lastIndex, &keep);
+    const std::vector<Simulation> sims = simulateMany(m, vols, be, lastIndex, be.keepAllStates ? nullptr : &keep);
     const auto t1 = clk::now();
     const long long l1 = be.launches();
     std::vector<std::vector<RV>> values(K);

@@ -30,6 +30,13 @@ int main(int argc, char** argv) {
         lmm::Backend be = makeHipBackend(&factory, (o.brownian == "mersenne") ? static_cast<const BrownianMotion*>(&mersenne) : &philox,
                                          o.chunk, o.stepsPerLaunch, o.jacobianBatch);
 
+        if (o.finmathLike) {
+            // What finmath-lib's own classes would do through the Java interface: the Euler scheme and the optimizer call RandomVariable
+            // methods and getAverage(), nothing else; every time step of the process stays referenced.
+            be.flush = [] {}; be.hold = [](bool) {}; be.clone = nullptr; be.recordedScalars = nullptr; be.averagesAsync = nullptr;
+            be.averages = [](const std::vector<RV>& v) { std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
+            be.jacobianBatch = 1; be.stepsPerLaunch = 1; be.chunk = 1 << 30; be.keepAllStates = true;
+        }
         ncclComm_t comm = nullptr;
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)
         long long collectives = 0;

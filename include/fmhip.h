@@ -188,7 +188,10 @@ int fmhip_flush(void);
  * have accumulated below one handle, so that the device starts early); it runs when a value is needed or at fmhip_flush.
  * For callers that record many independent chains of identical structure — all products of a valuation, all bumped
  * parameter sets of a Jacobian — and want them batched as rows of the same launches.  Releasing the hold executes nothing
- * by itself.  Returns the previous setting through *previous (may be NULL). */
+ * by itself.  hold == 2 is a SOFT hold: the same, except that everything pending is executed once more than 32768
+ * operations wait — for helpers that group work on a caller's behalf and cannot know when the caller is done
+ * (BrownianMotionHip groups the time steps of an Euler scheme this way).  Returns the previous setting (0, 1 or 2)
+ * through *previous (may be NULL). */
 int fmhip_fusion_hold(int hold, int* previous);
 /* Replicate PENDING expressions: a caller that is about to record the same chain of methods again with other vectors and other
  * scalar operands — the next scenario, the next bumped parameter set of a Jacobian — records it ONCE and asks for copies.

@@ -32,6 +32,20 @@ public class BrownianMotionHip implements BrownianMotion, Serializable {
 	private transient RandomVariable[][] brownianIncrements;
 	private final Object brownianIncrementsLazyInitLock = new Object();
 
+	/*
+	 * Time-step grouping on the caller's behalf (mirror of host/random_variable.hpp: BrownianMotionHip::stepBoundary).
+	 * finmath-lib's EulerSchemeFromProcessModel asks for the increments of time index i exactly once per time step: the one
+	 * place where code that was not written for this engine tells it where a step ends.  With groupSteps = S > 0 the
+	 * methods recorded between S such boundaries stay pending (soft hold, Native.fusionHold(2)) and are executed together;
+	 * the engine then sees S whole time steps at once and runs their periodic part as one rolled-loop launch instead of
+	 * cutting the stream every ~40 methods.  Measured with the native driver's hint-free mode (lmm_hip --finmath-like,
+	 * 1 M paths): 26.5 -> 12.8 ms per objective evaluation at S = 2.  System property net.finmath.hip.groupTimeSteps
+	 * (default 2; 0 = off).
+	 */
+	private int groupSteps = Integer.getInteger("net.finmath.hip.groupTimeSteps", 2);
+	private transient int lastTimeIndex = -1;
+	private transient int stepsSinceFlush = 0;
+
 	/**
 	 * @param timeDiscretization the time grid; increment i covers [t_i, t_{i+1}]
 	 * @param numberOfFactors independent components per time step
@@ -67,8 +81,34 @@ public class BrownianMotionHip implements BrownianMotion, Serializable {
 			if(brownianIncrements == null) {
 				doGenerateBrownianMotion();
 			}
+			if(groupSteps > 0 && timeIndex != lastTimeIndex) {
+				stepBoundary(timeIndex);
+			}
 		}
 		return brownianIncrements[timeIndex][factor];
+	}
+
+	public void setGroupSteps(final int steps) {
+		groupSteps = steps;
+	}
+
+	private void stepBoundary(final int timeIndex) {
+		lastTimeIndex = timeIndex;
+		if(timeIndex == 0) {
+			stepsSinceFlush = 0;		// a new simulation
+		}
+		if(stepsSinceFlush == 0) {
+			Native.check(Native.fusionHold(2, null));		// soft hold: the engine lifts it by itself if nobody flushes
+		}
+		if(++stepsSinceFlush > groupSteps) {
+			Native.check(Native.flush());
+			stepsSinceFlush = 1;
+		}
+		if(timeIndex == timeDiscretization.getNumberOfTimeSteps() - 1) {
+			stepsSinceFlush = 0;
+			lastTimeIndex = -1;
+			Native.check(Native.fusionHold(0, null));		// last step: what follows is not ours to group
+		}
 	}
 
 	private void doGenerateBrownianMotion() {
