@@ -708,7 +708,11 @@ static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is
                                        // recording of the next methods, and that path is host-bound
 
 void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
-static const size_t FUSION_SOFT_CAP = 32768;
+static const size_t FUSION_SOFT_CAP = 32768;     // pending operations at which a SOFT hold (fmhip_fusion_hold(2)) executes everything
+// Experiment knob (off): execute everything once this many operations are pending anywhere, instead of the per-handle weight rule.
+// On the hint-free LMM calibration (lmm_hip --finmath-like) 1000 … 16000 gave 15-18 ms per evaluation against 22.8 with the
+// weight rule and 12.5 with BrownianMotionHip's time-step grouping: cut points that do not coincide with time steps give graph
+// shapes that never repeat, so every flush plans from scratch and nothing rolls.
 static size_t FUSION_MAX_PENDING = [] { const char* e = std::getenv("FMHIP_FUSION_MAX_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)0; }();   // 0 = off
 
 fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scalar) {
