@@ -7,7 +7,9 @@ A step = ONE pass of the canonical fused RandomVariable stream S (SURVEY.md §8d
  — 12 path-ops, 3 input vectors, 1 escaping output, 1 fused reduction) over a batch of B independent
 (x,y,z) triples of N = 1 000 000 paths, executed as ONE horizontally batched launch through the C-ABI
 (fmhip_program_run_into).  B·16 MB ≫ 256 MB Infinity Cache, so the traffic is HBM traffic.
-Inputs are resident in HBM before the timed region starts.
+Inputs: x, y, z = java.util.Random(31415 / 27182 / 16180).nextDouble() (+0.5 for y and z) as config 2 specifies, narrowed to
+fp32 and resident in HBM before the timed region starts; the expectations of triple 0 are checked against the CPU twin on the
+same inputs in the run itself ("parity_triple0").
 
 metric  path-ops/s = 12 · N · B · n_gpus / step time        (whole job, all ranks)
 roofline achieved = algorithmic bytes per launch (4 B · (3 in + 1 out) · N · B) / average device duration of the
@@ -16,7 +18,8 @@ cpu_baseline: the oracle (C restatement of the reference's CPU class, one single
          array per method call — the reference's cost model) timed on this host, rank 0, N=1 only.
 
 Multi-GPU (torchrun, one rank per GPU): independent Monte-Carlo path blocks per rank (weak scaling, no data-path
-collective); the only exchange is ONE small RCCL all-gather of the per-rank expectation partials per step.
+collective); the only exchange is ONE small RCCL all-gather of the per-rank expectation partials per 8 steps
+(--exchange-every; DESIGN.md §7 says why not per step).
 
 The default run carries BOTH halves of BASELINE.json's metric in ONE JSON line: the stream line above (top level,
 contract keys unchanged) and, under "lmm", the LIBOR-Market-Model ATM calibration at 1 M paths per GPU (configs[3]; with
