@@ -10,7 +10,20 @@
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) { std::fprintf(stderr, "usage: %s <descriptions> <output dir>\n", argv[0]); return 2; }
+    if (argc == 3 && std::string(argv[1]) == "--check") {            // round trip of every description: parse, describe again, compare (no compilation)
+        std::ifstream in(argv[2]);
+        std::string line; int n = 0, bad = 0;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            fm::DevProgramArgs proto; fm::RolledBody body;
+            const std::string again = fm::jit_parse_description(line, proto) ? fm::jit_describe(proto) : fm::jit_parse_description(line, body) ? fm::jit_describe(body) : std::string("<unparsed>");
+            ++n;
+            if (again != line) { ++bad; std::fprintf(stderr, "round trip differs:\n  %s\n  %s\n", line.c_str(), again.c_str()); }
+        }
+        std::printf("%d descriptions, %d round-trip differences\n", n, bad);
+        return bad ? 1 : 0;
+    }
+    if (argc != 3) { std::fprintf(stderr, "usage: %s <descriptions> <output dir>  |  %s --check <descriptions>\n", argv[0], argv[0]); return 2; }
     std::ifstream in(argv[1]);
     if (!in) { std::fprintf(stderr, "jit_pack_tool: cannot read %s\n", argv[1]); return 2; }
     const auto t0 = std::chrono::steady_clock::now();

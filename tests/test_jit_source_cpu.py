@@ -92,3 +92,9 @@ def test_kernel_pack_is_built_from_its_descriptions():
     assert len(objects) == len(lines)
     with open(os.path.join(pack, objects[0]), "rb") as fh:
         assert fh.read(8) == b"FMJITCO1"                                # the cache's own container (jit.cpp: cache_store)
+    # every description survives parse → describe unchanged (what is compiled is what was recorded)
+    import subprocess
+    tool = os.path.join(pkg, "build", "jit_pack_tool")
+    out = subprocess.run([tool, "--check", os.path.join(pkg, "csrc", "kernel_pack.txt")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith(f"{len(lines)} descriptions, 0 round-trip differences")
