@@ -47,6 +47,12 @@ typedef float f32x9 __attribute__((ext_vector_type(9)));   // > 8 elements: dyna
         break;
 // sqrt: all E elements share one special-case branch (fm_device_math.hpp: sqrt_all)
 #define FM_USQRT case U_SQRT: sqrt_all<E>(a); break;
+// log: four elements at a time like the other fp64 bodies, their special arguments behind one wave-uniform branch (log_all)
+#define FM_ULOG case U_LOG:                                                                             \
+        _Pragma("unroll") for (int g = 0; g < E; g += 4) { log_all<4>(a + g); __builtin_amdgcn_sched_barrier(0); }   \
+        break;
+// (micro-ops with a division stay on `a / b` here: the paired expansion of the specialised tier, ueval_div_all, costs this kernel
+// 8 VGPRs — 129 with a fused reduction, i.e. 3 instead of 4 waves per SIMD; the quotients are the same either way)
 #define FM_U1(CODE) case CODE: {                                                                        \
         float p[E];                                                                                     \
         _Pragma("unroll") for (int j = 0; j < E; ++j) p[j] = R[j][r1];                                  \
@@ -150,7 +156,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             const uint32_t r1 = (w >> 8) & 15u, r2 = (w >> 12) & 15u, st = (w >> 16) & 15u;
             switch (code) {
                 FM_U1(U_LDA)
-                FM_U0(U_SQUARED) FM_USQRT FM_U0H(U_EXP) FM_U0H(U_LOG) FM_U0(U_INVERT) FM_U0(U_ABS)
+                FM_U0(U_SQUARED) FM_USQRT FM_U0H(U_EXP) FM_ULOG FM_U0(U_INVERT) FM_U0(U_ABS)
                 FM_U0(U_ISNAN) FM_U0(U_EXP_FAST) FM_U0(U_LOG_FAST)
                 FM_U0(U_CAP_S) FM_U0(U_FLOOR_S) FM_U0(U_ADD_S) FM_U0(U_SUB_S) FM_U0(U_BUS_S) FM_U0(U_MULT_S)
                 FM_U0(U_DIV_S) FM_U0(U_VID_S)
