@@ -26,7 +26,7 @@ def test_stream_half_of_the_bench_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0.3 < r["frac"] < 0.78                                        # below the streaming ceiling of this data, above a broken kernel
-    assert r["tier"] == "specialised"
+    assert r["tier"] == ("interpreter" if os.environ.get("FMHIP_JIT") == "off" else "specialised")
     # value = path-ops of the whole job / step time; consistent with ms_per_step
     assert abs(d["value"] - 12 * 1_000_000 * 64 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     c = d["cpu_baseline"]
