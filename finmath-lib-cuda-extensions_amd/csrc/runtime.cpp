@@ -902,17 +902,19 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
 }
 
 // Execute structurally identical, mutually independent DAGs as ONE launch (one batch row per DAG).
-bool Engine::run_dags(std::vector<Dag>& dags) {
+bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_moments* host_moments, void* dev_moments) {
     HostTimer timer(HostProfile::RUN_DAGS);
     Dag& d0 = dags[0];
     const int64_t n = d0.roots[0]->n;
     Program* prog = nullptr;
-    auto it = program_cache_.find(d0.sig);
+    if (reduce_shift && dags.size() != 1) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a fused expectation belongs to one expression");
+    const std::string key = reduce_shift ? d0.sig + "\xfeR" : d0.sig;       // the program that also reduces its root is a different program
+    auto it = program_cache_.find(key);
     if (it != program_cache_.end()) prog = it->second;
     else {
-        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, {}, nullptr, false); }
+        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, reduce_shift ? std::vector<int>{ d0.out_ids[0] } : std::vector<int>{}, nullptr, false); }
         catch (const Error& e) { if (e.code == FMHIP_ERR_PROGRAM_LIMIT) return false; throw; }
-        program_cache_[d0.sig] = prog;
+        program_cache_[key] = prog;
     }
     std::vector<std::vector<Buffer*>> out_bufs(dags.size());
     std::vector<RowSpec> rows(dags.size());
@@ -925,9 +927,9 @@ bool Engine::run_dags(std::vector<Dag>& dags) {
                 rows[i].out.push_back(b->ptr);
             }
             rows[i].scalars = dags[i].scalars.data();
-            rows[i].shifts = nullptr;
+            rows[i].shifts = reduce_shift;
         }
-        launch(prog, n, rows, nullptr, nullptr);
+        launch(prog, n, rows, host_moments, dev_moments);
     } catch (...) {
         for (auto& v : out_bufs) for (Buffer* b : v) buffer_unref(b);
         throw;
@@ -1581,7 +1583,13 @@ Program* Engine::reduce_program() {
 void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out) {
     require_init();
     Node* nd = node(h);
-    if (!nd->buf) materialize({ nd });
+    if (!nd->buf) {
+        // `chain.getAverage()`: the expectation of a pending expression that fits one launch is taken in THAT launch (the kernel's
+        // fused reduction) instead of a second launch that reads the vector again — one launch and 4 B per path less
+        std::vector<Dag> one(1);
+        if (fusion && build_dag({ nd }, one[0]) && run_dags(one, &shift, host_out, dev_out)) return;
+        if (!nd->buf) materialize({ nd });
+    }
     Program* prog = reduce_program();
     std::vector<RowSpec> rows(1);
     rows[0].in.push_back(nd->buf->ptr);

@@ -249,7 +249,8 @@ private:
     int64_t n_rolled_launches_ = 0;
     std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
-    bool run_dags(std::vector<Dag>& dags);
+    // reduce_shift != nullptr (one DAG only): the root is ALSO reduced in the same launch — {Σ, Σ(x-shift)², min, max} into host_moments / dev_moments
+    bool run_dags(std::vector<Dag>& dags, const double* reduce_shift = nullptr, fmhip_moments* host_moments = nullptr, void* dev_moments = nullptr);
 };
 
 void hip_check(hipError_t e, const char* what);
