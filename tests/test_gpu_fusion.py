@@ -98,6 +98,30 @@ def test_lazy_chain_is_one_launch_and_bit_identical(gpu, oracle):
     assert (fused == want).all()
 
 
+def test_expectation_of_a_pending_chain_is_taken_in_its_own_launch(gpu, oracle):
+    """`chain.getAverage()`: ONE launch computes the chain AND its {Σ, Σ², min, max}; the vector is there afterwards and later
+    statistics are the usual stand-alone reductions.  Everything equal to the twin's values."""
+    n = 30011
+    d = oracle.java_random_doubles(27182, n)
+    f, of = gpu.RandomVariableHipFactory(), oracle.RandomVariableFloatFactory()
+    want = of.createRandomVariable(0.0, d).add(4.0).div(2.0).exp()
+    x = f.createRandomVariable(0.0, d)
+    gpu.set_fusion(True)
+    try:
+        before = gpu.pool_stats().n_kernel_launches
+        r = x.add(4.0).div(2.0).exp()
+        avg = r.getAverage()
+        assert gpu.pool_stats().n_kernel_launches - before == 1
+        assert abs(avg - want.getAverage()) <= 1e-13 * abs(want.getAverage())
+        var = r.getVariance()                                           # the vector exists now: two more launches (mean, shifted squares), none for the chain
+        assert gpu.pool_stats().n_kernel_launches - before <= 3
+        assert abs(var - want.getVariance()) <= 1e-10 * want.getVariance()
+        assert r.getMin() == want.getMin() and r.getMax() == want.getMax()
+        assert (r.getRealizations() == want.getRealizations()).all()
+    finally:
+        gpu.set_fusion(False)
+
+
 def test_lazy_escaping_intermediate_is_materialised_once(gpu, oracle):
     n = 4099
     d = oracle.java_random_doubles(5, n)
