@@ -1591,8 +1591,11 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     if (!nd->buf) {
         // `chain.getAverage()`: the expectation of a pending expression that fits one launch is taken in THAT launch (the kernel's
         // fused reduction) instead of a second launch that reads the vector again — one launch and 4 B per path less
+        // Only while the launch is small: a launch with a fused reduction has ONE workgroup per 8192 elements of a row (the span
+        // fixes the order of the partial sums, §4.1) — a single row of 1 M paths is 122 workgroups on 256 CUs, fine for one
+        // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
         std::vector<Dag> one(1);
-        if (fusion && build_dag({ nd }, one[0]) && run_dags(one, &shift, host_out, dev_out)) return;
+        if (fusion && build_dag({ nd }, one[0]) && nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) && run_dags(one, &shift, host_out, dev_out)) return;
         if (!nd->buf) materialize({ nd });
     }
     Program* prog = reduce_program();
