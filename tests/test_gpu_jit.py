@@ -264,6 +264,7 @@ def test_kernel_pack_serves_a_cold_machine(tmp_path):
     import subprocess
     lmm = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip")
     env = dict(os.environ, FMHIP_JIT_CACHE_DIR=str(tmp_path / "cache"), FMHIP_JIT="auto")
+    env.pop("FMHIP_ROLL", None)                                         # the pack holds the rolled kernels of this workload
     out = subprocess.run([lmm, "--paths", "200000", "--mode", "evaluate", "--evaluations", "24", "--jacobian-batch", "8"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr
     r = json.loads(out.stdout.strip().splitlines()[-1])
