@@ -72,12 +72,14 @@ def set_fusion(enabled: bool) -> bool:
     return bool(prev.value)
 
 
-def fusion_hold(hold: bool) -> bool:
+def fusion_hold(hold) -> int:
     """While held, pending chains run only when a value is needed or at flush() — many independent chains of identical
-    structure recorded under a hold are batched as rows of the same launches (include/fmhip.h: fmhip_fusion_hold)."""
+    structure recorded under a hold are batched as rows of the same launches (include/fmhip.h: fmhip_fusion_hold).
+    `hold`: False / 0 = off, True / 1 = hard hold, 2 = soft hold (lifted by the engine beyond 32 k pending methods).
+    Returns the previous setting as that integer, so that restoring it never turns a soft hold into a hard one."""
     prev = _C.c_int(0)
-    _native.check(lib().fmhip_fusion_hold(1 if hold else 0, _C.byref(prev)))
-    return bool(prev.value)
+    _native.check(lib().fmhip_fusion_hold(int(hold), _C.byref(prev)))
+    return prev.value
 
 
 class holding:

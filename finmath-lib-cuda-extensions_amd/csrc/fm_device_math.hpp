@@ -366,28 +366,90 @@ __device__ __forceinline__ f32x2 div_pair(f32x2 a, f32x2 b) {
     q.y = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(r1.y, y1.y, q1.y, n1), b.y, a.y);
     return q;
 }
-// E elements of a dividing micro-op (same results as ueval<CODE> element by element); r1 / r2: operand registers or nullptr
+// ---- the same quotient without the scaling and the fix-up, for operands in a range where both are the identity -----------------
+// div_pair spends 8 of its 16 instructions per pair on v_div_scale_f32 (x4), v_div_fmas_f32 (x2) and v_div_fixup_f32 (x2).  By the
+// ISA's definition of those three (CDNA3/4 ISA guide, VOP3 opcodes) they do nothing when |a| and |b| both lie in [2^-48, 2^48):
+//   v_div_scale_f32 D, VCC, S0, S1 = b, S2 = a returns S0 UNCHANGED with VCC = 0 unless one of its cases applies:
+//     a or b zero / NaN / inf        — excluded: both operands are finite, non-zero normal numbers;
+//     exponent(a) - exponent(b) >= 96 — the exponents (unbiased) lie in [-48, 47], their difference in [-95, 95];
+//     b denormal, 1/b denormal (|b| > 2^126), a/b denormal (|a/b| < 2^-126) — |b| < 2^48 and |a/b| > 2^-96;
+//     biased exponent(a) <= 23 (|a| < 2^-103) — |a| >= 2^-48;
+//   v_div_fmas_f32 with VCC = 0 is a plain fused multiply-add (the post-scaling by 2^±32 / 2^±64 applies to VCC = 1 only);
+//   v_div_fixup_f32 D, S0 = q, S1 = b, S2 = a returns ±|q| with the sign of a/b unless an operand is NaN, infinite or zero, the
+//     quotient underflows (exponent(a) - exponent(b) < -150) or b is huge (exponent 255) — none of which can occur; q, the value the
+//     multiply-add chain produced, is a non-zero normal number of magnitude in (2^-96, 2^96) and carries the sign of a/b already.
+// Inside the range the chain below is therefore div_pair's own chain on the same numbers: the result is the same correctly rounded
+// quotient BY CONSTRUCTION (and it is checked anyway: benchmarks/div_packed.hip, the 2^32 sweeps of the dividing methods through the
+// engine).  9 instructions per pair (2 v_rcp_f32, 7 packed multiply-adds) + the range test instead of 16.
+__device__ __forceinline__ f32x2 div_pair_in_range(f32x2 a, f32x2 b) {
+    f32x2 y;
+    y.x = __builtin_amdgcn_rcpf(b.x);
+    y.y = __builtin_amdgcn_rcpf(b.y);
+    const f32x2 one = { 1.0f, 1.0f };
+    const f32x2 nd = -b;
+    const f32x2 e = __builtin_elementwise_fma(nd, y, one);
+    const f32x2 y1 = __builtin_elementwise_fma(e, y, y);
+    const f32x2 q0 = a * y1;
+    const f32x2 r0 = __builtin_elementwise_fma(nd, q0, a);
+    const f32x2 q1 = __builtin_elementwise_fma(r0, y1, q0);
+    const f32x2 r1 = __builtin_elementwise_fma(nd, q1, a);
+    return __builtin_elementwise_fma(r1, y1, q1);
+}
+// Range key of one operand: (bits << 1) drops the sign, the subtraction moves 2^-48 (biased exponent 79) to zero; the operand is in
+// [2^-48, 2^48) exactly when key < FM_DIV_RANGE_SPAN (unsigned).  ONE instruction (v_lshl_add_u32); the keys of a whole group of
+// elements are combined with v_max3_u32 (two operands per instruction) and tested once.  A wave-uniform operand (a scalar of the
+// row block, the constant 1) costs nothing: its key is computed on the scalar unit.
+constexpr uint32_t FM_DIV_RANGE_LOW = 79u << 24, FM_DIV_RANGE_SPAN = 96u << 24;
+__device__ __forceinline__ uint32_t div_range_key(float x) { return (__float_as_uint(x) << 1) - FM_DIV_RANGE_LOW; }
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_elementwise_max(__builtin_elementwise_max(a, b), c); }
+
+// Numerator and denominator of element pair j of a dividing micro-op (the additions and multiplications in front of the division
+// of accrue / discount are part of the micro-op: each rounds once, like the reference's kernels, .cu:234-244)
+template <uint32_t CODE, int E>
+__device__ __forceinline__ void div_operands(int j, const float (&acc)[E], const float* r1, const float* r2, float s, f32x2& num, f32x2& den) {
+    const f32x2 a = { acc[j], acc[j + 1] };
+    f32x2 x = { 0.f, 0.f }, y = { 0.f, 0.f };
+    if (r1) { x.x = r1[j]; x.y = r1[j + 1]; }
+    if (r2) { y.x = r2[j]; y.y = r2[j + 1]; }
+    const f32x2 sv = { s, s }, one = { 1.0f, 1.0f };
+    if constexpr (CODE == U_INVERT)          { num = one; den = a; }
+    else if constexpr (CODE == U_DIV_S)      { num = a; den = sv; }
+    else if constexpr (CODE == U_VID_S)      { num = sv; den = a; }
+    else if constexpr (CODE == U_DIV)        { num = a; den = x; }
+    else if constexpr (CODE == U_VID)        { num = x; den = a; }
+    else if constexpr (CODE == U_DISCOUNT_A) { const f32x2 p = x * sv; num = a; den = one + p; }
+    else if constexpr (CODE == U_DISCOUNT_B) { const f32x2 p = a * sv; num = x; den = one + p; }
+    else                                     { num = x; den = y; }          // addRatio / subRatio
+}
+// E elements of a dividing micro-op (same results as ueval<CODE> element by element); r1 / r2: operand registers or nullptr.
+// The quotients of all E elements by the in-range chain, ONE wave-uniform branch to the full expansion if any operand of any lane
+// lies outside the range (Monte-Carlo data: never, in practice) — as sqrt_all and log_all do for their special arguments.
 template <uint32_t CODE, int E>
 __device__ __forceinline__ void ueval_div_all(float (&out)[E], const float (&acc)[E], const float* r1, const float* r2, float s) {
     static_assert(E % 2 == 0 && fm_uop_divides(CODE), "pairs of elements of a dividing micro-op");
+    constexpr bool num_uniform = CODE == U_INVERT || CODE == U_VID_S, den_uniform = CODE == U_DIV_S;
+    f32x2 num[E / 2], den[E / 2], q[E / 2];
+    uint32_t key = 0u;
 #pragma unroll
-    for (int j = 0; j < E; j += 2) {
-        const f32x2 a = { acc[j], acc[j + 1] };
-        f32x2 x = { 0.f, 0.f }, y = { 0.f, 0.f };
-        if (r1) { x.x = r1[j]; x.y = r1[j + 1]; }
-        if (r2) { y.x = r2[j]; y.y = r2[j + 1]; }
-        const f32x2 sv = { s, s }, one = { 1.0f, 1.0f };
-        f32x2 q;
-        if constexpr (CODE == U_INVERT)          q = div_pair(one, a);
-        else if constexpr (CODE == U_DIV_S)      q = div_pair(a, sv);
-        else if constexpr (CODE == U_VID_S)      q = div_pair(sv, a);
-        else if constexpr (CODE == U_DIV)        q = div_pair(a, x);
-        else if constexpr (CODE == U_VID)        q = div_pair(x, a);
-        else if constexpr (CODE == U_DISCOUNT_A) { const f32x2 p = x * sv; q = div_pair(a, one + p); }
-        else if constexpr (CODE == U_DISCOUNT_B) { const f32x2 p = a * sv; q = div_pair(x, one + p); }
-        else if constexpr (CODE == U_ADDRATIO_A) q = a + div_pair(x, y);
-        else                                     q = a - div_pair(x, y);
-        out[j] = q.x; out[j + 1] = q.y;
+    for (int p = 0; p < E / 2; ++p) {
+        div_operands<CODE, E>(2 * p, acc, r1, r2, s, num[p], den[p]);
+        q[p] = div_pair_in_range(num[p], den[p]);
+        if constexpr (!num_uniform) key = umax3(key, div_range_key(num[p].x), div_range_key(num[p].y));
+        if constexpr (!den_uniform) key = umax3(key, div_range_key(den[p].x), div_range_key(den[p].y));
+    }
+    if constexpr (num_uniform) key = __builtin_elementwise_max(key, div_range_key(num[0].x));       // scalar unit
+    if constexpr (den_uniform) key = __builtin_elementwise_max(key, div_range_key(den[0].x));
+    if (__builtin_amdgcn_ballot_w64(key >= FM_DIV_RANGE_SPAN) != 0ull) {        // wave-uniform and rare; the volatile asm keeps the compiler from if-converting the block
+        asm volatile("; division: IEEE expansion with scaling and fix-up for operands outside [2^-48, 2^48)");
+#pragma unroll
+        for (int p = 0; p < E / 2; ++p) q[p] = div_pair(num[p], den[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < E / 2; ++p) {
+        f32x2 r = q[p];
+        if constexpr (CODE == U_ADDRATIO_A)      { const f32x2 a = { acc[2 * p], acc[2 * p + 1] }; r = a + q[p]; }
+        else if constexpr (CODE == U_SUBRATIO_A) { const f32x2 a = { acc[2 * p], acc[2 * p + 1] }; r = a - q[p]; }
+        out[2 * p] = r.x; out[2 * p + 1] = r.y;
     }
 }
 

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <functional>
 #include <map>
 #include <sstream>
 #include <unordered_set>
@@ -180,6 +181,8 @@ void Engine::shutdown() {
         delete nd;
     }
     nodes_.clear();
+    for (auto& kv : replicas_) delete kv.second;
+    replicas_.clear();
     pend_clear();
     for (Node* nd : node_pool_) delete nd;
     node_pool_.clear();
@@ -729,6 +732,8 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
         throw Error(FMHIP_ERR_INVALID_ARGUMENT, "opcode " + std::to_string(opcode) + " does not match this call shape");
     Node* ins[3] = { nullptr, nullptr, nullptr };
     for (int i = 0; i < n_in; ++i) ins[i] = node(in[i]);
+    if (!replicas_.empty())                                     // an operation on the root of a copy that exists as a description only: the copy becomes an expression first
+        for (int i = 0; i < n_in; ++i) if (!ins[i]->buf && ins[i]->rep_copy) if (ReplicaGroup* g = replica_of(ins[i])) expand_replicas(g);
     for (int i = 1; i < n_in; ++i)
         if (ins[i]->n != ins[0]->n)
             throw Error(FMHIP_ERR_SIZE_MISMATCH, "operand sizes differ: " + std::to_string(ins[0]->n) + " vs " + std::to_string(ins[i]->n));
@@ -753,6 +758,8 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
 
 void Engine::collect_pending(const fmhip_vec* roots, int n_roots, std::vector<Node*>& graph) {
     if (n_roots <= 0 || !roots) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "no roots");
+    if (!replicas_.empty())                                     // the root of a copy that exists as a description only: it becomes an expression first
+        for (int r = 0; r < n_roots; ++r) { Node* root = node(roots[r]); if (!root->buf && root->rep_copy) if (ReplicaGroup* g = replica_of(root)) expand_replicas(g); }
     const uint64_t ep = ++epoch_;
     std::vector<Node*> stack;
     for (int r = 0; r < n_roots; ++r) {
@@ -778,6 +785,39 @@ int Engine::graph_scalars(const fmhip_vec* roots, int n_roots, double* out, int 
     return count;
 }
 
+// The copies of a pending graph as ordinary nodes: copy j of the operations `graph` (recording order, marked ep_graph with tmp_id = position;
+// substituted operands marked ep_leaf with tmp_id = i).  root_node(j, i) != nullptr: the node that is to carry operation i of copy j
+// (a root that exists already: expand_replicas); otherwise a fresh node without a handle.  ids: id_of(j, i).
+template <class RootNode, class IdOf, class ScalarOf, class LeafTo>
+static void clone_nodes_impl(std::vector<Node*>& graph, uint64_t ep_graph, uint64_t ep_leaf, int n_copies, RootNode root_node, IdOf id_of, ScalarOf scalar_of, LeafTo leaf_to,
+                             std::vector<Node*>& node_pool, std::vector<std::vector<Node*>>& copies, const std::function<void(Node*)>& pend_insert)
+{
+    copies.assign((size_t)n_copies, std::vector<Node*>(graph.size(), nullptr));
+    for (int j = 0; j < n_copies; ++j) {
+        std::vector<Node*>& copy = copies[(size_t)j];
+        for (size_t i = 0; i < graph.size(); ++i) {
+            const Node* src = graph[i];
+            Node* nd = root_node(j, i);
+            const bool fresh = nd == nullptr;
+            if (fresh) {                                             // like new_node, but without a handle: inner values of a copy have none
+                if (!node_pool.empty()) { nd = node_pool.back(); node_pool.pop_back(); *nd = Node(); } else nd = new Node();
+                nd->id = id_of(j, i); nd->n = src->n;
+            }
+            nd->opcode = src->opcode; nd->n_in = src->n_in; nd->weight = src->weight;
+            nd->scalar = scalar_of(j, i, src);
+            for (int k = 0; k < src->n_in; ++k) {
+                Node* c = src->in[k];
+                Node* m = c->mark == ep_graph ? copy[(size_t)c->tmp_id] : (c->mark == ep_leaf ? leaf_to(j, c->tmp_id) : c);
+                nd->in[k] = m; m->refs_int++;
+            }
+            if (fresh) pend_insert(nd);
+            copy[i] = nd;
+        }
+    }
+}
+
+static const bool REPLICAS = [] { const char* e = std::getenv("FMHIP_REPLICAS"); return !(e && e[0] == '0'); }();     // =0: copies are always made of nodes (A/B measurement)
+
 void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
                          const double* scalars, int n_scalars, fmhip_vec* out) {
     HostTimer timer(HostProfile::CLONE);
@@ -800,38 +840,167 @@ void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, cons
     }
     std::vector<Node*> root_nodes((size_t)n_roots);
     for (int r = 0; r < n_roots; ++r) root_nodes[(size_t)r] = node(roots[r]);
-    std::vector<Node*> to((size_t)n_map), copy(graph.size());
-    for (int j = 0; j < n_copies; ++j) {
+    std::vector<Node*> to((size_t)n_map * (size_t)n_copies);
+    for (int j = 0; j < n_copies; ++j)
         for (int i = 0; i < n_map; ++i) {
-            to[(size_t)i] = node(leaf_to[(size_t)j * n_map + i]);
-            if (to[(size_t)i]->n != from[(size_t)i]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "a substituted operand differs in size");
+            Node* t = node(leaf_to[(size_t)j * n_map + i]);
+            if (t->n != from[(size_t)i]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "a substituted operand differs in size");
+            to[(size_t)j * n_map + i] = t;
         }
-        const double* sc = scalars ? scalars + (size_t)j * n_scalars : nullptr;
-        int k_scalar = 0;
-        for (size_t i = 0; i < graph.size(); ++i) {
-            const Node* src = graph[i];
-            Node* nd;                                            // like new_node, but without a handle: inner values of a copy have none
-            if (!node_pool_.empty()) { nd = node_pool_.back(); node_pool_.pop_back(); *nd = Node(); } else nd = new Node();
-            nd->id = next_id_++; nd->n = src->n;
-            nd->opcode = src->opcode; nd->n_in = src->n_in; nd->weight = src->weight;
-            nd->scalar = src->scalar;
-            if (op_info(src->opcode).scalar) { if (sc) nd->scalar = sc[k_scalar]; ++k_scalar; }
-            for (int k = 0; k < src->n_in; ++k) {
-                Node* c = src->in[k];
-                Node* m = c->mark == ep_graph ? copy[(size_t)c->tmp_id] : (c->mark == ep_leaf ? to[(size_t)c->tmp_id] : c);
-                nd->in[k] = m; m->refs_int++;
+    auto shared_root = [&](Node* root, int j) {                      // a root that is a vector already: the copy shares it (or its substitute)
+        Node* c = root->mark == ep_leaf && n_map > 0 ? to[(size_t)j * n_map + root->tmp_id] : root;
+        c->refs_ext++;
+        if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+        return c->id;
+    };
+    // The copies as a DESCRIPTION (ReplicaGroup): only when every operand a copy would read exists as a vector already and no part of
+    // the graph or of the operand map belongs to another live description.
+    bool describe = REPLICAS && n_copies > 0 && !graph.empty();
+    for (size_t i = 0; describe && i < graph.size(); ++i) describe = graph[i]->rep_id == 0 || replica_of(graph[i]) == nullptr;
+    for (size_t i = 0; describe && i < from.size(); ++i) describe = from[i]->buf != nullptr && (from[i]->leaf_rep_id == 0 || replicas_.find(from[i]->leaf_rep_id) == replicas_.end());
+    for (size_t i = 0; describe && i < to.size(); ++i) describe = to[i]->buf != nullptr;
+    if (!describe) {
+        std::vector<std::vector<Node*>> copies;
+        clone_nodes_impl(graph, ep_graph, ep_leaf, n_copies,
+                         [](int, size_t) -> Node* { return nullptr; }, [&](int, size_t) { return next_id_++; },
+                         [&](int j, size_t, const Node* src) { return scalars && op_info(src->opcode).scalar ? 0.0 : src->scalar; },      // patched below (recording order)
+                         [&](int j, int i) { return to[(size_t)j * n_map + i]; }, node_pool_, copies, [this](Node* nd) { pend_insert(nd); });
+        for (int j = 0; j < n_copies; ++j) {
+            if (scalars) { int k = 0; for (size_t i = 0; i < graph.size(); ++i) if (op_info(graph[i]->opcode).scalar) copies[(size_t)j][i]->scalar = scalars[(size_t)j * n_scalars + k++]; }
+            for (int r = 0; r < n_roots; ++r) {
+                Node* root = root_nodes[(size_t)r];
+                if (root->mark != ep_graph) { out[(size_t)j * n_roots + r] = shared_root(root, j); continue; }
+                Node* c = copies[(size_t)j][(size_t)root->tmp_id];
+                c->refs_ext++;
+                if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+                out[(size_t)j * n_roots + r] = c->id;
             }
-            pend_insert(nd);
-            copy[i] = nd;
+            // copies of values nobody holds and nothing uses cannot exist: every graph node is below a root
         }
-        for (int r = 0; r < n_roots; ++r) {
-            Node* root = root_nodes[(size_t)r];
-            Node* c = root->mark == ep_graph ? copy[(size_t)root->tmp_id] : (root->mark == ep_leaf ? to[(size_t)root->tmp_id] : root);   // a root that is already a vector: shared
-            c->refs_ext++;
-            if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+        return;
+    }
+    ReplicaGroup* g = new ReplicaGroup();
+    g->id = next_replica_id_++;
+    g->n_copies = n_copies; g->n_roots = n_roots; g->n_scalars = scalars ? n_scalars : 0;
+    g->graph_size = (int)graph.size();
+    g->id_base = next_id_; next_id_ += (int64_t)graph.size() * n_copies;
+    g->scalar_slot.assign(graph.size(), -1);
+    int slot = 0;
+    for (size_t i = 0; i < graph.size(); ++i) {
+        Node* nd = graph[i];
+        nd->rep_id = g->id; nd->rep_index = (int32_t)i; nd->rep_root = -1; nd->rep_copy = 0;
+        if (op_info(nd->opcode).scalar) g->scalar_slot[i] = slot++;
+    }
+    if (scalars) g->scalars.assign(scalars, scalars + (size_t)n_copies * n_scalars);
+    g->leaf_from = from; g->leaf_to = to;
+    for (size_t i = 0; i < from.size(); ++i) { from[i]->refs_int++; from[i]->leaf_rep_id = g->id; from[i]->leaf_rep_index = (int32_t)i; }
+    for (Node* t : to) t->refs_int++;
+    g->roots.assign((size_t)n_roots, nullptr);
+    g->root_done.assign((size_t)n_roots, 1);
+    g->copy_roots.assign((size_t)n_copies * n_roots, nullptr);
+    for (int r = 0; r < n_roots; ++r) {
+        Node* root = root_nodes[(size_t)r];
+        if (root->mark != ep_graph) { for (int j = 0; j < n_copies; ++j) out[(size_t)j * n_roots + r] = shared_root(root, j); continue; }
+        if (root->rep_root >= 0) {                                   // listed twice: the same copies again
+            for (int j = 0; j < n_copies; ++j) { Node* c = g->copy_roots[(size_t)j * n_roots + root->rep_root]; c->refs_ext++; out[(size_t)j * n_roots + r] = c->id; }
+            continue;
+        }
+        root->rep_root = r;
+        root->refs_ext++;                                            // the group's hold on the original: the graph stays whole until it has run with its copies (or been expanded)
+        g->roots[(size_t)r] = root; g->root_done[(size_t)r] = 0; g->remaining++;
+        for (int j = 0; j < n_copies; ++j) {
+            Node* c;
+            if (!node_pool_.empty()) { c = node_pool_.back(); node_pool_.pop_back(); *c = Node(); } else c = new Node();
+            c->id = g->id_base + (int64_t)j * g->graph_size + root->rep_index;
+            c->n = root->n; c->refs_ext = 1; c->refs_int = 1;        // refs_int: the group's hold
+            c->rep_id = g->id; c->rep_copy = (uint32_t)j + 1u; c->rep_root = r; c->rep_index = root->rep_index;
+            nodes_[c->id] = c;
+            pend_insert(c);
+            g->copy_roots[(size_t)j * n_roots + r] = c;
             out[(size_t)j * n_roots + r] = c->id;
         }
-        // copies of values nobody holds and nothing uses cannot exist: every graph node is below a root
+    }
+    replicas_[g->id] = g;
+    if (g->remaining == 0) destroy_replica_group(g);                 // (cannot happen: a non-empty graph lies below a pending root)
+}
+
+// Drops a group's holds on its operands and forgets it (its roots have all been executed, or expanded).
+void Engine::destroy_replica_group(ReplicaGroup* g) {
+    replicas_.erase(g->id);
+    for (Node* l : g->leaf_from) { if (l->leaf_rep_id == g->id) { l->leaf_rep_id = 0; l->leaf_rep_index = -1; } node_unref_int(l); }
+    for (Node* t : g->leaf_to) node_unref_int(t);
+    delete g;
+}
+
+// The roots `done` (indices) have been executed together with all their copies: the copies' root nodes have their buffers.
+void Engine::replica_roots_done(ReplicaGroup* g, const std::vector<int>& done) {
+    for (int r : done) {
+        if (g->root_done[(size_t)r]) continue;
+        g->root_done[(size_t)r] = 1; g->remaining--;
+        for (int j = 0; j < g->n_copies; ++j) {
+            Node* c = g->copy_roots[(size_t)j * g->n_roots + r];
+            c->rep_id = 0; c->rep_copy = 0; c->rep_root = -1; c->rep_index = -1;
+            node_unref_int(c);
+        }
+        Node* root = g->roots[(size_t)r];
+        root->rep_id = 0; root->rep_root = -1; root->rep_index = -1;
+        if (--root->refs_ext == 0) { nodes_.erase(root->id); node_maybe_free(root); }
+    }
+    if (g->remaining == 0) destroy_replica_group(g);
+}
+
+// Fallback: the description becomes ordinary pending nodes (what graph_clone made before descriptions existed), for the roots that
+// have not been executed yet.  The copies' root nodes — the handles are out — receive the root operations; every other operation of
+// a copy becomes a fresh node with the id reserved for it.
+void Engine::expand_replicas(ReplicaGroup* g) {
+    std::vector<Node*> graph;
+    {
+        const uint64_t ep = ++epoch_;
+        std::vector<Node*> stack;
+        for (int r = 0; r < g->n_roots; ++r) {
+            Node* root = g->roots[(size_t)r];
+            if (!root || g->root_done[(size_t)r] || root->buf || root->mark == ep) continue;
+            root->mark = ep; stack.push_back(root);
+            while (!stack.empty()) {
+                Node* nd = stack.back(); stack.pop_back();
+                graph.push_back(nd);
+                for (int k = 0; k < nd->n_in; ++k) { Node* c = nd->in[k]; if (!c->buf && c->mark != ep) { c->mark = ep; stack.push_back(c); } }
+            }
+        }
+        std::sort(graph.begin(), graph.end(), [](const Node* a, const Node* b) { return a->id < b->id; });
+    }
+    const uint64_t ep_graph = ++epoch_;
+    for (size_t i = 0; i < graph.size(); ++i) { graph[i]->mark = ep_graph; graph[i]->tmp_id = (int)i; }
+    const uint64_t ep_leaf = ++epoch_;
+    const int n_map = (int)g->leaf_from.size();
+    for (int i = 0; i < n_map; ++i) { g->leaf_from[(size_t)i]->mark = ep_leaf; g->leaf_from[(size_t)i]->tmp_id = i; }
+    std::vector<std::vector<Node*>> copies;
+    clone_nodes_impl(graph, ep_graph, ep_leaf, g->n_copies,
+                     [&](int j, size_t i) -> Node* { const Node* src = graph[i]; return src->rep_root >= 0 ? g->copy_roots[(size_t)j * g->n_roots + src->rep_root] : nullptr; },
+                     [&](int j, size_t i) { return g->id_base + (int64_t)j * g->graph_size + graph[i]->rep_index; },
+                     [&](int j, size_t i, const Node* src) { const int32_t sl = g->scalar_slot[(size_t)src->rep_index];
+                                                             return (sl >= 0 && !g->scalars.empty()) ? g->scalars[(size_t)j * g->n_scalars + sl] : src->scalar; },
+                     [&](int j, int i) { return g->leaf_to[(size_t)j * n_map + i]; }, node_pool_, copies, [this](Node* nd) { pend_insert(nd); });
+    for (Node* nd : graph) { nd->rep_id = 0; nd->rep_index = -1; }   // (rep_root is cleared with the roots below)
+    std::vector<int> all;
+    for (int r = 0; r < g->n_roots; ++r) if (g->roots[(size_t)r] && !g->root_done[(size_t)r]) all.push_back(r);
+    replica_roots_done(g, all);                                       // drops the holds; the copies' roots are ordinary pending expressions now
+}
+
+// Every live description the pending graph below `targets` touches is expanded: for the paths that execute a single expression
+// (read, reduce, device_ptr, a chain passing the size threshold) instead of flushing everything.
+void Engine::expand_replicas_below(const std::vector<Node*>& targets) {
+    if (replicas_.empty()) return;
+    for (bool again = true; again;) {
+        again = false;
+        const uint64_t ep = ++epoch_;
+        std::vector<Node*> stack;
+        for (Node* t : targets) { if (!t->buf && t->mark != ep) { t->mark = ep; stack.push_back(t); } }
+        while (!stack.empty() && !again) {
+            Node* nd = stack.back(); stack.pop_back();
+            if (nd->rep_id) { if (ReplicaGroup* g = replica_of(nd)) { expand_replicas(g); again = true; break; } }
+            for (int k = 0; k < nd->n_in; ++k) { Node* c = nd->in[k]; if (!c->buf && c->mark != ep) { c->mark = ep; stack.push_back(c); } }
+        }
     }
 }
 
@@ -844,6 +1013,9 @@ struct Engine::Dag {
     std::vector<int> out_ids;
     std::vector<float> scalars;
     std::string sig;
+    // replica descriptions (ReplicaGroup): the stamp all pending nodes of this DAG share (0: none), whether they all share one, whether any has one
+    uint32_t rep_id = 0;
+    bool rep_uniform = true, rep_any = false;
 };
 
 // Linearise the pending expressions below `roots` into ONE program (roots may share intermediates: they become
@@ -854,9 +1026,14 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
     const uint64_t ep = ++epoch_;                   // nodes with mark == ep have been visited by THIS build
     std::vector<std::pair<Node*, int>> stack;
     auto visit = [&](Node* nd) { nd->mark = ep; nd->tmp_id = -1; nd->tmp_uses = 0; };
+    bool first_pending = true;
+    auto note_rep = [&](const Node* nd) {
+        if (first_pending) { dag.rep_id = nd->rep_id; first_pending = false; } else if (nd->rep_id != dag.rep_id) dag.rep_uniform = false;
+        dag.rep_any |= nd->rep_id != 0;
+    };
     for (Node* root : roots) {
         if (root->mark == ep) continue;             // a root that is also an operand of an earlier root
-        visit(root);
+        visit(root); note_rep(root);
         stack.push_back({ root, 0 });
         while (!stack.empty()) {                    // iterative post-order
             auto& top = stack.back();
@@ -866,7 +1043,7 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
                 if (c->buf) {
                     if (c->mark != ep) { visit(c); dag.leaves.push_back(c); }
                 } else {
-                    if (c->mark != ep) { visit(c); stack.push_back({ c, 0 }); }
+                    if (c->mark != ep) { visit(c); note_rep(c); stack.push_back({ c, 0 }); }
                     c->tmp_uses++;
                 }
             } else {
@@ -907,10 +1084,12 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
 }
 
 // Execute structurally identical, mutually independent DAGs as ONE launch (one batch row per DAG).
-bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_moments* host_moments, void* dev_moments) {
+// proto: the member that carries the structure (signature, operations); nullptr = dags[0].  Members that are copies existing as a
+// description (flush_all: replica_dag) carry vectors, outputs and scalars only.
+bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_moments* host_moments, void* dev_moments, const Dag* proto) {
     HostTimer timer(HostProfile::RUN_DAGS);
-    Dag& d0 = dags[0];
-    const int64_t n = d0.roots[0]->n;
+    const Dag& d0 = proto ? *proto : dags[0];
+    const int64_t n = dags[0].outs[0]->n;
     Program* prog = nullptr;
     if (reduce_shift && dags.size() != 1) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a fused expectation belongs to one expression");
     const std::string key = reduce_shift ? d0.sig + "\xfeR" : d0.sig;       // the program that also reduces its root is a different program
@@ -961,6 +1140,14 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
 // component SHAPE and cached); components of identical shape — e.g. the same Euler step of several parameter sets — are
 // cut identically and their segments run as rows of the same launches.
 
+// What a copy that exists as a description (ReplicaGroup) needs to know about the ORIGINAL's component, per position of its order —
+// taken from the nodes before anything runs (a segment's nodes are dismantled as soon as it has been committed).
+struct Engine::ReplicaView {
+    ReplicaGroup* g = nullptr;
+    std::vector<int32_t> rep_index, rep_root;   // recording index (→ scalar slot) and root number (-1: an inner value) of the operation
+    std::vector<double> scalar;                  // the original's scalar operand (copies without a scalar list use it)
+};
+
 struct Engine::BigDag {
     std::vector<Node*> roots;
     std::vector<Node*> order;       // all pending nodes of the component, operands before users
@@ -968,6 +1155,23 @@ struct Engine::BigDag {
     std::vector<char> escapes;      // per node of the order: needed outside the component (a handle, or a consumer elsewhere)
     std::string sig;                // shape: per op {opcode, operand ids (16 bit), escapes?}
     uint64_t hash = 0;              // of sig
+    int64_t n = 0;                  // elements per vector
+    uint32_t rep_id = 0;            // replica descriptions: as in Dag
+    bool rep_uniform = true, rep_any = false;
+    // A member WITHOUT nodes — a copy of another member's component that exists as a description: `leaves` holds the copy's operands
+    // (same numbering as the original's), values produced by one launch for a later one live in `temp` (by position of the order),
+    // root values also go to the copy's root nodes.
+    std::shared_ptr<const ReplicaView> view;
+    int copy = -1;
+    std::vector<Buffer*> temp;
+    bool described() const { return copy >= 0; }
+    Buffer* value(size_t pos) const { return described() ? temp[pos] : order[pos]->buf; }        // nullptr: not computed (yet)
+    float scalar_at(size_t pos) const {
+        if (!described()) return (float)order[pos]->scalar;
+        const ReplicaGroup* g = view->g;
+        const int32_t slot = g->scalar_slot[(size_t)view->rep_index[pos]];
+        return (float)((slot >= 0 && !g->scalars.empty()) ? g->scalars[(size_t)copy * g->n_scalars + slot] : view->scalar[pos]);
+    }
 };
 
 bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
@@ -979,9 +1183,15 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
     std::vector<Node*>& leaves = big.leaves;
     leaves.clear();
     auto visit = [&](Node* nd) { nd->mark = ep; nd->tmp_id = -1; nd->tmp_uses = 0; };
+    bool first_pending = true;
+    auto note_rep = [&](const Node* nd) {
+        if (first_pending) { big.rep_id = nd->rep_id; first_pending = false; } else if (nd->rep_id != big.rep_id) big.rep_uniform = false;
+        big.rep_any |= nd->rep_id != 0;
+    };
+    big.n = roots[0]->n;
     for (Node* root : roots) {
         if (root->mark == ep) continue;
-        visit(root);
+        visit(root); note_rep(root);
         stack.push_back({ root, 0 });
         while (!stack.empty()) {
             auto& top = stack.back();
@@ -989,7 +1199,7 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
             if (top.second < nd->n_in) {
                 Node* c = nd->in[top.second++];
                 if (c->buf) { if (c->mark != ep) { visit(c); c->tmp_id = --n_leaves; leaves.push_back(c); } }      // leaves: -1, -2, …
-                else { if (c->mark != ep) { visit(c); stack.push_back({ c, 0 }); } c->tmp_uses++; }
+                else { if (c->mark != ep) { visit(c); note_rep(c); stack.push_back({ c, 0 }); } c->tmp_uses++; }
             } else { big.order.push_back(nd); stack.pop_back(); }
         }
     }
@@ -1094,9 +1304,21 @@ bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag) {
     return true;
 }
 
+// A value of a member without nodes has been computed: it is kept for the launches that read it, and handed to the copy's root node
+// if it is one of the replicated roots.
+void Engine::commit_described(BigDag& big, size_t pos, Buffer* b) {
+    big.temp[pos] = b;                                  // owns the buffer's first reference
+    const int32_t root = big.view->rep_root[pos];
+    if (root < 0) return;
+    const ReplicaGroup* g = big.view->g;
+    Node* c = g->copy_roots[(size_t)big.copy * g->n_roots + root];
+    c->buf = b; b->refs++;
+    pend_erase(c);
+}
+
 // One segment of a planned component for every member of a group: gather the row blocks by index, launch, commit.
 void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count) {
-    const int64_t n = group[first].order[(size_t)seg.out[0]]->n;
+    const int64_t n = group[first].n;
     const size_t n_scal = seg.scal.empty() ? 1 : seg.scal.size();
     std::vector<RowSpec> rows(count);
     std::vector<float> scalars(count * n_scal, 0.0f);
@@ -1108,27 +1330,36 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
             RowSpec& r = rows[c];
             r.in.reserve(seg.in.size()); r.out.reserve(seg.out.size());
             for (int32_t i : seg.in) {
-                Node* nd = i >= 0 ? big.order[(size_t)i] : big.leaves[(size_t)(-1 - i)];
-                if (!nd->buf) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "planned segment reads a value that has not been computed");
-                r.in.push_back(nd->buf->ptr);
+                Buffer* b = i >= 0 ? big.value((size_t)i) : big.leaves[(size_t)(-1 - i)]->buf;
+                if (!b) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "planned segment reads a value that has not been computed");
+                r.in.push_back(b->ptr);
             }
             for (size_t k = 0; k < seg.out.size(); ++k) { Buffer* b = new_buffer(n); out_bufs.push_back(b); r.out.push_back(b->ptr); }
             float* sc = scalars.data() + c * n_scal;
-            for (size_t k = 0; k < seg.scal.size(); ++k) sc[k] = (float)big.order[(size_t)seg.scal[k]]->scalar;
+            for (size_t k = 0; k < seg.scal.size(); ++k) sc[k] = big.scalar_at((size_t)seg.scal[k]);
             r.scalars = sc; r.shifts = nullptr;
         }
         launch(seg.prog, n, rows, nullptr, nullptr);
     } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
     // commit (as run_dags): outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
-    for (size_t c = 0; c < count; ++c)
-        for (size_t k = 0; k < seg.out.size(); ++k) { Node* nd = group[first + c].order[(size_t)seg.out[k]]; nd->buf = out_bufs[c * seg.out.size() + k]; pend_erase(nd); }
-    for (size_t c = 0; c < count; ++c)
+    for (size_t c = 0; c < count; ++c) {
+        BigDag& big = group[first + c];
         for (size_t k = 0; k < seg.out.size(); ++k) {
-            Node* nd = group[first + c].order[(size_t)seg.out[k]];
+            Buffer* b = out_bufs[c * seg.out.size() + k];
+            if (big.described()) commit_described(big, (size_t)seg.out[k], b);
+            else { Node* nd = big.order[(size_t)seg.out[k]]; nd->buf = b; pend_erase(nd); }
+        }
+    }
+    for (size_t c = 0; c < count; ++c) {
+        BigDag& big = group[first + c];
+        if (big.described()) continue;
+        for (size_t k = 0; k < seg.out.size(); ++k) {
+            Node* nd = big.order[(size_t)seg.out[k]];
             nd->refs_int++;                 // keep alive while its expression is dismantled
             drop_expression(nd);
             nd->refs_int--;
         }
+    }
 }
 
 // ---------------------------------------------------------------- rolled loops
@@ -1279,6 +1510,9 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
     ROLL_TRACE("[fmhip roll]   begin %zu, %zu iterations of %u: %zu global, %zu carried, %zu in, %zu out, %zu scalars\n", begin, R, P, G, CI, LI, LO, LS);
     if (G > 8 || CI > 12 || CO > 12 || LI > 12 || LO > 12 || LO + CO == 0 || LS > 48) return false;
     ro.row_words = (uint32_t)(G + CI + CO + R * (LI + LO) + (R * LS + 1) / 2);
+    ro.iter_leaf.resize(R * LI);
+    for (size_t r = 0; r < R; ++r)
+        for (size_t m2 = 0; m2 < LI; ++m2) ro.iter_leaf[r * LI + m2] = -1 - operand[begin + r * P + ro.leaf_in[m2].first][(size_t)ro.leaf_in[m2].second];
     // ---- the kernel
     // elements per lane: 8 keeps more bytes in flight per wave, 4 halves the registers (more waves per SIMD to overlap the loop's
     // load → compute → store with each other); FMHIP_ROLL_ELEMS overrides for measurements
@@ -1307,27 +1541,27 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 {
     const size_t G = ro.global_leaf.size(), CI = ro.carried.size(), CO = ro.final_pos.size(), LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size();
     const size_t R = ro.iterations, P = ro.period, rw = ro.row_words;
-    const int64_t n = group[first].order[ro.begin]->n;
+    const int64_t n = group[first].n;
     std::vector<uint64_t> table(count * rw, 0);
     std::vector<Buffer*> out_bufs;
     out_bufs.reserve(count * (R * LO + CO));
-    auto ptr_of = [](Node* nd) -> uint64_t {
-        if (!nd->buf) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "rolled loop reads a value that has not been computed");
-        return (uint64_t)(uintptr_t)nd->buf->ptr;
+    auto ptr_of = [](const Buffer* b) -> uint64_t {
+        if (!b) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "rolled loop reads a value that has not been computed");
+        return (uint64_t)(uintptr_t)b->ptr;
     };
     try {
         for (size_t c = 0; c < count; ++c) {
             BigDag& big = group[first + c];
             uint64_t* row = table.data() + c * rw;
-            for (size_t k = 0; k < G; ++k) row[k] = ptr_of(big.leaves[(size_t)ro.global_leaf[k]]);
-            for (size_t k = 0; k < CI; ++k) row[G + k] = ptr_of(big.order[ro.begin - P + ro.carried[k]]);       // the iteration before the loop ran as ordinary launches
+            for (size_t k = 0; k < G; ++k) row[k] = ptr_of(big.leaves[(size_t)ro.global_leaf[k]]->buf);
+            for (size_t k = 0; k < CI; ++k) row[G + k] = ptr_of(big.value(ro.begin - P + ro.carried[k]));       // the iteration before the loop ran as ordinary launches
             float* sc = reinterpret_cast<float*>(row + G + CI + CO + R * (LI + LO));
             for (size_t r = 0; r < R; ++r) {
                 uint64_t* ip = row + G + CI + CO + r * (LI + LO);
                 const size_t base = ro.begin + r * P;
-                for (size_t m = 0; m < LI; ++m) ip[m] = ptr_of(big.order[base + ro.leaf_in[m].first]->in[ro.leaf_in[m].second]);
+                for (size_t m = 0; m < LI; ++m) ip[m] = ptr_of(big.leaves[(size_t)ro.iter_leaf[r * LI + m]]->buf);
                 for (size_t m = 0; m < LO; ++m) { Buffer* b = new_buffer(n); out_bufs.push_back(b); ip[LI + m] = (uint64_t)(uintptr_t)b->ptr; }
-                for (size_t m = 0; m < LS; ++m) sc[r * LS + m] = (float)big.order[base + ro.scal_pos[m]]->scalar;
+                for (size_t m = 0; m < LS; ++m) sc[r * LS + m] = big.scalar_at(base + ro.scal_pos[m]);
             }
             for (size_t k = 0; k < CO; ++k) { Buffer* b = new_buffer(n); out_bufs.push_back(b); row[G + CI + k] = (uint64_t)(uintptr_t)b->ptr; }    // after the per-iteration outputs, in this order
         }
@@ -1357,11 +1591,56 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
     std::vector<Node*> outs;
     outs.reserve(out_bufs.size());
     for (size_t c = 0; c < count; ++c) {
+        BigDag& big = group[first + c];
+        auto commit = [&](size_t pos) {
+            Buffer* b = out_bufs[k++];
+            if (big.described()) commit_described(big, pos, b);
+            else { Node* nd = big.order[pos]; nd->buf = b; pend_erase(nd); outs.push_back(nd); }
+        };
         for (size_t r = 0; r < R; ++r)
-            for (size_t m = 0; m < LO; ++m) { Node* nd = group[first + c].order[ro.begin + r * P + ro.out_pos[m]]; nd->buf = out_bufs[k++]; pend_erase(nd); outs.push_back(nd); }
-        for (size_t m = 0; m < CO; ++m) { Node* nd = group[first + c].order[ro.begin + (R - 1) * P + ro.final_pos[m]]; nd->buf = out_bufs[k++]; pend_erase(nd); outs.push_back(nd); }
+            for (size_t m = 0; m < LO; ++m) commit(ro.begin + r * P + ro.out_pos[m]);
+        for (size_t m = 0; m < CO; ++m) commit(ro.begin + (R - 1) * P + ro.final_pos[m]);
     }
     for (Node* nd : outs) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
+}
+
+// A component shape with a plan, for every member of a group: segment by segment (the rolled stretch as one launch once its kernel
+// exists), ≤ 1024 members per launch.
+void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group) {
+    const size_t max_batch = 1024;
+    if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
+        plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
+    bool rolled = plan.rolled.present && jit_mode != FMHIP_JIT_OFF && plan.rolled.jit && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::READY;
+    // The rolled launch carries one row table for all its members through the pinned ring (≈ 5 KB per row for the LMM step, but
+    // iterations x (inputs + outputs) words in general): as many members per launch as fit; a single row that does not fit leaves the
+    // stretch to its segments.
+    size_t rolled_batch = max_batch;
+    if (rolled) {
+        const size_t rows_fit = ring_cap_ / ((size_t)plan.rolled.row_words * 8 + 256);
+        if (rows_fit == 0) rolled = false; else rolled_batch = std::min(max_batch, rows_fit);
+    }
+    bool any_described = false;
+    for (const BigDag& b : group) any_described |= b.described();
+    auto release_temps = [&](const std::vector<int32_t>& positions) {
+        if (!any_described) return;
+        for (BigDag& b : group) {
+            if (!b.described()) continue;
+            for (int32_t pos : positions) if (Buffer* t = b.temp[(size_t)pos]) { b.temp[(size_t)pos] = nullptr; buffer_unref(t); }
+        }
+    };
+    struct TempGuard {              // whatever happens, the values held for members without nodes go back to the pool
+        Engine* e; std::vector<BigDag>& g;
+        ~TempGuard() { for (BigDag& b : g) if (b.described()) for (Buffer*& t : b.temp) if (t) { e->buffer_unref(t); t = nullptr; } }
+    } guard{ this, group };
+    bool rolled_done = false;
+    for (const BigPlan::Seg& seg : plan.segs) {
+        if (rolled && seg.zone == 1) {              // the loop's stretch: one launch of the rolled kernel instead of its segments
+            if (!rolled_done) for (size_t off = 0; off < group.size(); off += rolled_batch) run_rolled(plan.rolled, group, off, std::min(rolled_batch, group.size() - off));
+            rolled_done = true;
+        } else
+            for (size_t off = 0; off < group.size(); off += max_batch) run_planned_segment(seg, group, off, std::min(max_batch, group.size() - off));
+        release_temps(seg.free_after);
+    }
 }
 
 void Engine::run_big_group(std::vector<BigDag>& group) {
@@ -1372,28 +1651,21 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
     auto planned = plan_cache_.find(g0.hash);
     if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
     const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
-    if (planned != plan_cache_.end()) {
-        BigPlan& plan = planned->second;
-        if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
-            plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
-        const bool rolled = plan.rolled.present && jit_mode != FMHIP_JIT_OFF && plan.rolled.jit && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::READY;
-        bool rolled_done = false;
-        for (const BigPlan::Seg& seg : plan.segs) {
-            if (rolled && seg.zone == 1) {              // the loop's stretch: one launch of the rolled kernel instead of its segments
-                if (!rolled_done) for (size_t off = 0; off < group.size(); off += max_batch) run_rolled(plan.rolled, group, off, std::min(max_batch, group.size() - off));
-                rolled_done = true;
-                continue;
-            }
-            for (size_t off = 0; off < group.size(); off += max_batch) run_planned_segment(seg, group, off, std::min(max_batch, group.size() - off));
-        }
-        return;
+    if (planned != plan_cache_.end()) { run_plan(planned->second, group); return; }
+    // Members without nodes (copies that exist as a description) cannot take the general path below, which works on nodes: they
+    // follow through the plan it writes down.
+    std::vector<BigDag> described;
+    {
+        std::vector<BigDag> with_nodes;
+        for (BigDag& b : group) (b.described() ? described : with_nodes).push_back(std::move(b));
+        group.swap(with_nodes);
     }
     // First component of this shape: find the cuts (longest segment that fits one launch, again and again), run it through the
     // general path, and write the plan down.  Node -> index in g0 for the plan (segment_dag reuses the nodes' scratch fields).
     std::unordered_map<const Node*, int32_t> index_of;
-    index_of.reserve(n_ops + g0.leaves.size());
-    for (size_t i = 0; i < n_ops; ++i) index_of[g0.order[i]] = (int32_t)i;
-    for (size_t i = 0; i < g0.leaves.size(); ++i) index_of[g0.leaves[i]] = -1 - (int32_t)i;
+    index_of.reserve(n_ops + group[0].leaves.size());
+    for (size_t i = 0; i < n_ops; ++i) index_of[group[0].order[i]] = (int32_t)i;
+    for (size_t i = 0; i < group[0].leaves.size(); ++i) index_of[group[0].leaves[i]] = -1 - (int32_t)i;
     BigPlan plan;
     // A periodic stretch of the order becomes a rolled loop (one launch) as soon as its kernel is compiled; the segments cut
     // below remain its fallback, with cuts forced at the loop's ends so that either form can run between them.
@@ -1402,9 +1674,9 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
     if (ROLL) {
         std::vector<std::array<int32_t, 3>> operand(n_ops);
         for (size_t i = 0; i < n_ops; ++i)
-            for (int k = 0; k < g0.order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(g0.order[i]->in[k]);
+            for (int k = 0; k < group[0].order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(group[0].order[i]->in[k]);
         std::string source; int elems = 0;
-        if (detect_loop(g0, operand, plan.rolled, &source, &elems)) {
+        if (detect_loop(group[0], operand, plan.rolled, &source, &elems)) {
             if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
             plan.rolled.present = true;
             plan.rolled.source = source; plan.rolled.elems = elems;
@@ -1422,12 +1694,12 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
             std::vector<size_t> cheap;
             for (size_t cand = s + 1; cand <= limit && cand - s <= (size_t)FM_MAX_OPS; ++cand) {
                 Dag d;
-                if (segment_dag(g0, s, cand, d)) cheap.push_back(cand);
+                if (segment_dag(group[0], s, cand, d)) cheap.push_back(cand);
                 else if ((int)d.leaves.size() > FM_MAX_IN) break;
             }
             for (size_t k = cheap.size(); k-- > 0 && e == 0;) {
                 Dag d;
-                segment_dag(g0, s, cheap[k], d);
+                segment_dag(group[0], s, cheap[k], d);
                 if (!program_cache_.count(d.sig)) {
                     try { program_cache_[d.sig] = compile(d.ops, (int)d.leaves.size(), d.out_ids, {}, nullptr, false); }
                     catch (const Error& err) { if (err.code == FMHIP_ERR_PROGRAM_LIMIT) continue; throw; }
@@ -1444,7 +1716,7 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
             seg.prog = program_cache_.at(dags[0].sig);
             for (Node* l : dags[0].leaves) seg.in.push_back(index_of.at(l));
             for (Node* o : dags[0].outs) seg.out.push_back(index_of.at(o));
-            for (size_t i = s; i < e; ++i) if (op_info(g0.order[i]->opcode).scalar) seg.scal.push_back((int32_t)i);
+            for (size_t i = s; i < e; ++i) if (op_info(group[0].order[i]->opcode).scalar) seg.scal.push_back((int32_t)i);
             seg.zone = s < zone_begin ? 0 : (s < zone_end ? 1 : 2);
             plan.segs.push_back(std::move(seg));
         }
@@ -1454,10 +1726,18 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
         }
         s = e;
     }
-    if (collision) return;
+    // values no later segment reads: members without nodes give them back to the pool there
+    {
+        std::unordered_map<int32_t, size_t> last_reader;
+        for (size_t k = 0; k < plan.segs.size(); ++k) for (int32_t i : plan.segs[k].in) if (i >= 0) last_reader[i] = k;
+        for (const auto& kv : last_reader) plan.segs[kv.second].free_after.push_back(kv.first);
+    }
+    if (collision) { if (!described.empty()) run_plan(plan, described); return; }
     for (BigPlan::Seg& seg : plan.segs) seg.prog->refs++;              // the plan holds its programs (pool_purge drops both caches together)
-    plan.sig = g0.sig;
-    plan_cache_[g0.hash] = std::move(plan);
+    plan.sig = group[0].sig;
+    const uint64_t key = group[0].hash;
+    plan_cache_[key] = std::move(plan);
+    if (!described.empty()) run_plan(plan_cache_[key], described);
 }
 
 bool Engine::try_fused(const std::vector<Node*>& roots) {
@@ -1467,6 +1747,7 @@ bool Engine::try_fused(const std::vector<Node*>& roots) {
 }
 
 void Engine::materialize(const std::vector<Node*>& targets) {
+    expand_replicas_below(targets);                 // a single expression is executed, not everything pending: descriptions of copies it touches become nodes first
     for (Node* t : targets) {
         if (t->buf) continue;
         if (try_fused({ t })) continue;
@@ -1526,20 +1807,48 @@ void Engine::flush_all() {
         std::unordered_map<std::string, std::vector<Dag>> groups;
         std::vector<std::string> group_order;
         std::vector<Node*> leftovers;
+        bool expanded = false;
         for (int c : comp_order) {
             Dag d;
             if (!build_dag(comps[c], d)) { for (Node* r : comps[c]) leftovers.push_back(r); continue; }
+            // A component of a replicated graph runs with its copies as further rows — if it still is exactly what was replicated: all
+            // its operations belong to ONE live description and nothing but the replicated roots escapes from it.  Otherwise every
+            // description it touches becomes ordinary nodes first, and the round starts again on the larger pending graph.
+            if (d.rep_any) {
+                ReplicaGroup* g = clean_replica_group(d.rep_id, d.rep_uniform);
+                for (size_t k = 0; g && k < d.outs.size(); ++k) if (d.outs[k]->rep_root < 0 || d.outs[k]->rep_copy) g = nullptr;
+                if (!g) { const size_t before = replicas_.size(); expand_replicas_below(comps[c]); expanded |= replicas_.size() != before; }
+                if (expanded) break;                                 // (an expansion may release nodes other components were found through)
+            }
             std::string key = d.sig; key.push_back('#'); key += std::to_string(d.roots[0]->n);
             if (!groups.count(key)) group_order.push_back(key);
             groups[key].push_back(std::move(d));
         }
+        if (expanded) continue;
         for (const std::string& key : group_order) {
             std::vector<Dag>& g = groups[key];
-            const size_t max_batch = 1024;
-            for (size_t off = 0; off < g.size(); off += max_batch) {
-                std::vector<Dag> part(std::make_move_iterator(g.begin() + off), std::make_move_iterator(g.begin() + std::min(g.size(), off + max_batch)));
-                if (!run_dags(part)) for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r);
+            // members: every component of this structure, each followed by its copies that exist as a description
+            std::vector<Dag> members;
+            std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done;
+            const Dag proto = g[0];                                   // carries the structure for launches that start with another member
+            for (Dag& d : g) {
+                ReplicaGroup* rg = d.rep_any ? clean_replica_group(d.rep_id, d.rep_uniform) : nullptr;
+                if (rg) {
+                    std::vector<int> roots_done;
+                    for (Node* o : d.outs) roots_done.push_back(o->rep_root);
+                    done.push_back({ rg, std::move(roots_done) });
+                    const size_t at = members.size();
+                    members.push_back(std::move(d));
+                    for (int j = 0; j < rg->n_copies; ++j) members.push_back(replica_dag(members[at], rg, j));
+                } else members.push_back(std::move(d));
             }
+            const size_t max_batch = 1024;
+            bool ran = true;
+            for (size_t off = 0; off < members.size(); off += max_batch) {
+                std::vector<Dag> part(std::make_move_iterator(members.begin() + off), std::make_move_iterator(members.begin() + std::min(members.size(), off + max_batch)));
+                if (!run_dags(part, nullptr, nullptr, nullptr, &proto)) { ran = false; for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r); }
+            }
+            if (ran) for (auto& kv : done) replica_roots_done(kv.first, kv.second);
         }
         // components that do not fit one launch: cut into segments; components of identical shape share the cuts and the launches
         if (!leftovers.empty()) {
@@ -1557,6 +1866,12 @@ void Engine::flush_all() {
                 if (roots.empty()) continue;
                 BigDag b;
                 if (!build_big(roots, b)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "pending expression too large");
+                if (b.rep_any) {                                         // as above
+                    ReplicaGroup* g = clean_replica_group(b.rep_id, b.rep_uniform);
+                    for (size_t i = 0; g && i < b.order.size(); ++i) if (b.escapes[i] && (b.order[i]->rep_root < 0 || b.order[i]->rep_copy)) g = nullptr;
+                    if (!g) { const size_t before = replicas_.size(); expand_replicas_below(roots); expanded |= replicas_.size() != before; }
+                    if (expanded) break;
+                }
                 uint64_t key = b.hash ^ ((uint64_t)roots[0]->n * 0x9E3779B97F4A7C15ull);
                 auto& members = big_groups[key];
                 if (members.empty()) big_group_order.push_back(key);
@@ -1568,9 +1883,59 @@ void Engine::flush_all() {
                 }
                 members.push_back(std::move(b));
             }
-            for (uint64_t key : big_group_order) run_big_group(big_groups[key]);
+            if (expanded) continue;
+            for (uint64_t key : big_group_order) {
+                std::vector<BigDag>& originals = big_groups[key];
+                std::vector<BigDag> members;
+                std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done;
+                for (BigDag& b : originals) {
+                    ReplicaGroup* rg = b.rep_any ? clean_replica_group(b.rep_id, b.rep_uniform) : nullptr;
+                    if (!rg) { members.push_back(std::move(b)); continue; }
+                    auto view = std::make_shared<ReplicaView>();
+                    view->g = rg;
+                    const size_t m = b.order.size();
+                    view->rep_index.resize(m); view->rep_root.resize(m); view->scalar.resize(m);
+                    std::vector<int> roots_done;
+                    for (size_t i = 0; i < m; ++i) {
+                        const Node* nd = b.order[i];
+                        view->rep_index[i] = nd->rep_index; view->rep_root[i] = nd->rep_root; view->scalar[i] = nd->scalar;
+                        if (nd->rep_root >= 0) roots_done.push_back(nd->rep_root);
+                    }
+                    done.push_back({ rg, std::move(roots_done) });
+                    const size_t n_map = rg->leaf_from.size();
+                    const size_t at = members.size();
+                    members.push_back(std::move(b));
+                    for (int j = 0; j < rg->n_copies; ++j) {
+                        BigDag r;
+                        r.n = members[at].n; r.view = view; r.copy = j;
+                        r.leaves.reserve(members[at].leaves.size());
+                        for (Node* l : members[at].leaves) r.leaves.push_back(l->leaf_rep_id == rg->id ? rg->leaf_to[(size_t)j * n_map + (size_t)l->leaf_rep_index] : l);
+                        r.temp.assign(m, nullptr);
+                        members.push_back(std::move(r));
+                    }
+                }
+                run_big_group(members);
+                for (auto& kv : done) replica_roots_done(kv.first, kv.second);
+            }
         }
     }
+}
+
+// A copy of the component `d` that exists as a description: the vectors it reads, the root nodes that receive its results, its scalars.
+Engine::Dag Engine::replica_dag(const Dag& d, ReplicaGroup* g, int copy) {
+    Dag r;
+    const size_t n_map = g->leaf_from.size();
+    r.leaves.reserve(d.leaves.size());
+    for (Node* l : d.leaves) r.leaves.push_back(l->leaf_rep_id == g->id ? g->leaf_to[(size_t)copy * n_map + (size_t)l->leaf_rep_index] : l);
+    r.outs.reserve(d.outs.size());
+    for (Node* o : d.outs) r.outs.push_back(g->copy_roots[(size_t)copy * g->n_roots + (size_t)o->rep_root]);
+    for (const Node* nd : d.order)
+        if (op_info(nd->opcode).scalar) {
+            const int32_t slot = g->scalar_slot[(size_t)nd->rep_index];
+            r.scalars.push_back((float)((slot >= 0 && !g->scalars.empty()) ? g->scalars[(size_t)copy * g->n_scalars + slot] : nd->scalar));
+        }
+    if (r.scalars.empty()) r.scalars.push_back(0.0f);
+    return r;
 }
 
 // ---------------------------------------------------------------- reductions
@@ -1594,6 +1959,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         // Only while the launch is small: a launch with a fused reduction has ONE workgroup per 8192 elements of a row (the span
         // fixes the order of the partial sums, §4.1) — a single row of 1 M paths is 122 workgroups on 256 CUs, fine for one
         // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
+        expand_replicas_below({ nd });
         std::vector<Dag> one(1);
         if (fusion && build_dag({ nd }, one[0]) && nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) && run_dags(one, &shift, host_out, dev_out)) return;
         if (!nd->buf) materialize({ nd });

@@ -77,6 +77,37 @@ struct Node {
     // ≈ 60 ns in all, a hash-set insert was a third of it)
     Node*   pend_prev = nullptr;
     Node*   pend_next = nullptr;
+    // replica groups (fmhip_graph_clone, see ReplicaGroup): rep_id != 0 marks an operation of a replicated pending graph
+    // (rep_copy == 0; rep_index = its position in recording order, rep_root = its number among the replicated roots or -1) or
+    // the root of a copy that exists as a description only (rep_copy = copy number + 1, rep_root = which root)
+    uint32_t rep_id = 0;
+    int32_t  rep_index = -1, rep_root = -1;
+    uint32_t rep_copy = 0;
+    uint32_t leaf_rep_id = 0;   // a substituted operand (leaf_from[i]) of that live group …
+    int32_t  leaf_rep_index = -1;   // … i
+};
+
+// Copies of a pending graph that exist as a DESCRIPTION until the graph runs (fmhip_graph_clone).  A copy differs from the
+// original in the vectors it reads (leaf_from[i] → leaf_to[copy][i]) and in its scalar operands, never in structure: instead of
+// duplicating every operation node — and walking, signing, scheduling and dismantling the duplicates at the next flush, which is
+// where a launch-bound caller's host time went (LMM calibration: 17.7 of 21 M nodes per run were such duplicates) — the engine
+// creates only the copies' ROOT nodes and, when the original's components are executed, appends one batch row per copy to the
+// original's launches: inputs by substitution, scalars from the copy's list, outputs into the copy's root nodes.  Whenever the
+// original's graph is no longer what was replicated (operations recorded on top of it, other handles inside it, a copy's root
+// used before the flush), the description is expanded into ordinary nodes first (expand_replicas): same results, old cost.
+struct ReplicaGroup {
+    uint32_t id = 0;
+    int n_copies = 0, n_roots = 0, n_scalars = 0;
+    int64_t id_base = 0;                        // copy j owns the ids [id_base + j·graph_size, +graph_size): its operation with recording index i
+    int graph_size = 0;                         //   has the id id_base + j·graph_size + i, whether it ever becomes a node or not
+    std::vector<Node*> roots;                   // the original's roots, or nullptr where the root was a vector already (each pending one holds one refs_ext of the group)
+    std::vector<char>  root_done;               // per root: executed (its copies have their buffers)
+    std::vector<Node*> leaf_from;               // substituted operands (each holds one refs_int)
+    std::vector<Node*> leaf_to;                 // [copy][i] (each holds one refs_int)
+    std::vector<int32_t> scalar_slot;           // per operation (recording index): index into a copy's scalar list, or -1
+    std::vector<double> scalars;                // [copy][n_scalars]; empty = the original's
+    std::vector<Node*> copy_roots;              // [copy][root]: pending nodes without an expression (each holds one refs_int), nullptr for a shared vector
+    int remaining = 0;                          // roots not executed yet
 };
 
 // ---------------------------------------------------------------- compiled programs
@@ -222,7 +253,8 @@ private:
     // the plan: no Dag, no strings, no hash lookups per segment (the general path cost ≈ 16 µs of host time per segment and
     // member, which made two-step groups of the LMM simulation host-bound).
     struct BigPlan {
-        struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; int zone = 0; };    // zone: 0 before a rolled loop, 1 inside (its fallback), 2 behind
+        struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; int zone = 0;       // zone: 0 before a rolled loop, 1 inside (its fallback), 2 behind
+                     std::vector<int32_t> free_after; };                                              // values no later segment reads (members without nodes release them here)
         std::vector<Seg> segs;
         std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
         // A periodic stretch of the scheduled order — the same few operations over one component after another, each iteration
@@ -236,6 +268,7 @@ private:
             std::vector<int32_t> global_leaf;                           // indices into BigDag::leaves: inputs every iteration reads
             std::vector<uint32_t> carried;                              // positions whose value of the PREVIOUS iteration is read
             std::vector<std::pair<uint32_t, uint32_t>> leaf_in;         // (position, operand) of the first use of each per-iteration input
+            std::vector<int32_t> iter_leaf;                             // [iteration][input]: which leaf (index into BigDag::leaves) that is
             std::vector<uint32_t> out_pos, scal_pos;                    // positions stored per iteration; positions with a scalar operand
             std::vector<uint32_t> final_pos;                            // positions whose value of the LAST iteration is stored behind the loop
         } rolled;
@@ -244,13 +277,26 @@ private:
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     void run_big_group(std::vector<BigDag>& group);
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count);
+    void run_plan(BigPlan& plan, std::vector<BigDag>& group);
+    void commit_described(BigDag& big, size_t pos, Buffer* b);
     bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
     int64_t n_rolled_launches_ = 0;
+    // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)
+    std::unordered_map<uint32_t, ReplicaGroup*> replicas_;
+    uint32_t next_replica_id_ = 1;
+    ReplicaGroup* replica_of(const Node* nd) const { if (!nd->rep_id) return nullptr; auto it = replicas_.find(nd->rep_id); return it == replicas_.end() ? nullptr : it->second; }
+    void expand_replicas(ReplicaGroup* g);                       // the description becomes ordinary pending nodes (fallback; also frees the group)
+    void expand_replicas_below(const std::vector<Node*>& targets);   // every group the pending graph below `targets` touches
+    void replica_roots_done(ReplicaGroup* g, const std::vector<int>& roots);   // those roots have been executed with all their copies
+    void destroy_replica_group(ReplicaGroup* g);
+    struct ReplicaView;
     std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
     // reduce_shift != nullptr (one DAG only): the root is ALSO reduced in the same launch — {Σ, Σ(x-shift)², min, max} into host_moments / dev_moments
-    bool run_dags(std::vector<Dag>& dags, const double* reduce_shift = nullptr, fmhip_moments* host_moments = nullptr, void* dev_moments = nullptr);
+    bool run_dags(std::vector<Dag>& dags, const double* reduce_shift = nullptr, fmhip_moments* host_moments = nullptr, void* dev_moments = nullptr, const Dag* proto = nullptr);
+    Dag replica_dag(const Dag& d, ReplicaGroup* g, int copy);
+    ReplicaGroup* clean_replica_group(uint32_t rep_id, bool uniform) const { if (!rep_id || !uniform) return nullptr; auto it = replicas_.find(rep_id); return it == replicas_.end() ? nullptr : it->second; }
 };
 
 void hip_check(hipError_t e, const char* what);

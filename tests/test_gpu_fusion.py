@@ -192,10 +192,14 @@ def test_fusion_hold_batches_long_chains(gpu, oracle):
         launches_plain = gpu.pool_stats().n_kernel_launches - before
         before = gpu.pool_stats().n_kernel_launches
         with gpu.holding():
-            assert gpu.fusion_hold(True) is True                       # already held by the context manager
+            assert gpu.fusion_hold(True) == 1                          # already held by the context manager
             res_held = record(rvs)
             assert gpu.pool_stats().n_kernel_launches == before        # nothing ran on the engine's own accord
-        assert gpu.fusion_hold(False) is False                         # the context manager restored "not held"
+        assert gpu.fusion_hold(False) == 0                             # the context manager restored "not held"
+        assert gpu.fusion_hold(2) == 0                                 # a soft hold …
+        with gpu.holding():
+            pass
+        assert gpu.fusion_hold(0) == 2                                 # … comes back from the context manager as a soft hold
         assert gpu.pool_stats().n_kernel_launches == before            # releasing the hold executes nothing by itself
         gpu.flush()
         launches_held = gpu.pool_stats().n_kernel_launches - before
