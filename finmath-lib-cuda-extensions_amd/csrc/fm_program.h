@@ -119,7 +119,9 @@ struct DevRolledArgs {
     uint32_t row_words;                  // row stride in 8-byte words
     uint32_t iterations;
     uint32_t pad;
+    uint64_t dump;                       // FM_DUMP_BYTES of device memory nobody reads: where lanes past the end of a vector put their stores
 };
+constexpr size_t FM_DUMP_BYTES = (size_t)FM_BLOCK * 16 * 4;      // one float4 per lane and per float4-per-lane of the widest kernel (E = 16)
 static_assert(FM_INLINE_WORDS >= FM_ROW_WORDS_MAX, "one row always fits");
 
 } // namespace fm

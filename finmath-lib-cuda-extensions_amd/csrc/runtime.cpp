@@ -152,6 +152,7 @@ void Engine::init(int device_index) {
     }
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
+    hip_check(hipMalloc(&dump_dev_, FM_DUMP_BYTES), "hipMalloc(dump)");
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
     hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
@@ -198,7 +199,8 @@ void Engine::shutdown() {
     if (ring_host_) (void)hipHostFree(ring_host_);
     if (ring_dev_) (void)hipFree(ring_dev_);
     if (counters_dev_) (void)hipFree(counters_dev_);
-    counters_dev_ = nullptr;
+    if (dump_dev_) (void)hipFree(dump_dev_);
+    counters_dev_ = nullptr; dump_dev_ = nullptr;
     stage_ = ring_host_ = ring_dev_ = nullptr; stage_cap_ = ring_cap_ = ring_off_ = 0;
     (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
@@ -1570,6 +1572,7 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
             DevRolledArgs args{};
             args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = (uint32_t)R;
+            args.dump = (uint64_t)(uintptr_t)dump_dev_;
             const size_t table_bytes = table.size() * 8;
             const size_t ring_off = ring_reserve(table_bytes);
             std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);

@@ -224,6 +224,7 @@ private:
     void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
     uint64_t ring_generation_ = 1;          // bumped on every wrap: device copies of older tables may be overwritten
     uint32_t* counters_dev_ = nullptr;      // arrival counters of the fused final combine (65536 rows, zero between launches)
+    void*  dump_dev_ = nullptr;             // FM_DUMP_BYTES nobody reads: target of the stores of lanes past the end of a vector (rolled kernels)
     void*  ensure_stage(size_t bytes);
     size_t ring_reserve(size_t bytes);
 
