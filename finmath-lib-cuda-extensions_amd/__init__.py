@@ -82,6 +82,14 @@ def fusion_hold(hold) -> int:
     return prev.value
 
 
+def set_step_grouping(steps: int) -> int:
+    """fmhip_set_step_grouping: the engine keeps the methods recorded between `steps` time-step boundaries (first use of a Brownian
+    increment with a new time index) pending and executes them together; 0 = off.  Returns the previous setting."""
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_set_step_grouping(int(steps), _C.byref(prev)))
+    return prev.value
+
+
 class holding:
     """`with fm.holding(): …` — record under fusion_hold(True), restore the previous setting on exit (no flush)."""
 

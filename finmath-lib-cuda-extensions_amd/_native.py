@@ -20,7 +20,7 @@ SYMBOLS = [
     "fmhip_vec_create_uninitialized", "fmhip_vec_retain", "fmhip_vec_release", "fmhip_vec_size",
     "fmhip_vec_read_double", "fmhip_vec_read_float", "fmhip_vec_device_ptr",
     "fmhip_call_v1s0", "fmhip_call_v1s1", "fmhip_call_v2s0", "fmhip_call_v2s1", "fmhip_call_v3s0",
-    "fmhip_set_fusion", "fmhip_flush", "fmhip_fusion_hold", "fmhip_graph_clone", "fmhip_graph_scalars", "fmhip_set_math_mode",
+    "fmhip_set_fusion", "fmhip_flush", "fmhip_fusion_hold", "fmhip_set_step_grouping", "fmhip_graph_clone", "fmhip_graph_scalars", "fmhip_set_math_mode",
     "fmhip_reduce_moments", "fmhip_reduce_moments_batch", "fmhip_reduce_moments_batch_device", "fmhip_reduce_moments_device",
     "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count",
     "fmhip_program_run", "fmhip_program_run_into",
@@ -125,7 +125,7 @@ def lib():
         "fmhip_call_v1s0": [i32, vec, pv], "fmhip_call_v1s1": [i32, vec, dbl, pv],
         "fmhip_call_v2s0": [i32, vec, vec, pv], "fmhip_call_v2s1": [i32, vec, vec, dbl, pv],
         "fmhip_call_v3s0": [i32, vec, vec, vec, pv],
-        "fmhip_set_fusion": [i32, C.POINTER(i32)], "fmhip_flush": [], "fmhip_fusion_hold": [i32, C.POINTER(i32)], "fmhip_set_math_mode": [i32, C.POINTER(i32)],
+        "fmhip_set_fusion": [i32, C.POINTER(i32)], "fmhip_flush": [], "fmhip_fusion_hold": [i32, C.POINTER(i32)], "fmhip_set_step_grouping": [i32, C.POINTER(i32)], "fmhip_set_math_mode": [i32, C.POINTER(i32)],
         "fmhip_graph_clone": [pv, i32, i32, pv, pv, i32, C.POINTER(dbl), i32, pv], "fmhip_graph_scalars": [pv, i32, C.POINTER(dbl), i32, C.POINTER(i32)],
         "fmhip_reduce_moments": [vec, dbl, C.POINTER(Moments)], "fmhip_reduce_moments_batch": [pv, i32, C.POINTER(dbl), C.POINTER(Moments)], "fmhip_reduce_moments_batch_device": [pv, i32, C.POINTER(dbl), vp], "fmhip_reduce_moments_device": [vec, dbl, vp],
         "fmhip_program_create": [C.POINTER(ProgOp), i32, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), i32, pv],

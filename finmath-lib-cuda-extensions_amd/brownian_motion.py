@@ -51,10 +51,6 @@ class BrownianMotionHip:
         self.randomVariableFactory = random_variable_factory or RandomVariableHipFactory()
         self._increments = None                 # lazy initialisation (:97)
         self._lock = threading.Lock()
-        # Time-step grouping on the caller's behalf (host/random_variable.hpp: BrownianMotionHip::stepBoundary): > 0 = the methods
-        # recorded while a scheme asks for the increments of that many consecutive time indices are executed together.
-        self.groupSteps = int(os.environ.get("FMHIP_BM_GROUP_STEPS", "0"))
-        self._last_index, self._steps_since_flush = -1, 0
 
     def getCloneWithModifiedSeed(self, seed):   # :111-113
         return BrownianMotionHip(self.timeDiscretization, self.numberOfFactors, self.numberOfPaths, seed,
@@ -68,26 +64,12 @@ class BrownianMotionHip:
         with self._lock:
             if self._increments is None:
                 self._generate()
-            if self.groupSteps > 0 and time_index != self._last_index:
-                self._step_boundary(time_index)
         return self._increments[time_index][factor]
 
     def setGroupSteps(self, steps):
-        self.groupSteps = int(steps)
-
-    def _step_boundary(self, time_index):
-        self._last_index = time_index
-        if time_index == 0:
-            self._steps_since_flush = 0
-        if self._steps_since_flush == 0:
-            N.check(N.lib().fmhip_fusion_hold(2, None))       # soft hold: lifted by the engine itself if nobody flushes
-        self._steps_since_flush += 1
-        if self._steps_since_flush > self.groupSteps:
-            N.check(N.lib().fmhip_flush())
-            self._steps_since_flush = 1
-        if time_index == self.timeDiscretization.getNumberOfTimeSteps() - 1:
-            self._steps_since_flush, self._last_index = 0, -1
-            N.check(N.lib().fmhip_fusion_hold(0, None))       # last step: what follows is not ours to group
+        """Time-step grouping is the engine's business since round 3 (fmhip_set_step_grouping: it watches for the first use of an
+        increment with a new time index itself, whatever class hands the increments out); kept for callers of round 2."""
+        N.check(N.lib().fmhip_set_step_grouping(int(steps), None))
 
     def getIncrement(self, time_index, factor):           # :236-238
         return self.getBrownianIncrement(time_index, factor)

@@ -111,6 +111,15 @@ int fmhip_fusion_hold(int hold, int* previous) {
         e.fusion_hold = hold == 2 ? 2 : (hold != 0 ? 1 : 0);
     });
 }
+int fmhip_set_step_grouping(int steps, int* previous) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        e.require_init();
+        if (steps < 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "negative number of time steps");
+        if (previous) *previous = e.group_steps;
+        e.group_steps = steps;
+    });
+}
 int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
                       const double* scalars, int n_scalars, fmhip_vec* out) {
     return guarded([&] { Engine::get().graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out); });
@@ -131,7 +140,7 @@ int fmhip_set_math_mode(int mode, int* previous) {
         e.math_mode = mode;
     });
 }
-int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); }); }
+int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); Engine::get().end_step_group(); }); }
 
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     return guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr); });

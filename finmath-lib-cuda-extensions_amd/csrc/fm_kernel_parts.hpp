@@ -158,7 +158,8 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
                                               const float (&acc_min)[NRED], const float (&acc_max)[NRED],
                                               const unsigned long long (&nan_mask)[NRED],
                                               double* __restrict__ partials, const uint32_t row,
-                                              double* __restrict__ results, uint32_t* __restrict__ counter)      // counter: this row's arrival counter
+                                              double* __restrict__ results, uint32_t* __restrict__ counter,       // counter: this row's arrival counter
+                                              uint64_t* done_flag, const uint64_t done_value)                       // see DevProgramArgs::done_flag
 {
     __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
     __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
@@ -231,7 +232,11 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
             }
         }
     }
-    if (G == 1u) return;
+    if (G == 1u) {
+        // results in pinned host memory, then the flag the host polls (release at system scope: the results are visible before it)
+        if (done_flag && lane == 63u) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (lane == 63u) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -253,6 +258,7 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
             o[2] = (mn != mn) ? __builtin_nan("") : (double)mn; o[3] = (mx != mx) ? __builtin_nan("") : (double)mx;
         }
     }
+    if (done_flag && lane == 63u) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 } // namespace fm

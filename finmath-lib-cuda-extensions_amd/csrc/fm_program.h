@@ -102,6 +102,8 @@ struct DevProgramArgs {
     int64_t  n;                          // elements per vector
     double*   results;                   // [batch][n_red][4] final {Σ, Σ², min, max} (written by the last workgroup of a row)
     uint32_t* counters;                  // [batch] arrival counters of the fused final combine, zero between launches
+    uint64_t* done_flag;                 // batch == 1 with the results wanted on the host: the wave that writes the final moments stores done_value here
+    uint64_t  done_value;                //   afterwards (system-scope release) — the host polls pinned memory instead of synchronising the stream; else nullptr
     uint32_t out_reg[FM_MAX_OUT];        // 32-bit so that they are fetched with scalar loads (gfx9 has no s_load_u8)
     uint32_t red_reg[FM_MAX_RED];
     DevOp    ops[FM_MAX_OPS + 2];            // two slack entries: the kernel prefetches ops[pc+1], ops[pc+2]

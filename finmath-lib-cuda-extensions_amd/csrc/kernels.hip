@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     for (int r = 0; r < NRED; ++r) red_finish(reinterpret_cast<const double*>(rowp)[n_in + n_out + r], acc_sq[r], nan_mask[r]);
 
     // ---- workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup
-    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE);
+    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE, A.done_flag, A.done_value);
 }
 
 // ---------------------------------------------------------------------------------------------

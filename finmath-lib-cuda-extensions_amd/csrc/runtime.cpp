@@ -13,6 +13,9 @@
 #include <map>
 #include <sstream>
 #include <unordered_set>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace fm {
 
@@ -166,6 +169,9 @@ void Engine::init(int device_index) {
     }
     jit_.start(device_index);
     g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr;
+    for (const char* name : { "FMHIP_BM_GROUP_STEPS", "FMHIP_GROUP_STEPS" })       // (the first: where round 2 had this, in BrownianMotionHip)
+        if (const char* e = std::getenv(name)) { const int v = std::atoi(e); if (v >= 0) group_steps = v; }
+    group_bm_id_ = 0; group_last_step_ = -1; group_steps_pending_ = 0; group_hold_ = false;
     if (const char* e = std::getenv("FMHIP_FUSION_MAX_WEIGHT")) { const int v = std::atoi(e); if (v > 0) fusion_max_weight_override(v); }
     initialized_ = true;
 }
@@ -189,7 +195,7 @@ void Engine::shutdown() {
     node_pool_.clear();
     for (auto& kv : programs_) if (--kv.second->refs == 0) delete kv.second;
     programs_.clear();
-    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) if (--seg.prog->refs == 0) delete seg.prog;
+    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) { if (--seg.prog->refs == 0) delete seg.prog; delete seg.prog_red; }
     plan_cache_.clear();
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
     program_cache_.clear();
@@ -356,6 +362,7 @@ fmhip_vec Engine::create_filled(int64_t n, float v) {
 
 void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
     require_init();
+    end_step_group();
     Node* nd = node(h);
     if (n != nd->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "read of " + std::to_string(n) + " elements from a vector of " + std::to_string(nd->n));
     if (n > 0 && !dst) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null host pointer");
@@ -373,6 +380,7 @@ void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
 
 void* Engine::device_ptr(fmhip_vec h) {
     require_init();
+    end_step_group();
     Node* nd = node(h);
     if (!nd->buf) materialize({nd});
     return nd->buf->ptr;
@@ -673,6 +681,17 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     }
     args.results = (double*)results;
     args.counters = counters_dev_;
+    // One row, results wanted on the host (`chain.getAverage()`): the kernel raises a flag in pinned memory behind the results and the
+    // host POLLS it instead of synchronising the stream.  A caller that values one product after the other (finmath-lib's
+    // calibration: 144 getAverage() per objective evaluation) pays the wake-up of hipStreamSynchronize and, measured, a launch
+    // that takes 20–25 µs instead of 5 right after it, once per product.
+    static const bool POLL = [] { const char* e = std::getenv("FMHIP_POLL"); return !(e && e[0] == '0'); }();
+    volatile uint64_t* poll_flag = nullptr;
+    if (POLL && results_on_host && batch == 1) {
+        poll_flag = reinterpret_cast<volatile uint64_t*>((char*)results + (((size_t)n_red * 32 + 63) & ~size_t(63)));      // (ensure_stage hands out at least 1 MB)
+        *poll_flag = 0;
+        args.done_flag = const_cast<uint64_t*>(poll_flag); args.done_value = ++poll_sequence_;
+    } else { args.done_flag = nullptr; args.done_value = 0; }
     auto cleanup = [&]() {
         if (partials) pool_.release(partials, partials_cap);
         if (results && !dev_moments && !results_on_host) pool_.release(results, results_cap);
@@ -702,7 +721,18 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
                 const size_t bytes = (size_t)batch * n_red * 32;
                 void* st = ensure_stage(bytes);
                 if (!results_on_host) hip_check(hipMemcpyAsync(st, results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H");
-                hip_check(hipStreamSynchronize(stream_), "moments sync");
+                bool arrived = false;
+                if (poll_flag) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (uint32_t spins = 1; !(arrived = *poll_flag == args.done_value); ++spins) {
+#if defined(__x86_64__)
+                        _mm_pause();
+#endif
+                        if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;      // a long kernel: wait the ordinary way
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
+                if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
                 std::memcpy(host_moments, st, bytes);
             }
         }
@@ -739,21 +769,38 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     for (int i = 1; i < n_in; ++i)
         if (ins[i]->n != ins[0]->n)
             throw Error(FMHIP_ERR_SIZE_MISMATCH, "operand sizes differ: " + std::to_string(ins[0]->n) + " vs " + std::to_string(ins[i]->n));
+    if (fusion && group_steps > 0 && fusion_hold == 0)         // a caller's own hold (or eager mode) leaves nothing to group on its behalf
+        for (int i = 0; i < n_in; ++i)
+            if (ins[i]->bm_id && (ins[i]->bm_step != group_last_step_ || ins[i]->bm_id != group_bm_id_)) step_boundary(ins[i]);
     Node* nd = new_node(ins[0]->n);
     nd->opcode = opcode; nd->n_in = n_in; nd->scalar = scalar;
     int w = 1;
     for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
     nd->weight = w;
     pend_insert(nd);
-    if (!fusion || (w > FUSION_MAX_WEIGHT && !fusion_hold)) {
+    const bool held = fusion_hold != 0 || group_hold_;
+    if (!fusion || (w > FUSION_MAX_WEIGHT && !held)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
-    } else if ((FUSION_MAX_PENDING && !fusion_hold && n_pending_ > FUSION_MAX_PENDING) || (fusion_hold == 2 && n_pending_ > FUSION_SOFT_CAP)) {
+    } else if ((FUSION_MAX_PENDING && !held && n_pending_ > FUSION_MAX_PENDING) || ((fusion_hold == 2 || (group_hold_ && fusion_hold == 0)) && n_pending_ > FUSION_SOFT_CAP)) {
         const fmhip_vec id = nd->id;
         flush_all();
         return id;
     }
     return nd->id;
+}
+
+// The first use of a Brownian increment with a new time index: a time step of the caller's discretisation scheme begins (what
+// BrownianMotionHip did for itself in round 2, now for every caller of fmhip_bm_generate's vectors, whatever class wraps them).
+// Index 0, or an index below the last one, starts a new simulation; the last index ends the grouping — what follows the
+// simulation is not the scheme's to group.
+void Engine::step_boundary(const Node* inc) {
+    const bool restart = inc->bm_id != group_bm_id_ || inc->bm_step <= group_last_step_ || inc->bm_step == 0;
+    group_bm_id_ = inc->bm_id; group_last_step_ = inc->bm_step;
+    if (restart) group_steps_pending_ = 0;
+    if (group_steps_pending_ == 0) group_hold_ = true;
+    if (++group_steps_pending_ > group_steps) { flush_all(); group_steps_pending_ = 1; }
+    if (inc->bm_step == inc->bm_steps - 1) { group_steps_pending_ = 0; group_last_step_ = -1; group_bm_id_ = 0; group_hold_ = false; }
 }
 
 // ---------------------------------------------------------------- replication of pending graphs (fmhip_graph_clone)
@@ -1319,7 +1366,7 @@ void Engine::commit_described(BigDag& big, size_t pos, Buffer* b) {
 }
 
 // One segment of a planned component for every member of a group: gather the row blocks by index, launch, commit.
-void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count) {
+void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr, Program* prog_red) {
     const int64_t n = group[first].n;
     const size_t n_scal = seg.scal.empty() ? 1 : seg.scal.size();
     std::vector<RowSpec> rows(count);
@@ -1339,9 +1386,10 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
             for (size_t k = 0; k < seg.out.size(); ++k) { Buffer* b = new_buffer(n); out_bufs.push_back(b); r.out.push_back(b->ptr); }
             float* sc = scalars.data() + c * n_scal;
             for (size_t k = 0; k < seg.scal.size(); ++k) sc[k] = big.scalar_at((size_t)seg.scal[k]);
-            r.scalars = sc; r.shifts = nullptr;
+            r.scalars = sc; r.shifts = rr ? &rr->shift : nullptr;
         }
-        launch(seg.prog, n, rows, nullptr, nullptr);
+        if (rr) { launch(prog_red, n, rows, rr->host_out, rr->dev_out); rr->done = true; }
+        else launch(seg.prog, n, rows, nullptr, nullptr);
     } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
     // commit (as run_dags): outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t c = 0; c < count; ++c) {
@@ -1609,7 +1657,7 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 
 // A component shape with a plan, for every member of a group: segment by segment (the rolled stretch as one launch once its kernel
 // exists), ≤ 1024 members per launch.
-void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group) {
+void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr) {
     const size_t max_batch = 1024;
     if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
         plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
@@ -1635,18 +1683,42 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group) {
         Engine* e; std::vector<BigDag>& g;
         ~TempGuard() { for (BigDag& b : g) if (b.described()) for (Buffer*& t : b.temp) if (t) { e->buffer_unref(t); t = nullptr; } }
     } guard{ this, group };
+    // The variant of the last segment that also reduces the component's root, for `chain.getAverage()` on a single large expression: one
+    // launch and one read of the root less than a stand-alone reduction behind the segment.  Only when that variant accumulates like
+    // the stand-alone reduction program does (8 elements per lane: the sums are then the same to the last bit).
+    Program* prog_red = nullptr;
+    if (rr && group.size() == 1 && !group[0].described() && !plan.segs.empty()) {
+        BigPlan::Seg& last = plan.segs.back();
+        const int32_t root_pos = (int32_t)group[0].order.size() - 1;
+        size_t k_root = last.out.size();
+        for (size_t k = 0; k < last.out.size(); ++k) if (last.out[k] == root_pos) k_root = k;
+        // (the size gate of reduce(): a launch with a fused reduction has one workgroup per 8192 elements of a row — fine for a segment
+        // over two input vectors, a starved launch for one over eleven)
+        if (!(rolled && last.zone == 1) && !last.no_red && !last.ssa.empty() && k_root < last.out.size() && group[0].order[(size_t)root_pos] == group[0].roots[0] &&
+            group[0].n * (int64_t)last.n_in <= (int64_t(1) << 21)) {
+            if (!last.prog_red) {
+                try { last.prog_red = compile(last.ssa, last.n_in, last.out_ids, { last.out_ids[k_root] }, nullptr, false); }
+                catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; last.no_red = true; }
+                if (last.prog_red && last.prog_red->proto.variant != 1u) { delete last.prog_red; last.prog_red = nullptr; last.no_red = true; }
+            }
+            prog_red = last.prog_red;
+        }
+    }
     bool rolled_done = false;
-    for (const BigPlan::Seg& seg : plan.segs) {
+    for (size_t si = 0; si < plan.segs.size(); ++si) {
+        const BigPlan::Seg& seg = plan.segs[si];
         if (rolled && seg.zone == 1) {              // the loop's stretch: one launch of the rolled kernel instead of its segments
             if (!rolled_done) for (size_t off = 0; off < group.size(); off += rolled_batch) run_rolled(plan.rolled, group, off, std::min(rolled_batch, group.size() - off));
             rolled_done = true;
-        } else
+        } else if (prog_red && si + 1 == plan.segs.size())
+            run_planned_segment(seg, group, 0, 1, rr, prog_red);
+        else
             for (size_t off = 0; off < group.size(); off += max_batch) run_planned_segment(seg, group, off, std::min(max_batch, group.size() - off));
         release_temps(seg.free_after);
     }
 }
 
-void Engine::run_big_group(std::vector<BigDag>& group) {
+void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
     HostTimer timer(HostProfile::RUN_BIG);
     BigDag& g0 = group[0];
     const size_t n_ops = g0.order.size();
@@ -1654,7 +1726,7 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
     auto planned = plan_cache_.find(g0.hash);
     if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
     const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
-    if (planned != plan_cache_.end()) { run_plan(planned->second, group); return; }
+    if (planned != plan_cache_.end()) { run_plan(planned->second, group, rr); return; }
     // Members without nodes (copies that exist as a description) cannot take the general path below, which works on nodes: they
     // follow through the plan it writes down.
     std::vector<BigDag> described;
@@ -1721,6 +1793,7 @@ void Engine::run_big_group(std::vector<BigDag>& group) {
             for (Node* o : dags[0].outs) seg.out.push_back(index_of.at(o));
             for (size_t i = s; i < e; ++i) if (op_info(group[0].order[i]->opcode).scalar) seg.scal.push_back((int32_t)i);
             seg.zone = s < zone_begin ? 0 : (s < zone_end ? 1 : 2);
+            if (e == n_ops) { seg.ssa = dags[0].ops; seg.out_ids = dags[0].out_ids; seg.n_in = (int)dags[0].leaves.size(); }
             plan.segs.push_back(std::move(seg));
         }
         for (size_t off = 0; off < dags.size(); off += max_batch) {
@@ -1955,6 +2028,7 @@ Program* Engine::reduce_program() {
 
 void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out) {
     require_init();
+    end_step_group();
     Node* nd = node(h);
     if (!nd->buf) {
         // `chain.getAverage()`: the expectation of a pending expression that fits one launch is taken in THAT launch (the kernel's
@@ -1965,6 +2039,15 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         expand_replicas_below({ nd });
         std::vector<Dag> one(1);
         if (fusion && build_dag({ nd }, one[0]) && nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) && run_dags(one, &shift, host_out, dev_out)) return;
+        // … and of one that takes several launches, in the LAST of them (when its plan exists: from the second time a shape is seen)
+        if (fusion && !nd->buf && nd->n > 0) {
+            std::vector<BigDag> big(1);
+            if (build_big({ nd }, big[0])) {
+                ReduceRequest rr{ shift, host_out, dev_out, false };
+                run_big_group(big, &rr);
+                if (rr.done) return;
+            }
+        }
         if (!nd->buf) materialize({ nd });
     }
     Program* prog = reduce_program();
@@ -1978,6 +2061,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
 void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out) {
     HostTimer timer(HostProfile::REDUCE);
     require_init();
+    end_step_group();
     if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
     std::vector<Node*> nds((size_t)count);
     for (int i = 0; i < count; ++i) nds[(size_t)i] = node(hs[i]);
@@ -2126,12 +2210,14 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
         throw;
     }
     pool_.release(sq_dev, sq_cap);
+    const uint32_t bm_id = next_bm_id_++;
     for (int64_t s = 0; s < n_streams; ++s) {
         Buffer* v = new Buffer();
         v->ptr = slab->ptr + s * stride; v->cap = 0; v->refs = 1; v->parent = slab;
         slab->refs++;
         Node* nd = new_node(n_paths);
         nd->buf = v;
+        nd->bm_id = bm_id; nd->bm_step = (int32_t)(s / n_factors); nd->bm_steps = n_steps;
         out[s] = nd->id;
     }
 }
@@ -2144,7 +2230,7 @@ void Engine::pool_purge() {
     require_init();
     hip_check(hipStreamSynchronize(stream_), "sync");
     pool_.purge();
-    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) if (--seg.prog->refs == 0) delete seg.prog;
+    for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) { if (--seg.prog->refs == 0) delete seg.prog; delete seg.prog_red; }
     plan_cache_.clear();
     for (auto it = program_cache_.begin(); it != program_cache_.end();) { if (--it->second->refs == 0) delete it->second; it = program_cache_.erase(it); }
 }

@@ -85,6 +85,9 @@ struct Node {
     uint32_t rep_copy = 0;
     uint32_t leaf_rep_id = 0;   // a substituted operand (leaf_from[i]) of that live group …
     int32_t  leaf_rep_index = -1;   // … i
+    // a Brownian increment (fmhip_bm_generate): which generation it belongs to, its time index, the number of time steps
+    uint32_t bm_id = 0;
+    int32_t  bm_step = -1, bm_steps = 0;
 };
 
 // Copies of a pending graph that exist as a DESCRIPTION until the graph runs (fmhip_graph_clone).  A copy differs from the
@@ -112,6 +115,8 @@ struct ReplicaGroup {
 
 // ---------------------------------------------------------------- compiled programs
 
+struct SsaOp { int opcode; int a, b, c; double scalar; };
+
 struct Program {
     int n_in = 0, n_out = 0, n_red = 0, n_ops = 0, n_scal = 1;
     DevProgramArgs proto{};                 // ops / out_reg / red_reg / counts filled in
@@ -126,7 +131,6 @@ struct Program {
     std::shared_ptr<JitSlot> jit;
 };
 
-struct SsaOp { int opcode; int a, b, c; double scalar; };
 
 class Engine {
 public:
@@ -157,6 +161,13 @@ public:
     int fusion_hold = 0;                    // fmhip_fusion_hold: 1 = no execution on the engine's own accord; 2 = the same, but everything pending is
                                             // executed once more than FUSION_SOFT_CAP operations wait (a hold somebody may forget to lift)
     int math_mode = FMHIP_MATH_EXACT;
+    // Time-step grouping (fmhip_set_step_grouping): a discretisation scheme reads the Brownian increments of time index i exactly
+    // while it computes step i — the one place where a caller that knows nothing about this engine (finmath-lib's Euler scheme)
+    // shows where a time step ends.  With group_steps = S > 0 the methods recorded between S such boundaries stay pending (like
+    // a soft hold) and are executed together: the engine sees S whole time steps at once, schedules them component by component
+    // and runs the periodic stretch as one rolled-loop launch, instead of cutting the stream every ≈ 40 methods.
+    int group_steps = 2;
+    void end_step_group() { group_hold_ = false; group_steps_pending_ = 0; }      // a value is read, or the caller flushes: whatever was being grouped has run
     void flush_all();
     void materialize(const std::vector<Node*>& targets);
     void graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
@@ -224,6 +235,7 @@ private:
     void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
     uint64_t ring_generation_ = 1;          // bumped on every wrap: device copies of older tables may be overwritten
     uint32_t* counters_dev_ = nullptr;      // arrival counters of the fused final combine (65536 rows, zero between launches)
+    uint64_t poll_sequence_ = 0;            // value of the completion flag of the last polled reduction (see launch)
     void*  dump_dev_ = nullptr;             // FM_DUMP_BYTES nobody reads: target of the stores of lanes past the end of a vector (rolled kernels)
     void*  ensure_stage(size_t bytes);
     size_t ring_reserve(size_t bytes);
@@ -255,7 +267,9 @@ private:
     // member, which made two-step groups of the LMM simulation host-bound).
     struct BigPlan {
         struct Seg { Program* prog = nullptr; std::vector<int32_t> in, out, scal; int zone = 0;       // zone: 0 before a rolled loop, 1 inside (its fallback), 2 behind
-                     std::vector<int32_t> free_after; };                                              // values no later segment reads (members without nodes release them here)
+                     std::vector<int32_t> free_after;                                                 // values no later segment reads (members without nodes release them here)
+                     // the LAST segment only: what it takes to compile the variant that also reduces the component's root (reduce())
+                     std::vector<SsaOp> ssa; std::vector<int> out_ids; int n_in = 0; Program* prog_red = nullptr; bool no_red = false; };
         std::vector<Seg> segs;
         std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
         // A periodic stretch of the scheduled order — the same few operations over one component after another, each iteration
@@ -276,9 +290,11 @@ private:
     };
     bool build_big(const std::vector<Node*>& roots, BigDag& big);
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
-    void run_big_group(std::vector<BigDag>& group);
-    void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count);
-    void run_plan(BigPlan& plan, std::vector<BigDag>& group);
+    // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
+    struct ReduceRequest { double shift; fmhip_moments* host_out; void* dev_out; bool done; };
+    void run_big_group(std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
+    void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, Program* prog_red = nullptr);
+    void run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
     void commit_described(BigDag& big, size_t pos, Buffer* b);
     bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
@@ -286,6 +302,13 @@ private:
     // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)
     std::unordered_map<uint32_t, ReplicaGroup*> replicas_;
     uint32_t next_replica_id_ = 1;
+    // time-step grouping: the generation and time index of the increment seen last, steps recorded since the last flush, whether
+    // the engine itself is holding pending work back for a group
+    uint32_t next_bm_id_ = 1, group_bm_id_ = 0;
+    int32_t  group_last_step_ = -1;
+    int      group_steps_pending_ = 0;
+    bool     group_hold_ = false;
+    void step_boundary(const Node* increment);
     ReplicaGroup* replica_of(const Node* nd) const { if (!nd->rep_id) return nullptr; auto it = replicas_.find(nd->rep_id); return it == replicas_.end() ? nullptr : it->second; }
     void expand_replicas(ReplicaGroup* g);                       // the description becomes ordinary pending nodes (fallback; also frees the group)
     void expand_replicas_below(const std::vector<Node*>& targets);   // every group the pending graph below `targets` touches

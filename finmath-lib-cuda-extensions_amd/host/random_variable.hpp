@@ -492,16 +492,11 @@ public:
         : td_(std::move(td)), factors_(numberOfFactors), paths_(numberOfPaths), seed_(seed), offset_(pathOffset) {}
     RV getBrownianIncrement(int timeIndex, int factor) const override {
         if (inc_.empty()) generate();
-        if (groupSteps_ > 0 && timeIndex != lastTimeIndex_) stepBoundary(timeIndex);
         return inc_.at((size_t)timeIndex * factors_ + factor);
     }
-    // Time-step grouping on the caller's behalf.  A discretisation scheme asks for the increments of time index i exactly when
-    // it starts (or finishes) step i — the one place where code the caller did NOT write for this engine (finmath-lib's Euler
-    // scheme) tells it where a time step ends.  With groupSteps = S > 0 the methods recorded between S such boundaries are
-    // kept pending (soft hold) and executed together: the engine sees S whole time steps at once, schedules them component by
-    // component and runs the periodic stretch as one rolled-loop launch, instead of cutting the stream every ≈ 40 methods.
-    // A request for time index 0 starts a new simulation.  Default: FMHIP_BM_GROUP_STEPS (0 = off).
-    void setGroupSteps(int steps) { groupSteps_ = steps; }
+    // Time-step grouping on the caller's behalf is the engine's business since round 3 (fmhip_set_step_grouping: it watches for the
+    // first use of an increment with a new time index itself, whatever class hands the increments out); process-wide.
+    static void setGroupSteps(int steps) { check(fmhip_set_step_grouping(steps, nullptr)); }
     const TimeDiscretization& getTimeDiscretization() const override { return td_; }
     int getNumberOfFactors() const override { return factors_; }
     int64_t getNumberOfPaths() const override { return paths_; }
@@ -525,19 +520,10 @@ private:
             for (int f = 0; f < factors_; ++f)
                 inc_.push_back(RandomVariableHip::of(td_.getTime(i + 1), DeviceVector(h[(size_t)i * factors_ + f]), paths_));
     }
-    void stepBoundary(int timeIndex) const {
-        lastTimeIndex_ = timeIndex;
-        if (timeIndex == 0) stepsSinceFlush_ = 0;
-        if (stepsSinceFlush_ == 0) check(fmhip_fusion_hold(2, nullptr));
-        if (++stepsSinceFlush_ > groupSteps_) { check(fmhip_flush()); stepsSinceFlush_ = 1; }
-        if (timeIndex == td_.getNumberOfTimeSteps() - 1) { stepsSinceFlush_ = 0; lastTimeIndex_ = -1; check(fmhip_fusion_hold(0, nullptr)); }   // last step: what follows is not ours to group
-    }
     TimeDiscretization td_;
     int factors_;
     int64_t paths_, seed_, offset_;
     mutable std::vector<RV> inc_;
-    int groupSteps_ = [] { const char* e = std::getenv("FMHIP_BM_GROUP_STEPS"); return e ? std::atoi(e) : 0; }();
-    mutable int lastTimeIndex_ = -1, stepsSinceFlush_ = 0;
 };
 
 // ------------------------------------------------------------------ BrownianMotionFromMersenneRandomNumbers

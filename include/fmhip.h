@@ -193,6 +193,16 @@ int fmhip_flush(void);
  * (BrownianMotionHip groups the time steps of an Euler scheme this way).  Returns the previous setting (0, 1 or 2)
  * through *previous (may be NULL). */
 int fmhip_fusion_hold(int hold, int* previous);
+/* Time-step grouping on behalf of callers that give no hints (finmath-lib's Euler scheme through the RandomVariable interface).
+ * A discretisation scheme reads the Brownian increments of time index i exactly while it computes step i; the engine watches for
+ * the first use of an increment of fmhip_bm_generate with a new time index and keeps the methods recorded between `steps` such
+ * boundaries pending (as under a soft hold), then executes them together — whole time steps, scheduled component by component,
+ * their periodic stretch as one rolled-loop launch — instead of cutting the stream every ≈ 40 methods.  The last time index of a
+ * generation ends the grouping.  Only while the fusion front-end is on and the caller holds nothing itself (fmhip_fusion_hold).
+ * steps = 0 switches it off; default 2 (environment: FMHIP_GROUP_STEPS).  Results never depend on it.
+ * Replaces what BrownianMotionCudaWithRandomVariableCuda's callers get from the reference: nothing (one launch per method).
+ * Returns the previous setting through *previous (may be NULL). */
+int fmhip_set_step_grouping(int steps, int* previous);
 /* Replicate PENDING expressions: a caller that is about to record the same chain of methods again with other vectors and other
  * scalar operands — the next scenario, the next bumped parameter set of a Jacobian — records it ONCE and asks for copies.
  * The graph = every pending (not yet executed) operation below `roots`.  Copy j reads leaf_to[j*n_map + i] wherever the

@@ -33,18 +33,18 @@ public class BrownianMotionHip implements BrownianMotion, Serializable {
 	private final Object brownianIncrementsLazyInitLock = new Object();
 
 	/*
-	 * Time-step grouping on the caller's behalf (mirror of host/random_variable.hpp: BrownianMotionHip::stepBoundary).
-	 * finmath-lib's EulerSchemeFromProcessModel asks for the increments of time index i exactly once per time step: the one
-	 * place where code that was not written for this engine tells it where a step ends.  With groupSteps = S > 0 the
-	 * methods recorded between S such boundaries stay pending (soft hold, Native.fusionHold(2)) and are executed together;
-	 * the engine then sees S whole time steps at once and runs their periodic part as one rolled-loop launch instead of
-	 * cutting the stream every ~40 methods.  Measured with the native driver's hint-free mode (lmm_hip --finmath-like,
-	 * 1 M paths): 26.5 -> 12.8 ms per objective evaluation at S = 2.  System property net.finmath.hip.groupTimeSteps
-	 * (default 2; 0 = off).
+	 * Time-step grouping on the caller's behalf is the ENGINE's business (fmhip_set_step_grouping, include/fmhip.h): finmath-lib's
+	 * EulerSchemeFromProcessModel reads the increments of time index i exactly while it computes step i, the engine watches for the
+	 * first use of an increment with a new time index and executes the methods recorded between S such boundaries together (whole
+	 * time steps, their periodic part as one rolled-loop launch) instead of cutting the stream every ~40 methods.  The system
+	 * property net.finmath.hip.groupTimeSteps overrides the engine's default (2; 0 = off).
 	 */
-	private int groupSteps = Integer.getInteger("net.finmath.hip.groupTimeSteps", 2);
-	private transient int lastTimeIndex = -1;
-	private transient int stepsSinceFlush = 0;
+	static {
+		final Integer steps = Integer.getInteger("net.finmath.hip.groupTimeSteps");
+		if(steps != null) {
+			Native.check(Native.setStepGrouping(steps, null));
+		}
+	}
 
 	/**
 	 * @param timeDiscretization the time grid; increment i covers [t_i, t_{i+1}]
@@ -81,34 +81,13 @@ public class BrownianMotionHip implements BrownianMotion, Serializable {
 			if(brownianIncrements == null) {
 				doGenerateBrownianMotion();
 			}
-			if(groupSteps > 0 && timeIndex != lastTimeIndex) {
-				stepBoundary(timeIndex);
-			}
 		}
 		return brownianIncrements[timeIndex][factor];
 	}
 
-	public void setGroupSteps(final int steps) {
-		groupSteps = steps;
-	}
-
-	private void stepBoundary(final int timeIndex) {
-		lastTimeIndex = timeIndex;
-		if(timeIndex == 0) {
-			stepsSinceFlush = 0;		// a new simulation
-		}
-		if(stepsSinceFlush == 0) {
-			Native.check(Native.fusionHold(2, null));		// soft hold: the engine lifts it by itself if nobody flushes
-		}
-		if(++stepsSinceFlush > groupSteps) {
-			Native.check(Native.flush());
-			stepsSinceFlush = 1;
-		}
-		if(timeIndex == timeDiscretization.getNumberOfTimeSteps() - 1) {
-			stepsSinceFlush = 0;
-			lastTimeIndex = -1;
-			Native.check(Native.fusionHold(0, null));		// last step: what follows is not ours to group
-		}
+	/** Number of time steps the engine executes together on the caller's behalf (0 = off); process-wide. */
+	public static void setGroupSteps(final int steps) {
+		Native.check(Native.setStepGrouping(steps, null));
 	}
 
 	private void doGenerateBrownianMotion() {

@@ -56,6 +56,7 @@ final class Native {
 	static native int setFusion(int enabled, int[] previous);
 	static native int flush();
 	static native int fusionHold(int hold, int[] previous);
+	static native int setStepGrouping(int steps, int[] previous);
 	static native int graphClone(long[] roots, int nCopies, long[] leafFrom, long[] leafTo, double[] scalarsOrNull, int nScalars, long[] out);
 	static native int graphScalars(long[] roots, double[] scalarsOutOrNull, int[] count);
 	static native int setMathMode(int mode, int[] previous);

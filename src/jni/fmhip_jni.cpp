@@ -120,6 +120,7 @@ FMJ(jlong, callV3s0)(JNIEnv*, jclass, jint opcode, jlong a, jlong b, jlong c) { 
 // ---------------------------------------------------------------- lazy fusion front-end
 FMJ(jint, setFusion)(JNIEnv* env, jclass, jint enabled, jintArray previous) { int prev = 0; const int st = fmhip_set_fusion(enabled, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 FMJ(jint, flush)(JNIEnv*, jclass) { return fmhip_flush(); }
+FMJ(jint, setStepGrouping)(JNIEnv* env, jclass, jint steps, jintArray previous) { int prev = 0; const int st = fmhip_set_step_grouping(steps, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 FMJ(jint, fusionHold)(JNIEnv* env, jclass, jint hold, jintArray previous) { int prev = 0; const int st = fmhip_fusion_hold(hold, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 FMJ(jint, graphClone)(JNIEnv* env, jclass, jlongArray roots, jint nCopies, jlongArray leafFrom, jlongArray leafTo, jdoubleArray scalars, jint nScalars, jlongArray out) {
     Pin<jlong> pr(env, roots, JNI_ABORT), pf(env, leafFrom, JNI_ABORT), pt(env, leafTo, JNI_ABORT), po(env, out); Pin<jdouble> ps(env, scalars, JNI_ABORT);

@@ -142,8 +142,8 @@ def test_full_size_calibration_meets_the_reference_acceptance():
 def test_caller_without_hints_gets_the_same_numbers():
     """lmm_hip --finmath-like: the driver as code that knows nothing about the engine (no hold / flush / replication / lock-step
     batches, every state kept, one getAverage per product — finmath-lib's Euler scheme and optimizer through the Java interface).
-    Same model volatilities as the driver with all its hints; with BrownianMotionHip grouping the time steps on the caller's
-    behalf (FMHIP_BM_GROUP_STEPS) the same again, in fewer launches."""
+    Same model volatilities as the driver with all its hints — with the engine grouping the time steps on the caller's behalf
+    (fmhip_set_step_grouping, default 2; FMHIP_GROUP_STEPS=0 switches it off) and without, the grouped run in fewer launches."""
     ensure_built()
     def evaluate(*extra, env=None):
         out = subprocess.run([LMM_HIP, "--paths", "20000", "--mode", "evaluate", "--evaluations", "2", *map(str, extra)], capture_output=True, text=True, timeout=600,
@@ -151,30 +151,35 @@ def test_caller_without_hints_gets_the_same_numbers():
         assert out.returncode == 0, out.stderr
         return json.loads(out.stdout.strip().splitlines()[-1])
     hinted = evaluate()
-    plain = evaluate("--finmath-like")
-    grouped = evaluate("--finmath-like", env={"FMHIP_BM_GROUP_STEPS": "2"})
+    plain = evaluate("--finmath-like", env={"FMHIP_GROUP_STEPS": "0"})
+    grouped = evaluate("--finmath-like")
     assert plain["model_volatility"] == hinted["model_volatility"] == grouped["model_volatility"]
     assert grouped["kernel_launches"] < 0.6 * plain["kernel_launches"]
     assert hinted["kernel_launches"] < 0.5 * grouped["kernel_launches"]
 
 
 def test_brownian_motion_groups_time_steps_for_a_plain_scheme(gpu):
-    """BrownianMotionHip.setGroupSteps: an Euler scheme written against the interfaces only (montecarlo.py) runs in groups of time
-    steps — same price bit for bit, fewer launches."""
+    """Time-step grouping by the engine (fmhip_set_step_grouping; BrownianMotionHip.setGroupSteps forwards to it): an Euler scheme
+    written against the interfaces only (montecarlo.py) runs in groups of time steps — same price bit for bit, fewer launches."""
     import importlib
     mc = importlib.import_module("finmath-lib-cuda-extensions_amd.montecarlo")
     bm = gpu.BrownianMotionHip(gpu.TimeDiscretization(0.0, 100, 0.02), 2, 100_000, 31415)
     bm.getBrownianIncrement(0, 0)
     prev = gpu.set_fusion(True)
     try:
+        default_steps = gpu.set_step_grouping(0)
+        assert default_steps == 2
         before = gpu.pool_stats().n_kernel_launches
         plain, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.3, -0.5, 2.0, 1.05)
         mid = gpu.pool_stats().n_kernel_launches
         bm.setGroupSteps(10)
         grouped, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.3, -0.5, 2.0, 1.05)
         after = gpu.pool_stats().n_kernel_launches
-        bm.setGroupSteps(0)
+        assert gpu.set_step_grouping(default_steps) == 10
+        by_default, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.3, -0.5, 2.0, 1.05)
+        assert by_default == plain and gpu.pool_stats().n_kernel_launches - after < mid - before
     finally:
+        gpu.set_step_grouping(2)
         gpu.fusion_hold(False)
         gpu.set_fusion(prev)
     assert grouped == plain
