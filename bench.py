@@ -219,6 +219,21 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
     if rank != 0:
         return None
     kernel_s = rp["kernel_ms_total"] / 1e3
+    # Where the host's own time goes (the engine's FMHIP_HOST_PROFILE table of a third run, N = 1 only): the slots that do not contain
+    # each other, largest first.  host_idle_s = wall time of the profiled run the device spent without a kernel.
+    host_top = None
+    if world == 1:
+        try:
+            hp = subprocess.run(base, capture_output=True, text=True, env=dict(os.environ, FMHIP_HOST_PROFILE="1"), timeout=240)
+            slots = {}
+            for ln in hp.stderr.splitlines():
+                parts = ln.split()
+                if "calls" in parts and parts[-1] == "us/call":
+                    slots[" ".join(parts[:parts.index("calls") - 1])] = float(parts[parts.index("calls") + 1])
+            leaf = {k: v for k, v in slots.items() if not k.endswith("(total)") or k.startswith("graph_clone")}
+            host_top = [{"what": k, "seconds": v} for k, v in sorted(leaf.items(), key=lambda kv: -kv[1])[:3]]
+        except Exception as e:
+            host_top = [{"error": str(e)[-200:]}]
     lmm = {"metric": "LMM calib wall-time, 1M paths" if world == 1 else f"LMM calib wall-time, {world}x1M paths (path-sharded)",
            "value": r["seconds"], "unit": "s", "higher_is_better": False, "n_gpus": world, "paths_per_gpu": paths, "paths": paths * world,
            "lm_iterations": r["iterations"], "objective_evaluations": r["evaluations"],
@@ -238,6 +253,7 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
                         "launches": rp["profiled_launches"], "specialised_launches": rp["specialised_launches"],
                         "algorithmic_bytes": rp["algorithmic_bytes"], "summed_kernel_s": kernel_s,
                         "device_busy_fraction_of_wall": kernel_s / rp["seconds"],
+                        "host_idle_s": rp["seconds"] - kernel_s, "host_time_top3": host_top,
                         "timing": "one HIP event pair per launch on the runtime stream, summed"}}
     if world == 1:
         env = dict(os.environ, FMHIP_JIT="sync")
@@ -268,6 +284,16 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
                                         "rms_error": 0.00480, "source": "README.md:254-255"},
                 "note": "model and optimiser restated from finmath-lib's documentation (the jar is not vendored): same inputs, same acceptance "
                         "test, not the same optimiser path; other hardware - context only, vs_baseline stays null"}
+        # What finmath-lib's own Euler scheme and optimizer would get through the interface: RandomVariable methods and one getAverage() per
+        # product, no hold / flush / replication / lock-step batches, every state kept (lmm_hip --finmath-like).
+        try:
+            fl, _ = run(base + ["--finmath-like"])
+            lmm["finmath_like_seconds"] = fl["seconds"]
+            lmm["finmath_like"] = {"seconds": fl["seconds"], "kernel_launches": fl["kernel_launches"], "mean_deviation": fl["mean_deviation"],
+                                   "identical_to_the_native_driver": fl["mean_deviation"] == r["mean_deviation"] and fl["rms_deviation"] == r["rms_deviation"],
+                                   "what": "the same calibration through methods + getAverage() only; the engine groups time steps itself (fmhip_set_step_grouping)"}
+        except Exception as e:
+            lmm["finmath_like"] = {"error": str(e)[-500:]}
         if cpu_base:
             cj, _ = run([LMM_CPU, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"])
             per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]
@@ -275,6 +301,49 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
                                    "sample": f"1 objective evaluation of the same model at {paths} paths on the CPU twin = {per_eval:.2f} s, "
                                              f"scaled by the {r['evaluations']} evaluations the calibration needed"}
     return lmm
+
+
+def brownian_block(fm, launches=6):
+    """BASELINE.json configs[2]: BrownianMotionHip 1 M paths x 200 steps x 5 factors (seed 31415 + k) = 4.0 GB of N(0, dt) increments per
+    generation, one launch of fm_bm_kernel into a slab the pool hands back from the previous generation (the first one allocates it
+    and is not counted); device time of that kernel alone from HIP events on the runtime stream (fmhip_profile_*).  Replaces
+    BrownianMotionCudaWithRandomVariableCuda.java:168-178 (one curandGenerateNormal per step and factor).  Then the Heston Monte-Carlo
+    of config 3 with vol-of-vol 0 on the last generation: must reproduce the Black-Scholes value 0.18994 within 0.005
+    (MonteCarloBlackScholesModelTest.java:156)."""
+    mc = importlib.import_module("finmath-lib-cuda-extensions_amd.montecarlo")
+    n, steps, factors, dt = N_PATHS, 200, 5, 0.01
+    td = fm.TimeDiscretization(0.0, steps, dt)
+    bm = fm.BrownianMotionHip(td, factors, n, 31415)
+    bm.getBrownianIncrement(0, 0)                      # allocates the 4 GB slab (first touch): not timed
+    del bm
+    us = []
+    fm.profile_enable(True)
+    for k in range(launches):
+        bm = fm.BrownianMotionHip(td, factors, n, 31416 + k)
+        bm.getBrownianIncrement(0, 0)
+        ms, count = fm.profile_read()
+        us.append(ms * 1e3 / max(1, count))
+        if k + 1 < launches:
+            del bm
+    fm.profile_enable(False)
+    nbytes = 4.0 * n * steps * factors
+    avg = sum(us) / len(us)
+    prev = fm.set_fusion(True)
+    t0 = time.perf_counter()
+    price, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.0, -0.5, 2.0, 1.05)
+    heston_s = time.perf_counter() - t0
+    fm.set_fusion(prev)
+    analytic = mc.black_scholes_call_analytic(1.0, 0.05, 0.30, 2.0, 1.05)
+    del bm
+    fm.purge()
+    return {"workload": "BrownianMotionHip 1M paths x 200 steps x 5 factors (BASELINE.json configs[2])", "kernel": "fm::fm_bm_kernel (Philox4x32-10 + LDS-table inverse normal CDF)",
+            "bytes_written_per_launch": nbytes, "launches": launches, "avg_kernel_us": avg, "min_kernel_us": min(us), "max_kernel_us": max(us),
+            "roofline": {"bound": "hbm", "achieved": nbytes / (avg * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "frac_best_launch": nbytes / (min(us) * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "timing": "one HIP event pair per launch on the runtime stream (fmhip_profile_read)"},
+            "normals_per_s": n * steps * factors / (avg * 1e-6),
+            "heston_xi0": {"price": price, "black_scholes_analytic": analytic, "abs_error": abs(price - analytic), "wall_s": heston_s,
+                           "acceptance": "abs error < 0.005 (MonteCarloBlackScholesModelTest.java:156)", "accepted": abs(price - analytic) < 0.005}}
 
 
 def rendezvous_nonce(world, rank):
@@ -539,6 +608,15 @@ def main():
         except Exception:
             continue
 
+    brownian = None
+    if world == 1 and args.workload == "both":
+        del rows, out_rows                      # the stream half's 1.5 GB of inputs are no longer needed
+        rows = out_rows = None
+        try:
+            brownian = brownian_block(fm)
+        except Exception as e:                  # never in the way of the headline
+            brownian = {"error": str(e)[-500:]}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = N_OPS * n * B * world / (elapsed / args.steps)
@@ -590,11 +668,13 @@ def main():
                                       "average_rel_diff": abs(gpu_avg - tw["average"]) / abs(tw["average"]),
                                       "min_max_identical": m0[2] == tw["min"] and m0[3] == tw["max"],
                                       "ok": abs(gpu_avg - tw["average"]) <= 1e-12 * abs(tw["average"]) and m0[2] == tw["min"] and m0[3] == tw["max"]}
+        if brownian is not None:
+            line["brownian"] = brownian
         if lmm is not None:
             line["lmm"] = lmm
         print(json.dumps(line), file=json_out, flush=True)
 
-    del rows, out_rows
+    rows = out_rows = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,6 +108,17 @@ __device__ __forceinline__ void red_finish(const double shift, const double acc_
     if (shift == 0.0) nan_mask |= __ballot(acc_sq != acc_sq);
 }
 
+// FM_HANDOFF_RELEASE: 1 = the arrival counter's add is an agent-scope release (see block_combine); 0 = relaxed behind sc1 stores
+// and an explicit drain.  Measured on the bench launch (profiles/round03_handoff_ab.txt) before choosing the default.
+#ifndef FM_HANDOFF_RELEASE
+#define FM_HANDOFF_RELEASE 0
+#endif
+#if FM_HANDOFF_RELEASE
+#define FM_HANDOFF_ADD_ORDER __ATOMIC_RELEASE
+#else
+#define FM_HANDOFF_ADD_ORDER __ATOMIC_RELAXED
+#endif
+
 // Device-coherent accesses for the hand-off between workgroups (possibly on different XCDs, whose L2s are not coherent
 // with each other): `sc1` stores / loads go through to memory, no cache-wide write-back or invalidate is needed.
 __device__ __forceinline__ void store_coherent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -198,14 +209,18 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // Ordering of this hand-off (MI355X_MICROARCH.md, "Valid forms", first row of the sc1 table): every partial is an sc1
-        // store drained by the s_waitcnt above before the counter moves; the last arriver learns that it is last from the value
-        // its own add RETURNED and loads the partials (all sc1 loads, wave_sum_partials) only after that.  The hardware keeps that
-        // order (the loads are issued behind a branch on the returned value); the signal fence keeps the COMPILER from moving the
-        // relaxed loads or stores across the relaxed add, whichever compiler (hipcc today, hiprtc at run time) builds this header.
+        const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+        // Ordering of this hand-off.  Producer: every partial is an sc1 (write-through) store, drained by the s_waitcnt above before the
+        // counter moves (MI355X_MICROARCH.md, "Valid forms", sc1 table; FM_HANDOFF_RELEASE = 1 makes the add an agent-scope RELEASE on
+        // top: buffer_wbl2 + wait in front of it).  Consumer: the last arriver learns that it is last from the value its own add
+        // RETURNED and only then loads the partials — all sc1 loads (wave_sum_partials), which do not hit in the L1 or in a foreign
+        // XCD's L2 — and, since round 3, behind an agent-scope ACQUIRE fence (buffer_inv sc1: one wave per row and launch, free), so
+        // the hand-off no longer rests on the measured envelope of the sc1-only form alone (that table is for one workgroup per CU;
+        // these kernels run four or five).  The signal fences keep the COMPILER from moving the relaxed accesses across the add,
+        // whichever compiler (hipcc today, hiprtc at run time) builds this header.
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (arrived == members - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __hip_atomic_store(counter + (size_t)g * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             group_last = 1u;
         }
@@ -239,9 +254,9 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
     }
     if (lane == 63u) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t groups_done = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (groups_done == G - 1u) { __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); row_last = 1u; }
+        if (groups_done == G - 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); row_last = 1u; }
     }
     row_last = __builtin_amdgcn_readlane(row_last, 63);
     if (row_last == 0u) return;

@@ -2200,7 +2200,12 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
                 a.stride_floats = stride; a.n_paths = n_paths; a.path_offset = path_offset;
                 a.key0 = (uint32_t)(uint64_t)seed; a.key1 = (uint32_t)((uint64_t)seed >> 32);
                 a.n_factors = (uint32_t)n_factors; a.stream0 = (uint32_t)s0;
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;            // fmhip_profile_enable: the generator's launches are bracketed like program launches
+                if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
                 hip_check(launch_bm(a, (uint32_t)ns, stream_), "launch fm_bm_kernel");
+                if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                                  profile_tags_.push_back({ 0, 0, (int)ns, 0, 1, 3, n_paths }); }
+                algorithmic_bytes_ += 4 * n_paths * ns;
                 n_launches_++;
             }
         }
@@ -2272,7 +2277,7 @@ void Engine::profile_read(double* ms_total, int64_t* n) {
         if (dump && i < profile_tags_.size()) {
             const ProfileTag& t = profile_tags_[i];
             char key[128];
-            std::snprintf(key, sizeof key, "ops %3d in %2d out %d red %d rows %4d n %9lld %s", t.n_ops, t.n_in, t.n_out, t.n_red, t.batch, (long long)t.n, t.tier ? "specialised" : "interpreter");
+            std::snprintf(key, sizeof key, "ops %3d in %2d out %d red %d rows %4d n %9lld %s", t.n_ops, t.n_in, t.n_out, t.n_red, t.batch, (long long)t.n, t.tier == 3 ? "fm_bm_kernel" : t.tier ? "specialised" : "interpreter");
             Agg& a = agg[key];
             a.launches++; a.ms += ms; a.bytes += 4.0 * (double)t.n * (t.n_in + t.n_out) * t.batch;
         }

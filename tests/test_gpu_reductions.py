@@ -95,3 +95,30 @@ def test_large_vector_closed_form(gpu, n):
     for _ in range(2):
         m = v.moments()
         assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == -2.0 and m.max == 6.0
+
+
+def test_hand_off_with_warm_caches_and_many_workgroups_per_cu(gpu, oracle):
+    """The cross-workgroup hand-off of the partials (fm_kernel_parts.hpp: block_combine) where a stale cache line would show: the SAME
+    output buffers, partial slots and arrival counters are reused launch after launch with DIFFERENT data (A, B, A, C, …), many rows
+    per launch and several workgroups per CU, a light program (the workgroups arrive in a burst), on both execution tiers.  Every
+    moment of every row of every launch against the oracle on that launch's data: a partial read from a previous launch's line
+    (the consumer's L1, or the L2 of another XCD) would be the other data set's sum."""
+    n, rows, sets = 300_007, 48, 3
+    data = [[oracle.f_from_double(oracle.java_random_doubles(9000 + 100 * s + r, n) * (s + 1.5) - 0.25 * r) for r in range(rows)] for s in range(sets)]
+    want = [[oracle.f_moments(oracle.f_v1s1("MULT_S", x, 1.25), 0.0) for x in row] for row in data]
+    for tier in (gpu.JIT_OFF, gpu.JIT_SYNC):
+        prev = gpu.set_jit(tier)
+        try:
+            p = gpu.Program(1)
+            w = p.op("MULT_S", 0, s=1.25)
+            p.output(w); p.reduce(w); p.compile()
+            dev = [[[gpu.DeviceVector.from_host(x)] for x in row] for row in data]
+            outs = [[gpu.DeviceVector.filled(n, 0.0)] for _ in range(rows)]
+            for s in (0, 1, 0, 2, 1, 1, 0, 2, 2, 0):
+                m = np.asarray(p.run_into(dev[s], outs)).reshape(rows, 4)
+                for r in range(rows):
+                    scale = float(np.abs(data[s][r].astype(np.float64)).sum()) * 1.25
+                    assert abs(m[r][0] - want[s][r][0]) <= 1e-13 * scale, (tier, s, r)
+                    assert m[r][2] == want[s][r][2] and m[r][3] == want[s][r][3], (tier, s, r)
+        finally:
+            gpu.set_jit(prev)

@@ -98,3 +98,73 @@ def test_kernel_pack_is_built_from_its_descriptions():
     out = subprocess.run([tool, "--check", os.path.join(pkg, "csrc", "kernel_pack.txt")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.startswith(f"{len(lines)} descriptions, 0 round-trip differences")
+
+
+def test_cross_workgroup_hand_off_in_the_machine_code(tmp_path):
+    """The hand-off of the reduction partials between workgroups (fm_kernel_parts.hpp: block_combine), checked where it counts — in the
+    gfx950 instructions hipcc emits for the same header both tiers are built from: every arrival-counter add is preceded by a full drain
+    of the vector-memory counter with no store in between (the sc1 partial stores are in memory before the workgroup is counted), the
+    partial stores and EVERY load behind the first add carry sc1 (no stale line from the L1 or a foreign XCD's L2), and an agent-scope
+    acquire (buffer_inv sc1) stands between each add and the loads of the workgroup that arrived last."""
+    import re
+    import shutil
+    import subprocess
+    import pytest
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this environment")
+    fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+    src = tmp_path / "reduce.hip"
+    src.write_text(build(fm).source())
+    out = tmp_path / "reduce.s"
+    csrc = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "csrc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-structurizecfg-skip-uniform-regions",
+                           "-I", csrc, "-S", "--cuda-device-only", "-o", str(out), str(src)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    for kernel in ("fm_jit_inline", "fm_jit_table"):
+        body = text[text.index(kernel + ":"):]
+        body = body[:body.index("s_endpgm")]
+        ins = [ln.strip() for ln in body.splitlines() if re.match(r"\s+[a-z]", ln)]
+        adds = [i for i, x in enumerate(ins) if x.startswith("global_atomic_add")]
+        assert len(adds) == 2, (kernel, len(adds))                      # the group counter and the second-level counter
+        for a in adds:
+            back = ins[:a][::-1]
+            drain = next(i for i, x in enumerate(back) if x.startswith("s_waitcnt") and "vmcnt(0)" in x)
+            assert not any(x.startswith(("global_store", "global_atomic", "flat_store")) for x in back[:drain]), (kernel, "a store between the drain and the counter")
+            assert sum(1 for x in back[drain:] if x.startswith("global_store_dwordx2") and "sc1" in x) >= 4, (kernel, "no sc1 partial stores in front of the drain")
+            ahead = ins[a + 1:]
+            inv = next(i for i, x in enumerate(ahead) if x.startswith("buffer_inv"))
+            first_load = next(i for i, x in enumerate(ahead) if x.startswith("global_load"))
+            assert "sc1" in ahead[inv] and inv < first_load, (kernel, "no acquire between the counter and the partial loads")
+        behind = [x for x in ins[adds[0] + 1:] if x.startswith(("global_load", "flat_load", "buffer_load"))]
+        assert behind and all("sc1" in x for x in behind), (kernel, [x for x in behind if "sc1" not in x][:3])
+
+
+def test_pack_code_objects_hand_off(tmp_path):
+    """The same check on the code objects that actually ship (lib/jit_pack, compiled with hiprtc at build time): disassembled with
+    llvm-objdump, every kernel that counts arrivals drains before the add and invalidates behind it."""
+    import glob
+    import re
+    import subprocess
+    import pytest
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    pack = sorted(glob.glob(os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "lib", "jit_pack", "*.co")))
+    if not os.path.exists(objdump) or not pack:
+        pytest.skip("no kernel pack / llvm-objdump in this environment")
+    checked = 0
+    for path in pack:
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"FMJITCO1"
+        co = tmp_path / "k.co"
+        co.write_bytes(raw[24:])                                         # magic, check word, size; then the ELF code object
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True).stdout
+        ins = [ln.split("//")[0].strip() for ln in dis.splitlines() if re.match(r"\s+[a-z_0-9]+ ", ln)]
+        adds = [i for i, x in enumerate(ins) if x.startswith("global_atomic_add")]
+        for a in adds:
+            back = ins[:a][::-1]
+            drain = next(i for i, x in enumerate(back) if x.startswith("s_waitcnt") and "vmcnt(0)" in x)
+            assert not any(x.startswith(("global_store", "flat_store")) for x in back[:drain]), path
+            ahead = ins[a + 1:a + 200]
+            assert any(x.startswith("buffer_inv") and "sc1" in x for x in ahead), path
+            checked += 1
+    assert checked >= 4                                                  # stream S, the stand-alone reduction …: two adds per kernel flavour
