@@ -181,7 +181,7 @@ LMM_HIP = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip"
 LMM_CPU = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
 
 
-def lmm_leg(args, world, rank, nonce, cpu_base=True):
+def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
     """BASELINE.json configs[3] / [4]: LMM ATM swaption calibration (LIBORMarketModelCalibrationATMTest.java:186-340 inputs,
     acceptance :466) at `--paths` paths per GPU in the native driver host/lmm.hpp over the C-ABI.  Runs in child processes
     (one lmm_hip per rank; LOCAL_RANK picks the device) and must be called BEFORE this process touches the GPU.
@@ -216,6 +216,17 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
 
     r, wall = run(base + dist_args("a"))
     rp, _ = run(base + ["--profile"] + dist_args("b"))
+    per_rank = None
+    if store is not None and world > 1:
+        # every rank ran the same optimiser on the same (all-gathered, rank-ordered) expectations: the calibrated parameter vectors
+        # must be equal BIT FOR BIT on all ranks — checked here, through the launcher's store, before anything is reported
+        store.set(f"fmhip_lmm_{nonce}_{rank}", json.dumps({"seconds": r["seconds"], "parameters": r["parameters"], "evaluations": r["evaluations"],
+                                                          "kernel_s": rp["kernel_ms_total"] / 1e3, "achieved_GBps": rp["achieved_GBps"]}))
+        if rank == 0:
+            per_rank = [json.loads(store.get(f"fmhip_lmm_{nonce}_{k}").decode()) for k in range(world)]
+            for k in range(1, world):
+                if per_rank[k]["parameters"] != per_rank[0]["parameters"] or per_rank[k]["evaluations"] != per_rank[0]["evaluations"]:
+                    raise RuntimeError(f"rank {k} calibrated other parameters than rank 0: the ranks did not see the same expectations")
     if rank != 0:
         return None
     kernel_s = rp["kernel_ms_total"] / 1e3
@@ -246,6 +257,9 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True):
            "kernel_launches": r["kernel_launches"], "path_ops_per_s": r["path_ops"] / r["seconds"],
            "process_wall_s": wall, "seconds_second_run_warm_code_object_cache_profiled": rp["seconds"],
            "specialised_kernels": r.get("specialised_kernels"), "specialisations_from_disk_cache": r.get("specialisations_from_disk_cache"),
+           "per_rank_seconds": None if per_rank is None else [x["seconds"] for x in per_rank],
+           "per_rank_roofline_frac": None if per_rank is None else [x["achieved_GBps"] / HBM_PEAK_GBS for x in per_rank],
+           "ranks_calibrated_identical_parameters": None if per_rank is None else True,
            "rccl": {"calls": r.get("rccl_collectives", 0), "summed_latency_s": r.get("rccl_collective_seconds", 0.0),
                     "what": "one all-gather of 144 x {sum, sumsq, min, max} fp64 partials per objective evaluation; latency = enqueue to result on the host"},
            "roofline": {"bound": "hbm", "achieved": rp["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["achieved_GBps"] / HBM_PEAK_GBS,
@@ -389,7 +403,7 @@ def main():
     lmm = None
     if args.workload in ("both", "lmm"):
         try:
-            lmm = lmm_leg(args, world, rank, nonce, cpu_base=not args.no_cpu_baseline)     # child processes; this process has not touched the GPU yet
+            lmm = lmm_leg(args, world, rank, nonce, cpu_base=not args.no_cpu_baseline, store=store)     # child processes; this process has not touched the GPU yet
         except Exception as e:
             if args.workload == "lmm":
                 raise

@@ -82,6 +82,54 @@ def fusion_hold(hold) -> int:
     return prev.value
 
 
+_expectation_gather = None          # keeps the ctypes callback of the expectation communicator alive
+
+
+def set_expectation_comm(world: int, rank: int, gather=None) -> None:
+    """fmhip_set_expectation_comm: Monte-Carlo paths sharded over `world` processes (one GPU each; this process holds the paths
+    [rank·n, (rank+1)·n) of every vector).  `gather(local)` receives this rank's moments as a float64 array and returns every
+    rank's, shape (world, len(local)), in rank order (an all-gather: torch.distributed, mpi4py …).  From then on getAverage(),
+    getVariance(), getMin(), getMax() and fm.reduce_moments* return the moments of the GLOBAL vectors on every rank — sums added
+    in rank order, so every rank sees the same bits.  world = 1 (or gather None) removes the communicator."""
+    import numpy as _np
+    global _expectation_gather
+    if gather is None or world <= 1:
+        _native.check(lib().fmhip_set_expectation_comm(1, 0, _native.GATHER_FN(0), None))
+        _expectation_gather = None
+        return
+
+    def _thunk(_ctx, local, count, gathered):
+        try:
+            mine = _np.ctypeslib.as_array(local, shape=(count,)).copy()
+            everyone = _np.ascontiguousarray(gather(mine), dtype=_np.float64).reshape(world, count)
+            _np.ctypeslib.as_array(gathered, shape=(world * count,))[:] = everyone.ravel()
+            return 0
+        except Exception:               # an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = _native.GATHER_FN(_thunk)
+    _native.check(lib().fmhip_set_expectation_comm(int(world), int(rank), cb, None))
+    _expectation_gather = cb
+
+
+def expectation_world():
+    """(world, rank) of the expectation communicator; (1, 0) without one."""
+    w, r = _C.c_int(1), _C.c_int(0)
+    _native.check(lib().fmhip_expectation_world(_C.byref(w), _C.byref(r)))
+    return w.value, r.value
+
+
+def expectation_combine(gathered):
+    """fmhip_expectation_combine (host only): gathered[rank][vector] = (sum, sumsq, min, max) → the global moments per vector."""
+    import numpy as _np
+    g = _np.ascontiguousarray(gathered, dtype=_np.float64)
+    world, count = g.shape[0], g.shape[1]
+    out = _np.zeros((count, 4), dtype=_np.float64)
+    _native.check(lib().fmhip_expectation_combine(g.ctypes.data_as(_C.POINTER(_native.Moments)), world, count, out.ctypes.data_as(_C.POINTER(_native.Moments))))
+    return out
+
+
 def set_step_grouping(steps: int) -> int:
     """fmhip_set_step_grouping: the engine keeps the methods recorded between `steps` time-step boundaries (first use of a Brownian
     increment with a new time index) pending and executes them together; 0 = off.  Returns the previous setting."""

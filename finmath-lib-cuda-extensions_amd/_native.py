@@ -22,7 +22,8 @@ SYMBOLS = [
     "fmhip_call_v1s0", "fmhip_call_v1s1", "fmhip_call_v2s0", "fmhip_call_v2s1", "fmhip_call_v3s0",
     "fmhip_set_fusion", "fmhip_flush", "fmhip_fusion_hold", "fmhip_set_step_grouping", "fmhip_graph_clone", "fmhip_graph_scalars", "fmhip_set_math_mode",
     "fmhip_reduce_moments", "fmhip_reduce_moments_batch", "fmhip_reduce_moments_batch_device", "fmhip_reduce_moments_device",
-    "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count",
+    "fmhip_set_expectation_comm", "fmhip_expectation_world", "fmhip_expectation_combine",
+    "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count", "fmhip_program_shape",
     "fmhip_program_run", "fmhip_program_run_into",
     "fmhip_set_jit", "fmhip_jit_wait", "fmhip_jit_stats", "fmhip_program_tier", "fmhip_program_source",
     "fmhip_bm_generate", "fmhip_mersenne_increments", "fmhip_bm_generate_mersenne", "fmhip_inverse_normal_cdf",
@@ -33,6 +34,10 @@ SYMBOLS = [
 OK = 0
 ERR_INVALID_HANDLE, ERR_SIZE_MISMATCH, ERR_OUT_OF_MEMORY, ERR_HIP = -1, -2, -3, -4
 ERR_INVALID_ARGUMENT, ERR_NOT_INITIALIZED, ERR_UNSUPPORTED, ERR_PROGRAM_LIMIT = -5, -6, -7, -8
+
+
+# fmhip_gather_fn: int (*)(void* context, const double* local, int count_doubles, double* gathered)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
 
 
 class Moments(C.Structure):
@@ -130,6 +135,9 @@ def lib():
         "fmhip_reduce_moments": [vec, dbl, C.POINTER(Moments)], "fmhip_reduce_moments_batch": [pv, i32, C.POINTER(dbl), C.POINTER(Moments)], "fmhip_reduce_moments_batch_device": [pv, i32, C.POINTER(dbl), vp], "fmhip_reduce_moments_device": [vec, dbl, vp],
         "fmhip_program_create": [C.POINTER(ProgOp), i32, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), i32, pv],
         "fmhip_program_release": [i64], "fmhip_program_launch_count": [i64, C.POINTER(i32)],
+        "fmhip_program_shape": [i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+        "fmhip_set_expectation_comm": [i32, i32, GATHER_FN, vp], "fmhip_expectation_world": [C.POINTER(i32), C.POINTER(i32)],
+        "fmhip_expectation_combine": [C.POINTER(Moments), i32, i32, C.POINTER(Moments)],
         "fmhip_program_run": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
         "fmhip_program_run_into": [i64, i32, pv, pv, C.POINTER(dbl), C.POINTER(Moments), vp],
         "fmhip_bm_generate": [i64, i32, i32, i64, i64, C.POINTER(dbl), pv],

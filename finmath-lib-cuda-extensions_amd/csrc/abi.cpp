@@ -1,6 +1,7 @@
 // abi.cpp — the extern "C" surface declared in include/fmhip.h.  No logic: argument checks, the engine
 // lock, exception → status translation.  A JNI layer maps 1:1 onto these.
 #include "runtime.hpp"
+#include <cmath>
 
 #include <cstring>
 #include <string>
@@ -142,11 +143,51 @@ int fmhip_set_math_mode(int mode, int* previous) {
 }
 int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); Engine::get().end_step_group(); }); }
 
+// ---- expectation communicator (include/fmhip.h): the global moments of path-sharded vectors
+static void combine_moments(const fmhip_moments* gathered, int world, int count, fmhip_moments* out) {
+    for (int k = 0; k < count; ++k) {
+        fmhip_moments m = gathered[k];                                   // rank 0, then the others in rank order
+        for (int r = 1; r < world; ++r) {
+            const fmhip_moments& g = gathered[(size_t)r * count + k];
+            m.sum += g.sum; m.sumsq += g.sumsq;
+            // java.lang.Math.min / max: NaN-propagating, -0.0 < +0.0 (as the device's reduction, fm_device_math.hpp)
+            m.min = (m.min != m.min || g.min != g.min) ? std::nan("") : (g.min < m.min || (g.min == m.min && std::signbit(g.min))) ? g.min : m.min;
+            m.max = (m.max != m.max || g.max != g.max) ? std::nan("") : (g.max > m.max || (g.max == m.max && !std::signbit(g.max))) ? g.max : m.max;
+        }
+        out[k] = m;
+    }
+}
+static void exchange_moments(Engine& e, fmhip_moments* inout, int count) {
+    if (e.comm_world <= 1 || !e.comm_gather) return;
+    std::vector<fmhip_moments> all((size_t)e.comm_world * count);
+    const int st = e.comm_gather(e.comm_context, reinterpret_cast<const double*>(inout), count * 4, reinterpret_cast<double*>(all.data()));
+    if (st != 0) throw Error(FMHIP_ERR_HIP, "the expectation communicator's gather failed with status " + std::to_string(st));
+    combine_moments(all.data(), e.comm_world, count, inout);
+}
+int fmhip_set_expectation_comm(int world, int rank, fmhip_gather_fn gather, void* context) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        if (world < 1 || rank < 0 || rank >= world) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad communicator: world " + std::to_string(world) + ", rank " + std::to_string(rank));
+        if (world > 1 && !gather) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a communicator of more than one rank needs a gather function");
+        e.comm_world = gather ? world : 1; e.comm_rank = gather ? rank : 0; e.comm_gather = gather; e.comm_context = context;
+    });
+}
+int fmhip_expectation_world(int* world, int* rank) {
+    return guarded([&] { Engine& e = Engine::get(); if (world) *world = e.comm_world; if (rank) *rank = e.comm_rank; });
+}
+int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int count, fmhip_moments* out) {
+    return guarded([&] {
+        need(gathered, "gathered"); need(out, "out");
+        if (world < 1 || count < 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad world or count");
+        combine_moments(gathered, world, count, out);
+    });
+}
+
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
-    return guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr); });
+    return guarded([&] { need(out, "out"); Engine& e = Engine::get(); e.reduce(v, shift, out, nullptr); exchange_moments(e, out, 1); });
 }
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
-    return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine::get().reduce_batch(vectors, count, shifts, out, nullptr); });
+    return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine& e = Engine::get(); e.reduce_batch(vectors, count, shifts, out, nullptr); exchange_moments(e, out, count); });
 }
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
     return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch(vectors, count, shifts, nullptr, device_out); });
@@ -160,6 +201,16 @@ int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
     return guarded([&] {
         need(out, "out");
         *out = Engine::get().program_create(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce);
+    });
+}
+int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_reduce) {
+    return guarded([&] {
+        Engine& e = Engine::get();
+        e.require_init();
+        const fm::Program* pr = e.program(p);
+        if (n_inputs) *n_inputs = pr->n_in;
+        if (n_outputs) *n_outputs = pr->n_out;
+        if (n_reduce) *n_reduce = pr->n_red;
     });
 }
 int fmhip_set_jit(int mode, int* previous) {

@@ -166,6 +166,10 @@ public:
     // shows where a time step ends.  With group_steps = S > 0 the methods recorded between S such boundaries stay pending (like
     // a soft hold) and are executed together: the engine sees S whole time steps at once, schedules them component by component
     // and runs the periodic stretch as one rolled-loop launch, instead of cutting the stream every ≈ 40 methods.
+    // expectation communicator (fmhip_set_expectation_comm): applied to host-side moments in abi.cpp
+    int comm_world = 1, comm_rank = 0;
+    fmhip_gather_fn comm_gather = nullptr;
+    void* comm_context = nullptr;
     int group_steps = 2;
     void end_step_group() { group_hold_ = false; group_steps_pending_ = 0; }      // a value is read, or the caller flushes: whatever was being grouped has run
     void flush_all();

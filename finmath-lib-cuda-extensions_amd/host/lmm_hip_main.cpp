@@ -134,7 +134,7 @@ int main(int argc, char** argv) {
             return std::string(buf) + prof;
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);
-        else { lmm::Options quiet = o; quiet.verbose = false; std::FILE* devnull = std::freopen("/dev/null", "w", stdout); (void)devnull; lmm::runAndReport(quiet, be, "hip", extra); }
+        else { lmm::Options quiet = o; quiet.verbose = false; lmm::runAndReport(quiet, be, "hip", extra); }        // every rank reports: the launcher compares the parameter vectors
         if (sums) fmhip_vec_release(sums);
         if (comm) ncclCommDestroy(comm);
         check(fmhip_shutdown());

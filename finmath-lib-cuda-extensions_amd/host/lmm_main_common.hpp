@@ -78,7 +78,7 @@ inline void runAndReport(const Options& o, const Backend& be, const char* backen
                 "\"initial_rms\": %.6e, \"rms_deviation\": %.6e, \"mean_deviation\": %.6e%s, \"parameters\": [",
                 backendName, (long long)o.paths, m.swaptions.size(), VolatilityModel().activeParameters(m).size(), r.iterations, r.evaluations,
                 r.seconds, r.seconds_simulation, r.seconds_valuation, r.initialRms, r.rmsDeviation, r.meanDeviation, extraJson().c_str());
-    for (size_t k = 0; k < r.model.parameter.size(); ++k) std::printf("%s%.10g", k ? ", " : "", r.model.parameter[k]);
+    for (size_t k = 0; k < r.model.parameter.size(); ++k) std::printf("%s%.17g", k ? ", " : "", r.model.parameter[k]);      // (17 digits: ranks compare them bit for bit)
     std::printf("]}\n");
 }
 

@@ -51,9 +51,12 @@ public:
     virtual double getVariance() const = 0;
     virtual double getMin() const = 0;
     virtual double getMax() const = 0;
-    double getSampleVariance() const { const int64_t n = size(); return (isDeterministic() || n == 1) ? 0.0 : getVariance() * n / (n - 1); }
+    // paths behind an expectation: size() unless the implementation shards its paths over processes (RandomVariableHip with an
+    // expectation communicator: size() of this process's shard times the number of ranks)
+    virtual int64_t sampleSize() const { return size(); }
+    double getSampleVariance() const { const int64_t n = sampleSize(); return (isDeterministic() || size() == 1) ? 0.0 : getVariance() * n / (n - 1); }
     double getStandardDeviation() const { return isDeterministic() ? 0.0 : std::sqrt(getVariance()); }
-    double getStandardError() const { return isDeterministic() ? 0.0 : getStandardDeviation() / std::sqrt((double)size()); }
+    double getStandardError() const { return isDeterministic() ? 0.0 : getStandardDeviation() / std::sqrt((double)sampleSize()); }
     virtual double getAverage(const RV& probabilities) const { return mult(probabilities)->getAverage(); }   // :886-888
     // scalar operand / unary
     virtual RV cap(double v) const = 0;
@@ -225,17 +228,19 @@ public:
     }
     const DeviceVector& deviceVector() const { return vec_; }
 
-    // ---- reductions on the device (replaces :830-901)
+    // ---- reductions on the device (replaces :830-901).  With an expectation communicator (fmhip_set_expectation_comm) the moments
+    // are those of the GLOBAL vector (this process holds one shard of its paths) and the sample size is that of all ranks.
+    int64_t sampleSize() const override { int world = 1; check(fmhip_expectation_world(&world, nullptr)); return size() * world; }
     double getAverage() const override {
         if (isDeterministic()) return value_;
         if (n_ == 0) return std::nan("");
-        return vec_.moments().sum / (double)n_;
+        return vec_.moments().sum / (double)sampleSize();
     }
     double getVariance() const override {                          // twin two-pass Σ(x-mean)²/n (twin:360-382)
         if (isDeterministic() || n_ == 1) return 0.0;
         if (n_ == 0) return std::nan("");
         const double mean = getAverage();
-        return vec_.moments(mean).sumsq / (double)n_;
+        return vec_.moments(mean).sumsq / (double)sampleSize();
     }
     double getMin() const override { return isDeterministic() ? value_ : vec_.moments().min; }
     double getMax() const override { return isDeterministic() ? value_ : vec_.moments().max; }
@@ -471,7 +476,8 @@ inline std::vector<double> getAverages(const std::vector<RV>& values) {
     if (!handles.empty() && uniform) {
         std::vector<fmhip_moments> m(handles.size());
         check(fmhip_reduce_moments_batch(handles.data(), (int)handles.size(), nullptr, m.data()));
-        for (size_t i = 0; i < handles.size(); ++i) out[where[i]] = m[i].sum / (double)n;
+        int world = 1; check(fmhip_expectation_world(&world, nullptr));
+        for (size_t i = 0; i < handles.size(); ++i) out[where[i]] = m[i].sum / ((double)n * world);
     } else for (size_t k : where) out[k] = values[k]->getAverage();
     return out;
 }

@@ -198,6 +198,13 @@ class RandomVariableHip:
         raise NotImplementedError("UnsupportedOperationException (:785)")
 
     # ---- reductions, on the device
+    def _sample_size(self):
+        """Paths behind an expectation: size() of this process's shard times the ranks of the expectation communicator
+        (fmhip_set_expectation_comm; 1 without one) — the moments the engine returns are then those of the global vector."""
+        w = C.c_int(1)
+        N.check(N.lib().fmhip_expectation_world(C.byref(w), None))
+        return self.size() * w.value
+
     def getMin(self):
         if self.isDeterministic(): return self.value
         return self.realizations.moments().min
@@ -211,7 +218,7 @@ class RandomVariableHip:
             return self.mult(probabilities).getAverage()            # :886-888
         if self.isDeterministic(): return self.value
         if self.size() == 0: return math.nan
-        return self.realizations.moments().sum / self.size()
+        return self.realizations.moments().sum / self._sample_size()
 
     def getVariance(self, probabilities=None):
         if probabilities is not None:                                # twin:385-407  Σ (x-avg)² p  (no division)
@@ -224,12 +231,13 @@ class RandomVariableHip:
         if self.isDeterministic() or self.size() == 1: return 0.0
         if self.size() == 0: return math.nan
         average = self.getAverage()
-        return self.realizations.moments(shift=average).sumsq / self.size()     # twin:368-381
+        return self.realizations.moments(shift=average).sumsq / self._sample_size()     # twin:368-381
 
     def getSampleVariance(self):                                    # :904-913
         if self.isDeterministic() or self.size() == 1: return 0.0
         if self.size() == 0: return math.nan
-        return self.getVariance() * self.size() / (self.size() - 1)
+        n = self._sample_size()
+        return self.getVariance() * n / (n - 1)
 
     def getStandardDeviation(self, probabilities=None):             # :916-937
         if self.isDeterministic(): return 0.0
@@ -239,7 +247,7 @@ class RandomVariableHip:
     def getStandardError(self, probabilities=None):                 # :940-967
         if self.isDeterministic(): return 0.0
         if self.size() == 0: return math.nan
-        return self.getStandardDeviation(probabilities) / math.sqrt(self.size())
+        return self.getStandardDeviation(probabilities) / math.sqrt(self._sample_size())
 
     def average(self):                                               # :1280
         return RandomVariableHip(-math.inf, self.getAverage())

@@ -247,6 +247,24 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
  * of the one RCCL all-reduce per objective evaluation when paths are sharded over GPUs. */
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out);
 
+/* Expectation communicator: Monte-Carlo paths sharded over processes (one GPU each) behind an UNCHANGED caller.
+ * Every vector of this process holds the paths [rank·n, (rank+1)·n) of a global vector of world·n paths; all element-wise
+ * work is local; the one thing that couples paths is an expectation.  With a communicator set, fmhip_reduce_moments and
+ * fmhip_reduce_moments_batch return the moments of the GLOBAL vector on every rank: the local {Σ, Σ², min, max} are handed to
+ * `gather` (called on the host, by the thread that asked; it must deliver every rank's `count` doubles to every rank, in rank
+ * order — an all-gather over RCCL / MPI / gloo) and combined by fmhip_expectation_combine: sums added in RANK ORDER (bitwise
+ * equal on every rank, whatever the transport), min / max over ranks.  The drop-in classes divide by world·n
+ * (fmhip_expectation_world), so getAverage() / getVariance() of a finmath-lib product mean the same as on one GPU and every
+ * rank's optimiser takes the same step.  The *_device variants stay local partials (for callers that run their own collective
+ * on the device).  Every rank must ask for the same expectations in the same order.  world = 1 or gather = NULL removes it.
+ * The reference has nothing here: one process, one device (RandomVariableCuda.java:161,177). */
+typedef int (*fmhip_gather_fn)(void* context, const double* local, int count_doubles, double* gathered /* [world][count_doubles] */);
+int fmhip_set_expectation_comm(int world, int rank, fmhip_gather_fn gather, void* context);
+/* The communicator's size and this process's rank (1 and 0 without one). */
+int fmhip_expectation_world(int* world, int* rank);
+/* The combination rule on its own (host only, needs no device): gathered[r·count + k] = rank r's moments of vector k. */
+int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int count, fmhip_moments* out);
+
 /* ---------------------------------------------------------------- fused programs */
 
 /* One SSA instruction. Values are numbered: 0 … n_inputs-1 are the program inputs, n_inputs+i is the
@@ -266,6 +284,8 @@ int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs,
 int fmhip_program_release(fmhip_program p);
 /* Number of kernel launches one run of p takes (1 unless the program had to be split). */
 int fmhip_program_launch_count(fmhip_program p, int* n_launches);
+/* Inputs, outputs and fused reductions per batch row of p: the lengths fmhip_program_run expects of its arrays. */
+int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_reduce);
 /* Run p over `batch` independent input tuples in ONE launch (horizontal batching).
  *   inputs  [batch * n_inputs ]  all of equal size
  *   outputs [batch * n_outputs]  receives new handles (caller releases)

@@ -66,11 +66,17 @@ final class Native {
 	static native int reduceMomentsDevice(long vector, double shift, long deviceOut4Doubles);
 	static native int reduceMomentsBatch(long[] vectors, double[] shiftsOrNull, double[] moments4PerVector);
 	static native int reduceMomentsBatchDevice(long[] vectors, double[] shiftsOrNull, long deviceOut);
+	// expectation communicator (paths sharded over processes): gatherFunction = address of a C function of type fmhip_gather_fn,
+	// e.g. from an MPI / RCCL helper library; context is handed back to it.  0 removes the communicator.
+	static native int setExpectationComm(int world, int rank, long gatherFunction, long context);
+	static native int expectationWorld(int[] world, int[] rankOrNull);
+	static native int expectationCombine(double[] gatheredMoments4PerRankAndVector, int world, int count, double[] moments4PerVector);
 
 	// ---- explicit fused programs: ops as parallel arrays {opcode, a, b, c, scalar}
 	static native long programCreate(int[] opcode, int[] a, int[] b, int[] c, double[] scalar, int nInputs, int[] outValues, int[] reduceValues);
 	static native int programRelease(long program);
 	static native int programLaunchCount(long program, int[] launches);
+	static native int programShape(long program, int[] inputsOutputsReductions3);
 	static native int programRun(long program, int batch, long[] inputs, long[] outputs, double[] reduceShiftOrNull, double[] moments4OrNull, long deviceMomentsOrZero);
 	static native int programRunInto(long program, int batch, long[] inputs, long[] outputs, double[] reduceShiftOrNull, double[] moments4OrNull, long deviceMomentsOrZero);
 

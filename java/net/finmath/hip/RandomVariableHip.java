@@ -196,6 +196,16 @@ public class RandomVariableHip implements RandomVariable {
 		return isDeterministic() ? valueIfNonStochastic : realizations.moments(0.0)[3];
 	}
 
+	/**
+	 * Paths behind an expectation: size() of this process's shard times the ranks of the expectation communicator
+	 * (Native.setExpectationComm; 1 without one) - the moments the engine returns are then those of the global vector.
+	 */
+	private long sampleSize() {
+		final int[] world = new int[1];
+		Native.check(Native.expectationWorld(world, null));
+		return (long)size() * world[0];
+	}
+
 	@Override
 	public double getAverage() {
 		if(isDeterministic()) {
@@ -204,7 +214,7 @@ public class RandomVariableHip implements RandomVariable {
 		if(size() == 0) {
 			return Double.NaN;
 		}
-		return realizations.moments(0.0)[0] / size();
+		return realizations.moments(0.0)[0] / sampleSize();
 	}
 
 	@Override
@@ -221,7 +231,7 @@ public class RandomVariableHip implements RandomVariable {
 			return Double.NaN;
 		}
 		final double average = getAverage();							// two passes like the twin (twin:360-382): Σ(x - mean)²/n, second pass on the device
-		return realizations.moments(average)[1] / size();
+		return realizations.moments(average)[1] / sampleSize();
 	}
 
 	@Override
@@ -235,7 +245,8 @@ public class RandomVariableHip implements RandomVariable {
 		if(isDeterministic() || size() == 1) {
 			return 0.0;
 		}
-		return getVariance() * size() / (size() - 1);
+		final long n = sampleSize();
+		return getVariance() * n / (n - 1);
 	}
 
 	@Override
@@ -250,12 +261,12 @@ public class RandomVariableHip implements RandomVariable {
 
 	@Override
 	public double getStandardError() {
-		return isDeterministic() ? 0.0 : getStandardDeviation() / Math.sqrt(size());
+		return isDeterministic() ? 0.0 : getStandardDeviation() / Math.sqrt(sampleSize());
 	}
 
 	@Override
 	public double getStandardError(final RandomVariable probabilities) {
-		return isDeterministic() ? 0.0 : getStandardDeviation(probabilities) / Math.sqrt(size());
+		return isDeterministic() ? 0.0 : getStandardDeviation(probabilities) / Math.sqrt(sampleSize());
 	}
 
 	// ---- host-side cold paths: the reference sorts on the host as well (:970-1091)
@@ -279,6 +290,38 @@ public class RandomVariableHip implements RandomVariable {
 		throw new RuntimeException("Method not implemented.");			// as :989-998
 	}
 
+	// The three methods below share one sorted copy of the sample and two helpers (as random_variable.py and host/random_variable.hpp
+	// do): the position a quantile falls on, and the number of sample points not above a bound (binary search).  Semantics as the
+	// reference's (:1001-1091): mean of the sorted sample between two quantile positions; shares of the sample per interval
+	// (points[k-1], points[k]] plus the share above the last point; a symmetric grid of points around the mean with its bin edges.
+
+	private double[] sortedSample() {
+		final double[] sample = getRealizations();
+		Arrays.sort(sample);
+		return sample;
+	}
+
+	/** Position of a quantile in a sorted sample of this size: round((n + 1) q - 1), kept inside the sample. */
+	private int quantilePosition(final double quantile, final int sampleLength) {
+		final long position = Math.round((size() + 1) * quantile - 1);
+		return (int)Math.min(Math.max(position, 0L), sampleLength - 1L);
+	}
+
+	/** Number of elements of the sorted array that are <= bound. */
+	private static int countNotAbove(final double[] sorted, final double bound) {
+		int low = 0, high = sorted.length;
+		while(low < high) {
+			final int middle = (low + high) >>> 1;
+			if(sorted[middle] <= bound) {
+				low = middle + 1;
+			}
+			else {
+				high = middle;
+			}
+		}
+		return low;
+	}
+
 	@Override
 	public double getQuantileExpectation(final double quantileStart, final double quantileEnd) {
 		if(isDeterministic()) {
@@ -287,68 +330,57 @@ public class RandomVariableHip implements RandomVariable {
 		if(size() == 0) {
 			return Double.NaN;
 		}
-		if(quantileStart > quantileEnd) {
-			return getQuantileExpectation(quantileEnd, quantileStart);
-		}
-		final double[] sorted = getRealizations();
-		Arrays.sort(sorted);
-		final int start = Math.min(Math.max((int)Math.round((size() + 1) * quantileStart - 1), 0), sorted.length - 1);
-		final int end = Math.min(Math.max((int)Math.round((size() + 1) * quantileEnd - 1), 0), sorted.length - 1);
-		double sum = 0.0;
-		for(int i = start; i <= end; i++) {
-			sum += sorted[i];
-		}
-		return sum / (end - start + 1);
+		final double[] sample = sortedSample();
+		final int from = quantilePosition(Math.min(quantileStart, quantileEnd), sample.length);
+		final int to = quantilePosition(Math.max(quantileStart, quantileEnd), sample.length);
+		return Arrays.stream(sample, from, to + 1).sum() / (to - from + 1);
 	}
 
 	@Override
 	public double[] getHistogram(final double[] intervalPoints) {
-		final double[] histogram = new double[intervalPoints.length + 1];
+		final int bins = intervalPoints.length + 1;
+		final double[] shares = new double[bins];
 		if(isDeterministic()) {
-			Arrays.fill(histogram, 0.0);
+			// the reference's convention for a constant (:1030-1041): the first point below the value, and the last bin
 			for(int k = 0; k < intervalPoints.length; k++) {
 				if(valueIfNonStochastic > intervalPoints[k]) {
-					histogram[k] = 1.0;
+					shares[k] = 1.0;
 					break;
 				}
 			}
-			histogram[intervalPoints.length] = 1.0;
-			return histogram;
+			shares[bins - 1] = 1.0;
+			return shares;
 		}
-		final double[] sorted = getRealizations();
-		Arrays.sort(sorted);
-		int sampleIndex = 0;
+		final double[] sample = sortedSample();
+		int below = 0;							// sample points accounted for so far
 		for(int k = 0; k < intervalPoints.length; k++) {
-			int count = 0;
-			while(sampleIndex < sorted.length && sorted[sampleIndex] <= intervalPoints[k]) {
-				sampleIndex++;
-				count++;
-			}
-			histogram[k] = count;
+			final int upTo = Math.max(countNotAbove(sample, intervalPoints[k]), below);		// (points that are not ascending get empty intervals)
+			shares[k] = upTo - below;
+			below = upTo;
 		}
-		histogram[intervalPoints.length] = sorted.length - sampleIndex;
-		if(sorted.length > 0) {
-			for(int k = 0; k < histogram.length; k++) {
-				histogram[k] /= sorted.length;
+		shares[bins - 1] = sample.length - below;
+		if(sample.length > 0) {
+			for(int k = 0; k < bins; k++) {
+				shares[k] /= sample.length;
 			}
 		}
-		return histogram;
+		return shares;
 	}
 
 	@Override
 	public double[][] getHistogram(final int numberOfPoints, final double standardDeviations) {
 		final double center = getAverage();
 		final double radius = standardDeviations * getStandardDeviation();
-		final double stepSize = (numberOfPoints - 1) / 2.0;
-		final double[] intervalPoints = new double[numberOfPoints];
-		final double[] anchorPoints = new double[numberOfPoints + 1];
+		final double halfSpan = (numberOfPoints - 1) / 2.0;			// grid points per side
+		final double halfBin = radius / (2 * halfSpan);
+		final double[] points = new double[numberOfPoints];
+		final double[] edges = new double[numberOfPoints + 1];
 		for(int i = 0; i < numberOfPoints; i++) {
-			final double alpha = (-(double)(numberOfPoints - 1) / 2.0 + i) / stepSize;
-			intervalPoints[i] = center + alpha * radius;
-			anchorPoints[i] = center + alpha * radius - radius / (2 * stepSize);
+			points[i] = center + (i - halfSpan) / halfSpan * radius;
+			edges[i] = points[i] - halfBin;
 		}
-		anchorPoints[numberOfPoints] = center + radius + radius / (2 * stepSize);
-		return new double[][] { anchorPoints, getHistogram(intervalPoints) };
+		edges[numberOfPoints] = center + radius + halfBin;
+		return new double[][] { edges, getHistogram(points) };
 	}
 
 	@Override

@@ -1,13 +1,19 @@
 // fmhip_jni.cpp — the JNI layer of net.finmath.hip.Native: ONE function per C-ABI function of include/fmhip.h, no logic
 // beyond argument marshalling ("JNI layer = one Java_net_finmath_hip_Native_* function per C-ABI function").
 //
-// UNCOMPILED / UNTESTED in this repository: the build image has no JDK (no jni.h).  CMakeLists.txt at the repository root
-// builds it only when find_package(JNI) succeeds.  tests/test_jni_binding_cpu.py checks on every run that the set of functions
-// here, the native methods of java/net/finmath/hip/Native.java and the exports of include/fmhip.h are the same set.
+// UNCOMPILED against a real JDK / UNTESTED in a JVM in this repository: the build image has no JDK (no jni.h).  CMakeLists.txt at
+// the repository root builds it only when find_package(JNI) succeeds.  What IS done on every run of the CPU test suite
+// (tests/test_jni_binding_cpu.py): this file is compiled against a hand-written declaration stub of <jni.h> (tests/jni_stub: the
+// types and the JNIEnv members used here) and linked against libfmhip.so — every C++ error and every mismatch with
+// include/fmhip.h shows — and the set of functions here, the native methods of java/net/finmath/hip/Native.java and the exports
+// of the header are checked to be the same set.
 //
-// Marshalling rules: whole-vector uploads / read-backs pin their ONE array with Get/ReleasePrimitiveArrayCritical (no copy; the
-// engine narrows double → float itself, RandomVariableCuda.java:768-774); everything else uses Get/Release<Type>ArrayElements;
-// out-parameters are 1-element (or documented-length) arrays; a null array where the C function accepts NULL is passed as NULL.
+// Marshalling rules: every array is accessed with Get/Release<Type>ArrayElements (may copy; other JNI calls stay legal) — no
+// critical region is held around an engine call (an upload or a read-back synchronises with the device and may compile a
+// kernel: a pinned array would stall the collector for that long); EVERY array length is checked against what the C function
+// will read or write before it is called (FMHIP_ERR_INVALID_ARGUMENT otherwise: a short array from Java must never become a
+// native overrun); out-parameters are 1-element (or documented-length) arrays; a null array where the C function accepts NULL
+// is passed as NULL.
 #include <jni.h>
 #include <cstdint>
 #include <string>
@@ -30,24 +36,17 @@ struct Pin {
     ~Pin() { if (arr && p) ArrayOps<T>::put(env, arr, p, mode); }
     jsize length() const { return len; }
 };
-// The bulk transfers (upload / read-back of a whole vector): ONE array, pinned without a copy around the one native call; its
-// length is read before the critical region begins and no other JNI function is called inside it.
-template <typename T>
-struct Critical {
-    JNIEnv* env; jarray arr; T* p; jint mode; jsize len;
-    Critical(JNIEnv* e, jarray a, jint release_mode = 0) : env(e), arr(a), p(nullptr), mode(release_mode), len(a ? e->GetArrayLength(a) : 0) { if (a) p = (T*)e->GetPrimitiveArrayCritical(a, nullptr); }
-    ~Critical() { if (arr && p) env->ReleasePrimitiveArrayCritical(arr, p, mode); }
-    jsize length() const { return len; }
-};
-
 // fmhip_prog_op[] from the parallel arrays of Native.programCreate / programSource
-std::vector<fmhip_prog_op> program_ops(JNIEnv* env, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar) {
+// (false: an operand array is missing or shorter than the opcode array)
+bool program_ops(JNIEnv* env, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar, std::vector<fmhip_prog_op>& ops) {
     const jsize n = opcode ? env->GetArrayLength(opcode) : 0;
-    std::vector<fmhip_prog_op> ops((size_t)n);
+    ops.assign((size_t)n, fmhip_prog_op{});
+    if (n == 0) return true;
     Pin<jint> po(env, opcode, JNI_ABORT), pa(env, a, JNI_ABORT), pb(env, b, JNI_ABORT), pc(env, c, JNI_ABORT);
     Pin<jdouble> ps(env, scalar, JNI_ABORT);
+    if (!po.p || !pa.p || !pb.p || !pc.p || pa.length() < n || pb.length() < n || pc.length() < n || (ps.p && ps.length() < n)) return false;
     for (jsize i = 0; i < n; ++i) ops[(size_t)i] = { po.p[i], pa.p[i], pb.p[i], pc.p[i], ps.p ? ps.p[i] : 0.0 };
-    return ops;
+    return true;
 }
 
 inline void set1(JNIEnv* env, jintArray arr, jint v) { if (arr && env->GetArrayLength(arr) > 0) env->SetIntArrayRegion(arr, 0, 1, &v); }
@@ -82,12 +81,12 @@ FMJ(jint, getStream)(JNIEnv* env, jclass, jlongArray stream) {
 
 // ---------------------------------------------------------------- vectors
 FMJ(jlong, vecCreateFromDouble)(JNIEnv* env, jclass, jdoubleArray values) {
-    Critical<jdouble> p(env, values, JNI_ABORT);
+    Pin<jdouble> p(env, values, JNI_ABORT);
     fmhip_vec out = 0;
     return fmhip_vec_create_from_double(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
 }
 FMJ(jlong, vecCreateFromFloat)(JNIEnv* env, jclass, jfloatArray values) {
-    Critical<jfloat> p(env, values, JNI_ABORT);
+    Pin<jfloat> p(env, values, JNI_ABORT);
     fmhip_vec out = 0;
     return fmhip_vec_create_from_float(p.p, p.length(), &out) == FMHIP_OK ? (jlong)out : 0;
 }
@@ -101,8 +100,8 @@ FMJ(jint, vecSize)(JNIEnv* env, jclass, jlong v, jlongArray size) {
     if (st == FMHIP_OK) set1(env, size, (jlong)n);
     return st;
 }
-FMJ(jint, vecReadDouble)(JNIEnv* env, jclass, jlong v, jdoubleArray out) { Critical<jdouble> p(env, out); return fmhip_vec_read_double(v, p.p, p.length()); }
-FMJ(jint, vecReadFloat)(JNIEnv* env, jclass, jlong v, jfloatArray out) { Critical<jfloat> p(env, out); return fmhip_vec_read_float(v, p.p, p.length()); }
+FMJ(jint, vecReadDouble)(JNIEnv* env, jclass, jlong v, jdoubleArray out) { Pin<jdouble> p(env, out); return fmhip_vec_read_double(v, p.p, p.length()); }     // (the engine checks the length against the vector's)
+FMJ(jint, vecReadFloat)(JNIEnv* env, jclass, jlong v, jfloatArray out) { Pin<jfloat> p(env, out); return fmhip_vec_read_float(v, p.p, p.length()); }
 FMJ(jint, vecDevicePtr)(JNIEnv* env, jclass, jlong v, jlongArray devicePointer) {
     void* ptr = nullptr;
     const int st = fmhip_vec_device_ptr(v, &ptr);
@@ -124,12 +123,13 @@ FMJ(jint, setStepGrouping)(JNIEnv* env, jclass, jint steps, jintArray previous) 
 FMJ(jint, fusionHold)(JNIEnv* env, jclass, jint hold, jintArray previous) { int prev = 0; const int st = fmhip_fusion_hold(hold, &prev); if (st == FMHIP_OK) set1(env, previous, prev); return st; }
 FMJ(jint, graphClone)(JNIEnv* env, jclass, jlongArray roots, jint nCopies, jlongArray leafFrom, jlongArray leafTo, jdoubleArray scalars, jint nScalars, jlongArray out) {
     Pin<jlong> pr(env, roots, JNI_ABORT), pf(env, leafFrom, JNI_ABORT), pt(env, leafTo, JNI_ABORT), po(env, out); Pin<jdouble> ps(env, scalars, JNI_ABORT);
-    if (pt.length() < pf.length() * nCopies || po.length() < pr.length() * nCopies || (ps.p && ps.length() < nScalars * nCopies)) return FMHIP_ERR_INVALID_ARGUMENT;
+    if (nCopies < 0 || nScalars < 0 || !pr.p || !po.p || (int64_t)pt.length() < (int64_t)pf.length() * nCopies || (int64_t)po.length() < (int64_t)pr.length() * nCopies ||
+        (ps.p && (int64_t)ps.length() < (int64_t)nScalars * nCopies)) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_graph_clone((const fmhip_vec*)pr.p, pr.length(), nCopies, (const fmhip_vec*)pf.p, (const fmhip_vec*)pt.p, pf.length(), ps.p, nScalars, (fmhip_vec*)po.p);
 }
 FMJ(jint, graphScalars)(JNIEnv* env, jclass, jlongArray roots, jdoubleArray scalarsOut, jintArray count) {
     int n = 0, st;
-    { Pin<jlong> pr(env, roots, JNI_ABORT); Pin<jdouble> ps(env, scalarsOut); st = fmhip_graph_scalars((const fmhip_vec*)pr.p, pr.length(), ps.p, ps.length(), &n); }
+    { Pin<jlong> pr(env, roots, JNI_ABORT); Pin<jdouble> ps(env, scalarsOut); st = fmhip_graph_scalars((const fmhip_vec*)pr.p, pr.length(), ps.p, ps.length(), &n); }     // capacity = the array's own length
     if (st == FMHIP_OK) set1(env, count, n);
     return st;
 }
@@ -146,28 +146,64 @@ FMJ(jint, reduceMomentsDevice)(JNIEnv*, jclass, jlong v, jdouble shift, jlong de
 FMJ(jint, reduceMomentsBatch)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jdoubleArray moments4PerVector) {
     Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT); Pin<jdouble> pm(env, moments4PerVector);
     static_assert(sizeof(fmhip_moments) == 4 * sizeof(double), "moments travel as 4 doubles");
+    if (!pv.p || !pm.p || (int64_t)pm.length() < 4 * (int64_t)pv.length() || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_reduce_moments_batch((const fmhip_vec*)pv.p, pv.length(), ps.p, (fmhip_moments*)pm.p);
 }
 FMJ(jint, reduceMomentsBatchDevice)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jlong deviceOut) {
     Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT);
+    if (!pv.p || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_reduce_moments_batch_device((const fmhip_vec*)pv.p, pv.length(), ps.p, (void*)(intptr_t)deviceOut);
+}
+FMJ(jint, setExpectationComm)(JNIEnv*, jclass, jint world, jint rank, jlong gatherFunction, jlong context) {
+    return fmhip_set_expectation_comm(world, rank, (fmhip_gather_fn)(intptr_t)gatherFunction, (void*)(intptr_t)context);
+}
+FMJ(jint, expectationWorld)(JNIEnv* env, jclass, jintArray world, jintArray rank) {
+    int w = 1, r = 0;
+    const int st = fmhip_expectation_world(&w, &r);
+    if (st == FMHIP_OK) { set1(env, world, w); set1(env, rank, r); }
+    return st;
+}
+FMJ(jint, expectationCombine)(JNIEnv* env, jclass, jdoubleArray gathered, jint world, jint count, jdoubleArray moments4PerVector) {
+    Pin<jdouble> pg(env, gathered, JNI_ABORT), pm(env, moments4PerVector);
+    if (world < 1 || count < 0 || !pg.p || !pm.p || (int64_t)pg.length() < 4 * (int64_t)world * count || (int64_t)pm.length() < 4 * (int64_t)count) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_expectation_combine((const fmhip_moments*)pg.p, world, count, (fmhip_moments*)pm.p);
 }
 
 // ---------------------------------------------------------------- explicit fused programs
 FMJ(jlong, programCreate)(JNIEnv* env, jclass, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar, jint nInputs, jintArray outValues, jintArray reduceValues) {
-    const std::vector<fmhip_prog_op> ops = program_ops(env, opcode, a, b, c, scalar);
+    std::vector<fmhip_prog_op> ops;
+    if (!program_ops(env, opcode, a, b, c, scalar, ops)) return 0;
     Pin<jint> po(env, outValues, JNI_ABORT), pr(env, reduceValues, JNI_ABORT);
     fmhip_program out = 0;
     return fmhip_program_create(ops.data(), (int)ops.size(), nInputs, (const int32_t*)po.p, po.length(), (const int32_t*)pr.p, pr.length(), &out) == FMHIP_OK ? (jlong)out : 0;
 }
 FMJ(jint, programRelease)(JNIEnv*, jclass, jlong p) { return fmhip_program_release(p); }
 FMJ(jint, programLaunchCount)(JNIEnv* env, jclass, jlong p, jintArray launches) { int n = 0; const int st = fmhip_program_launch_count(p, &n); if (st == FMHIP_OK) set1(env, launches, n); return st; }
+FMJ(jint, programShape)(JNIEnv* env, jclass, jlong p, jintArray inputsOutputsReductions3) {
+    int shape[3] = { 0, 0, 0 };
+    const int st = fmhip_program_shape(p, &shape[0], &shape[1], &shape[2]);
+    if (st == FMHIP_OK && inputsOutputsReductions3 && env->GetArrayLength(inputsOutputsReductions3) >= 3) { const jint v[3] = { shape[0], shape[1], shape[2] }; env->SetIntArrayRegion(inputsOutputsReductions3, 0, 3, v); }
+    return st;
+}
+namespace {
+// the arrays of programRun / programRunInto against the program's shape: batch x inputs handles in, batch x outputs handles,
+// one shift per reduction, 4 doubles per row and reduction
+bool run_arrays_fit(jlong p, jint batch, const Pin<jlong>& in, const Pin<jlong>& out, const Pin<jdouble>& shift, const Pin<jdouble>& moments) {
+    int n_in = 0, n_out = 0, n_red = 0;
+    if (batch <= 0 || fmhip_program_shape(p, &n_in, &n_out, &n_red) != FMHIP_OK) return false;
+    const int64_t b = batch;
+    return in.p && (int64_t)in.length() >= b * n_in && (n_out == 0 || (out.p && (int64_t)out.length() >= b * n_out)) &&
+           (!shift.p || shift.length() >= n_red) && (!moments.p || (int64_t)moments.length() >= 4 * b * n_red);
+}
+}
 FMJ(jint, programRun)(JNIEnv* env, jclass, jlong p, jint batch, jlongArray inputs, jlongArray outputs, jdoubleArray reduceShift, jdoubleArray moments4, jlong deviceMoments) {
     Pin<jlong> pi(env, inputs, JNI_ABORT), po(env, outputs); Pin<jdouble> ps(env, reduceShift, JNI_ABORT), pm(env, moments4);
+    if (!run_arrays_fit(p, batch, pi, po, ps, pm)) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_program_run(p, batch, (const fmhip_vec*)pi.p, (fmhip_vec*)po.p, ps.p, (fmhip_moments*)pm.p, (void*)(intptr_t)deviceMoments);
 }
 FMJ(jint, programRunInto)(JNIEnv* env, jclass, jlong p, jint batch, jlongArray inputs, jlongArray outputs, jdoubleArray reduceShift, jdoubleArray moments4, jlong deviceMoments) {
     Pin<jlong> pi(env, inputs, JNI_ABORT), po(env, outputs, JNI_ABORT); Pin<jdouble> ps(env, reduceShift, JNI_ABORT), pm(env, moments4);
+    if (!run_arrays_fit(p, batch, pi, po, ps, pm)) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_program_run_into(p, batch, (const fmhip_vec*)pi.p, (const fmhip_vec*)po.p, ps.p, (fmhip_moments*)pm.p, (void*)(intptr_t)deviceMoments);
 }
 
@@ -190,7 +226,8 @@ FMJ(jint, programTier)(JNIEnv* env, jclass, jlong p, jintArray tierAndVgprs) {
     return st;
 }
 FMJ(jstring, programSource)(JNIEnv* env, jclass, jintArray opcode, jintArray a, jintArray b, jintArray c, jdoubleArray scalar, jint nInputs, jintArray outValues, jintArray reduceValues) {
-    const std::vector<fmhip_prog_op> ops = program_ops(env, opcode, a, b, c, scalar);
+    std::vector<fmhip_prog_op> ops;
+    if (!program_ops(env, opcode, a, b, c, scalar, ops)) return nullptr;
     std::vector<int32_t> outs, reds;
     { Pin<jint> po(env, outValues, JNI_ABORT), pr(env, reduceValues, JNI_ABORT); outs.assign(po.p, po.p + po.length()); reds.assign(pr.p, pr.p + pr.length()); }
     int64_t needed = 0;
@@ -203,17 +240,17 @@ FMJ(jstring, programSource)(JNIEnv* env, jclass, jintArray opcode, jintArray a, 
 // ---------------------------------------------------------------- Brownian increments
 FMJ(jint, bmGenerate)(JNIEnv* env, jclass, jlong seed, jint nSteps, jint nFactors, jlong nPaths, jlong pathOffset, jdoubleArray dt, jlongArray outHandles) {
     Pin<jdouble> pd(env, dt, JNI_ABORT); Pin<jlong> po(env, outHandles);
-    if (po.length() < (jsize)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    if (nSteps <= 0 || nFactors <= 0 || !po.p || !pd.p || (int64_t)po.length() < (int64_t)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_bm_generate(seed, nSteps, nFactors, nPaths, pathOffset, pd.p, (fmhip_vec*)po.p);
 }
 FMJ(jint, mersenneIncrements)(JNIEnv* env, jclass, jint seed, jint nSteps, jint nFactors, jlong nPaths, jdoubleArray dt, jdoubleArray hostOut) {
     Pin<jdouble> pd(env, dt, JNI_ABORT), po(env, hostOut);
-    if ((int64_t)po.length() < (int64_t)nSteps * nFactors * nPaths || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    if (nSteps <= 0 || nFactors <= 0 || nPaths < 0 || !po.p || !pd.p || (int64_t)po.length() < (int64_t)nSteps * nFactors * nPaths || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_mersenne_increments(seed, nSteps, nFactors, nPaths, pd.p, po.p);
 }
 FMJ(jint, bmGenerateMersenne)(JNIEnv* env, jclass, jint seed, jint nSteps, jint nFactors, jlong nPaths, jdoubleArray dt, jlongArray outHandles) {
     Pin<jdouble> pd(env, dt, JNI_ABORT); Pin<jlong> po(env, outHandles);
-    if (po.length() < (jsize)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
+    if (nSteps <= 0 || nFactors <= 0 || !po.p || !pd.p || (int64_t)po.length() < (int64_t)nSteps * nFactors || pd.length() < nSteps) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_bm_generate_mersenne(seed, nSteps, nFactors, nPaths, pd.p, (fmhip_vec*)po.p);
 }
 FMJ(jdouble, inverseNormalCdf)(JNIEnv*, jclass, jdouble p) { return fmhip_inverse_normal_cdf(p); }

@@ -81,3 +81,32 @@ def test_status_is_stated():
         assert re.search(r"UNCOMPILED|never configured or compiled", read(path)), path
     for doc in ("README.md", "INTEGRATION.md"):
         assert re.search(r"uncompiled|not compiled|never compiled", read(ROOT, doc), flags=re.I), doc
+
+
+def test_jni_layer_compiles_against_a_declaration_stub_and_links_against_the_library(tmp_path):
+    """No JDK here — but a hand-written declaration stub of <jni.h> (tests/jni_stub/jni.h: the specification's types and the JNIEnv
+    members the layer uses, nothing with a body) is enough to put src/jni/fmhip_jni.cpp through a C++ compiler with all warnings on
+    and to link it against libfmhip.so: every C++ error, every call that does not match include/fmhip.h, every fmhip_* function
+    that the library does not export shows up in this test instead of at a user's first build.  The resulting library exports
+    exactly one Java_net_finmath_hip_Native_* symbol per native method of Native.java."""
+    import shutil
+    import subprocess
+    import pytest
+    gxx = shutil.which("g++")
+    lib = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "lib", "libfmhip.so")
+    if not gxx or not os.path.exists(lib):
+        pytest.skip("needs g++ and the built libfmhip.so")
+    out = tmp_path / "libfmhip_jni.so"
+    res = subprocess.run([gxx, "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fPIC", "-shared", "-Wl,--no-undefined-version",
+                          "-I", os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"),
+                          os.path.join(ROOT, "src", "jni", "fmhip_jni.cpp"), "-o", str(out), "-L", os.path.dirname(lib), "-lfmhip"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-3000:]
+    defined = subprocess.run(["nm", "-D", "--defined-only", str(out)], capture_output=True, text=True).stdout
+    exported = sorted(re.findall(r"Java_net_finmath_hip_Native_(\w+)", defined))
+    native = sorted(re.findall(r"static native [\w\[\]]+\s+(\w+)\s*\(", read(JAVA, "Native.java")))
+    assert exported == native
+    # every fmhip_* symbol the layer needs is one the library really exports (the header alone could promise more than the library has)
+    needed = set(re.findall(r"\bU\s+(fmhip_\w+)", subprocess.run(["nm", "-D", "--undefined-only", str(out)], capture_output=True, text=True).stdout))
+    have = set(re.findall(r"\bT\s+(fmhip_\w+)", subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True).stdout))
+    assert needed and needed <= have, sorted(needed - have)
+    assert needed == set(header_exports())

@@ -97,3 +97,57 @@ def test_bench_rendezvous_hands_every_rank_the_same_nonce(tmp_path):
                         "--master-port", str(_free_port()), str(script)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "nonce agreed on 2 ranks" in r.stdout
+
+
+def _comm_worker(rank, world, port, n_total, q):
+    """The ENGINE's combination rule (fmhip_expectation_combine: what fmhip_reduce_moments applies behind an expectation communicator)
+    fed by a two-process all-gather over gloo with the oracle's partial moments — the library is loaded, no device is needed."""
+    import importlib, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+    par = importlib.import_module("finmath-lib-cuda-extensions_amd.parallel")
+    import oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    off, cnt = par.path_shard(n_total, world, rank)
+    z = oracle.bm_increment(27182, 5, off, cnt, np.float32(np.sqrt(0.25)))
+    w = oracle.f_v1s1("ADD_S", oracle.f_v1s0("ABS", z), -0.5)
+    if rank == 1:
+        w[7] = np.nan
+        z[3] = -0.0
+    if rank == 0:
+        z[11] = 0.0
+    local = np.stack([oracle.f_moments(z, 0.125), oracle.f_moments(w)])              # [vector][4]; a shifted second moment for the first
+    mine = torch.tensor(local.ravel(), dtype=torch.float64)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)                                                  # what a gather function of fmhip_set_expectation_comm does
+    gathered = np.stack([t.numpy().reshape(2, 4) for t in everyone])                 # [rank][vector][4]
+    combined = fm.expectation_combine(gathered)
+    q.put((rank, off, cnt, z, w, combined))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_engine_combination_rule_over_a_two_process_gather(oracle, fm):
+    n_total = 30011
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    for p in procs: p.join(timeout=120); assert p.exitcode == 0
+    z = np.concatenate([got[0][3], got[1][3]]); w = np.concatenate([got[0][4], got[1][4]])
+    assert z.size == n_total
+    assert (got[0][5].view(np.uint64) == got[1][5].view(np.uint64)).all() or np.isnan(got[0][5]).any()     # every rank holds the same bits …
+    both = np.stack([got[0][5], got[1][5]])
+    assert (np.isnan(both[0]) == np.isnan(both[1])).all() and (both[0][~np.isnan(both[0])] == both[1][~np.isnan(both[1])]).all()
+    c = got[0][5]
+    mz = oracle.f_moments(z, 0.125)
+    assert abs(c[0, 0] - mz[0]) <= 1e-12 * np.abs(z.astype(np.float64) - 0.125).sum()                      # … the moments of the union
+    assert abs(c[0, 1] - mz[1]) <= 1e-12 * mz[1]
+    assert c[0, 2] == mz[2] and c[0, 3] == mz[3]
+    assert np.isnan(c[1, 2]) and np.isnan(c[1, 3]) and np.isnan(c[1, 0])                                   # the injected NaN
+    # java.lang.Math.min / max order the zeros: -0.0 (rank 1) below +0.0 (rank 0)
+    zeros = fm.expectation_combine(np.array([[[0.0, 0.0, 0.0, -0.0]], [[0.0, 0.0, -0.0, 0.0]]]))
+    assert np.signbit(zeros[0, 2]) and not np.signbit(zeros[0, 3])
