@@ -111,7 +111,23 @@ def lib():
     # must `import torch` BEFORE this library is loaded, so that the loader resolves our NEEDED
     # libamdhip64.so.7 to the runtime already in the process (one HIP runtime, shared device pointers).
     if _stale():
-        build()
+        # One builder at a time (every rank of a torchrun launch imports this module at once): the others wait for the lock and then find
+        # the library current.  A box with a prebuilt library but no compiler keeps working: the existing library is loaded, loudly.
+        import fcntl
+        os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+        with open(LIB_PATH + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if _stale():
+                    try:
+                        build()
+                    except Exception as e:
+                        if not os.path.exists(LIB_PATH):
+                            raise
+                        import warnings
+                        warnings.warn(f"libfmhip.so is older than its sources and rebuilding it failed ({e}); loading the existing library", RuntimeWarning)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing — the HIP extension is required (no CPU fallback exists)")
     L = C.CDLL(LIB_PATH)

@@ -66,6 +66,20 @@ struct RolledBody {
     std::vector<uint32_t> carried, final_pos, out_pos;                 // positions whose value is carried / stored once behind the loop / stored every iteration
     struct Op { uint32_t uop; std::string x0, x1, x2; bool scalar; };  // x1 / x2 empty: the micro-op does not read them
     std::vector<Op> ops;
+    // PEELED form: the operations in front of the loop and behind it run in the SAME launch (runtime.cpp: plan_peel) — a component
+    // that is a short head, a periodic stretch and a short tail (a swaption's backward induction with its payoff) is ONE launch
+    // instead of three, and the values between the parts stay in registers.  Further operand names: p<i> = result of operation i
+    // in front of the loop, q<i> = of operation i behind it, x<k> = k-th extra input vector (the first extra_pre of them are loaded
+    // in front of the loop, the others behind it), F<k> = k-th final value of the loop.  The carried values start from
+    // carried_init[k] (a p-name) instead of being loaded.
+    struct Peel {
+        bool present = false;
+        std::vector<Op> pre, post;
+        uint32_t extra_pre = 0, extra_post = 0;
+        std::vector<std::string> carried_init;
+        std::vector<uint32_t> pre_out, post_out;                        // operations (indices into pre / post) whose result is stored
+        std::vector<uint32_t> final_store;                              // per final value: 1 = stored (somebody outside the component reads it)
+    } peel;
 };
 std::string jit_generate_rolled_source(const RolledBody& body);
 std::string jit_describe(const RolledBody& body);

@@ -588,6 +588,18 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     if (batch <= 0) return;
     if (batch > 65535) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch too large");
     const int n_red = p->n_red;
+    {   // a row table that does not fit the pinned ring (FMHIP_RING_BYTES can be as small as 4 KB): as many rows per launch as fit
+        const size_t row_bytes = (size_t)p->proto.row_words * 8;
+        const size_t rows_fit = std::max<size_t>(1, (ring_cap_ - std::min<size_t>(ring_cap_, 256)) / row_bytes);
+        if ((size_t)batch * p->proto.row_words > (size_t)FM_INLINE_WORDS && (size_t)batch > rows_fit) {
+            for (size_t off = 0; off < (size_t)batch; off += rows_fit) {
+                const size_t m = std::min(rows_fit, (size_t)batch - off);
+                const std::vector<RowSpec> part(rows.begin() + (std::ptrdiff_t)off, rows.begin() + (std::ptrdiff_t)(off + m));
+                launch(p, n, part, host_moments ? host_moments + off * n_red : nullptr, dev_moments ? (char*)dev_moments + off * n_red * 32 : nullptr);
+            }
+            return;
+        }
+    }
     if (n == 0) {       // nothing to compute; reductions of an empty vector as the twin's loops leave them (:288,:303,:325)
         if (host_moments) for (int i = 0; i < batch * n_red; ++i) host_moments[i] = { 0.0, 0.0, DBL_MAX, -DBL_MAX };
         if (dev_moments && n_red > 0) {
@@ -784,7 +796,12 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
     } else if ((FUSION_MAX_PENDING && !held && n_pending_ > FUSION_MAX_PENDING) || ((fusion_hold == 2 || (group_hold_ && fusion_hold == 0)) && n_pending_ > FUSION_SOFT_CAP)) {
         const fmhip_vec id = nd->id;
-        flush_all();
+        try { flush_all(); }
+        catch (...) {                       // the caller never receives this handle: take the node (and whatever still hangs below it) back
+            auto it = nodes_.find(id);
+            if (it != nodes_.end() && it->second == nd) { nd->refs_ext = 0; nodes_.erase(it); node_maybe_free(nd); }
+            throw;
+        }
         return id;
     }
     return nd->id;
@@ -1427,7 +1444,7 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
 static inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
 
 #define ROLL_TRACE(...) do { if (roll_trace) std::fprintf(stderr, __VA_ARGS__); } while (0)
-bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, std::string* source, int* elems_out)
+bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, std::string* source, int* elems_out, RolledBody* body_out)
 {
     static const bool roll_trace = std::getenv("FMHIP_ROLL_TRACE") != nullptr;
     const size_t n = g.order.size();
@@ -1583,6 +1600,85 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
     }
     jit_.record(jit_describe(body));
     *source = jit_generate_rolled_source(body);
+    if (body_out) *body_out = body;
+    return true;
+}
+
+// The PEELED form of a component with a rolled loop: everything in front of the loop and behind it in the same launch (jit.hpp:
+// RolledBody::Peel).  Possible when both parts are short, read few vectors of their own, and the part behind the loop reads nothing
+// of the loop but final values of its last iteration.
+bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, const RolledBody& loop_body)
+{
+    static const bool PEEL = [] { const char* e = std::getenv("FMHIP_PEEL"); return !(e && e[0] == '0'); }();
+    if (!PEEL) return false;
+    const size_t n = g.order.size(), P = ro.period, R = ro.iterations, begin = ro.begin, end = begin + P * R;
+    const size_t MAX_OPS = 16, MAX_EXTRA = 6;
+    if (begin > MAX_OPS || n - end > MAX_OPS || begin == 0) return false;
+    RolledBody body = loop_body;
+    RolledBody::Peel& pl = body.peel;
+    BigPlan::Rolled::Peeled pe;
+    pl.present = true;
+    std::vector<int> global_of(g.leaves.size(), -1), extra_of(g.leaves.size(), -1);
+    for (size_t k = 0; k < ro.global_leaf.size(); ++k) global_of[(size_t)ro.global_leaf[k]] = (int)k;
+    auto leaf_name = [&](size_t l) {
+        if (global_of[l] >= 0) return "g" + std::to_string(global_of[l]);
+        if (extra_of[l] < 0) { extra_of[l] = (int)pe.extra_leaf.size(); pe.extra_leaf.push_back((int32_t)l); }
+        return "x" + std::to_string(extra_of[l]);
+    };
+    std::vector<int> final_of(P, -1);
+    for (size_t k = 0; k < ro.final_pos.size(); ++k) final_of[ro.final_pos[k]] = (int)k;
+    auto make_op = [&](size_t i, bool behind, RolledBody::Op& out) {
+        const Node* nd = g.order[i];
+        UVariant uv{};
+        if (!variant_for(nd->opcode, 0, &uv)) return false;
+        if (nd->opcode == FMHIP_OP_POW_S || nd->opcode == FMHIP_OP_SIN || nd->opcode == FMHIP_OP_COS) return false;     // out-of-line library code: not in these kernels
+        uint32_t uop = uv.uop;
+        if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
+        body.uses_log |= uop == U_LOG;
+        std::string name[3];
+        for (int k = 0; k < nd->n_in; ++k) {
+            const int32_t o = operand[i][(size_t)k];
+            if (o < 0) name[k] = leaf_name((size_t)(-1 - o));
+            else if ((size_t)o < begin) name[k] = "p" + std::to_string(o);
+            else if ((size_t)o >= end) { if (!behind) return false; name[k] = "q" + std::to_string((size_t)o - end); }
+            else {                                                   // a value of the loop: only a final value of its LAST iteration, only from behind it
+                const size_t it = ((size_t)o - begin) / P, q = ((size_t)o - begin) % P;
+                if (!behind || it != R - 1 || final_of[q] < 0) return false;
+                name[k] = "F" + std::to_string(final_of[q]);
+            }
+        }
+        out = { uop, name[0], uv.r1_pos >= 0 ? name[(size_t)uv.r1_pos] : std::string(), uv.r2_pos >= 0 ? name[(size_t)uv.r2_pos] : std::string(), op_info(nd->opcode).scalar };
+        return true;
+    };
+    for (size_t i = 0; i < begin; ++i) {
+        RolledBody::Op op;
+        if (!make_op(i, false, op)) return false;
+        pl.pre.push_back(op);
+        if (op.scalar) pe.pre_scal.push_back((uint32_t)i);
+        if (g.escapes[i]) { pl.pre_out.push_back((uint32_t)i); pe.pre_out.push_back((uint32_t)i); }
+    }
+    pl.extra_pre = (uint32_t)pe.extra_leaf.size();
+    for (size_t k = 0; k < ro.carried.size(); ++k) pl.carried_init.push_back("p" + std::to_string(begin - P + ro.carried[k]));
+    for (size_t i = end; i < n; ++i) {
+        RolledBody::Op op;
+        if (!make_op(i, true, op)) return false;
+        pl.post.push_back(op);
+        if (op.scalar) pe.post_scal.push_back((uint32_t)i);
+        if (g.escapes[i]) { pl.post_out.push_back((uint32_t)(i - end)); pe.post_out.push_back((uint32_t)i); }
+    }
+    pl.extra_post = (uint32_t)pe.extra_leaf.size() - pl.extra_pre;
+    if (pe.extra_leaf.size() > MAX_EXTRA) return false;
+    // a value of the loop that a later launch used to read (stored every iteration) must not be one the tail needed from an earlier
+    // iteration: make_op has rejected those.  Final values are stored only where somebody outside the component reads them.
+    for (size_t k = 0; k < ro.final_pos.size(); ++k) { const bool esc = g.escapes[begin + (R - 1) * P + ro.final_pos[k]] != 0; pl.final_store.push_back(esc ? 1u : 0u); pe.final_store.push_back(esc ? 1 : 0); }
+    pe.n_pre_scal = (uint32_t)pe.pre_scal.size(); pe.n_post_scal = (uint32_t)pe.post_scal.size(); pe.n_ops = (uint32_t)n;
+    const size_t NX = pe.extra_leaf.size(), G = ro.global_leaf.size(), CO = ro.final_pos.size(), NXO = pe.pre_out.size() + pe.post_out.size(), LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size();
+    pe.row_words = (uint32_t)(NX + G + CO + NXO + R * (LI + LO) + (pe.n_pre_scal + R * LS + pe.n_post_scal + 1) / 2);
+    jit_.record(jit_describe(body));
+    pe.source = jit_generate_rolled_source(body);
+    pe.elems = body.elems;
+    pe.present = true;
+    ro.peeled = std::move(pe);
     return true;
 }
 
@@ -1655,6 +1751,78 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
     for (Node* nd : outs) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
 }
 
+// The whole component of every member of a group as ONE launch of its peeled kernel (plan_peel): row tables by index, launch, commit.
+void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count)
+{
+    const BigPlan::Rolled::Peeled& pe = ro.peeled;
+    const size_t NX = pe.extra_leaf.size(), G = ro.global_leaf.size(), CO = ro.final_pos.size(), NXO = pe.pre_out.size() + pe.post_out.size();
+    const size_t LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size(), NS0 = pe.n_pre_scal, NS2 = pe.n_post_scal;
+    const size_t R = ro.iterations, P = ro.period, rw = pe.row_words;
+    const size_t oG = NX, oCO = oG + G, oXO = oCO + CO, oIT = oXO + NXO;
+    const int64_t n = group[first].n;
+    std::vector<uint64_t> table(count * rw, 0);
+    struct Out { size_t member, pos; Buffer* buf; };
+    std::vector<Out> outs;
+    outs.reserve(count * (R * LO + CO + NXO));
+    auto ptr_of = [](const Buffer* b) -> uint64_t {
+        if (!b) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "peeled loop reads a value that has not been computed");
+        return (uint64_t)(uintptr_t)b->ptr;
+    };
+    try {
+        for (size_t c = 0; c < count; ++c) {
+            BigDag& big = group[first + c];
+            uint64_t* row = table.data() + c * rw;
+            auto fresh = [&](size_t pos) { Buffer* b = new_buffer(n); outs.push_back({ first + c, pos, b }); return (uint64_t)(uintptr_t)b->ptr; };
+            for (size_t k = 0; k < NX; ++k) row[k] = ptr_of(big.leaves[(size_t)pe.extra_leaf[k]]->buf);
+            for (size_t k = 0; k < G; ++k) row[oG + k] = ptr_of(big.leaves[(size_t)ro.global_leaf[k]]->buf);
+            for (size_t k = 0; k < CO; ++k) if (pe.final_store[k]) row[oCO + k] = fresh(ro.begin + (R - 1) * P + ro.final_pos[k]);
+            for (size_t k = 0; k < pe.pre_out.size(); ++k) row[oXO + k] = fresh(pe.pre_out[k]);
+            for (size_t k = 0; k < pe.post_out.size(); ++k) row[oXO + pe.pre_out.size() + k] = fresh(pe.post_out[k]);
+            float* sc = reinterpret_cast<float*>(row + oIT + R * (LI + LO));
+            for (size_t k = 0; k < NS0; ++k) sc[k] = big.scalar_at(pe.pre_scal[k]);
+            for (size_t r = 0; r < R; ++r) {
+                uint64_t* ip = row + oIT + r * (LI + LO);
+                const size_t base = ro.begin + r * P;
+                for (size_t m = 0; m < LI; ++m) ip[m] = ptr_of(big.leaves[(size_t)ro.iter_leaf[r * LI + m]]->buf);
+                for (size_t m = 0; m < LO; ++m) ip[LI + m] = fresh(base + ro.out_pos[m]);
+                for (size_t m = 0; m < LS; ++m) sc[NS0 + r * LS + m] = big.scalar_at(base + ro.scal_pos[m]);
+            }
+            for (size_t k = 0; k < NS2; ++k) sc[NS0 + R * LS + k] = big.scalar_at(pe.post_scal[k]);
+        }
+        if (n > 0) {
+            const int64_t elems_per_pass = (int64_t)FM_BLOCK * pe.jit->elems;
+            const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
+            DevRolledArgs args{};
+            args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = (uint32_t)R;
+            args.dump = (uint64_t)(uintptr_t)dump_dev_;
+            const size_t table_bytes = table.size() * 8;
+            const size_t ring_off = ring_reserve(table_bytes);
+            std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
+            hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "peeled row table H2D");
+            const uint64_t* rows_arg = (const uint64_t*)((char*)ring_dev_ + ring_off);
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
+            void* params[] = { &args, &rows_arg };
+            hip_check(hipModuleLaunchKernel(pe.jit->fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
+            const size_t stored = R * LO + NXO + (size_t)std::count(pe.final_store.begin(), pe.final_store.end(), (char)1);
+            if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                              profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, 0, (int)count, 2, n }); }
+            n_launches_++; n_jit_launches_++; n_rolled_launches_++;
+            n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
+            algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
+        }
+    } catch (...) { for (Out& o : outs) buffer_unref(o.buf); throw; }
+    // commit: every stored value becomes a materialised vector; the rest of the component goes away with their expressions
+    std::vector<Node*> done;
+    done.reserve(outs.size());
+    for (Out& o : outs) {
+        BigDag& big = group[o.member];
+        if (big.described()) commit_described(big, o.pos, o.buf);
+        else { Node* nd = big.order[o.pos]; nd->buf = o.buf; pend_erase(nd); done.push_back(nd); }
+    }
+    for (Node* nd : done) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
+}
+
 // A component shape with a plan, for every member of a group: segment by segment (the rolled stretch as one launch once its kernel
 // exists), ≤ 1024 members per launch.
 void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr) {
@@ -1669,6 +1837,24 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
     if (rolled) {
         const size_t rows_fit = ring_cap_ / ((size_t)plan.rolled.row_words * 8 + 256);
         if (rows_fit == 0) rolled = false; else rolled_batch = std::min(max_batch, rows_fit);
+    }
+    // The peeled form — head, loop and tail of the component in one launch — where a launch costs more than the bytes it moves: few
+    // workgroups (a caller that values one product after the other: 1 row x 489 tiles; three launches of ≈ 9 + 20 + 8 µs become one).
+    // Large batches keep their separate launches: those stream at the HBM ceiling, and the loop kernel keeps its registers.
+    {
+        BigPlan::Rolled::Peeled& pe = plan.rolled.peeled;
+        if (pe.present && jit_mode != FMHIP_JIT_OFF && (!pe.jit || (jit_mode == FMHIP_JIT_SYNC && pe.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
+            pe.jit = jit_.request_source(pe.source, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+        if (pe.present && jit_mode != FMHIP_JIT_OFF && pe.jit && pe.jit->state.load(std::memory_order_acquire) == JitSlot::READY && group[0].n > 0) {
+            static const size_t PEEL_MAX_WORKGROUPS = [] { const char* e = std::getenv("FMHIP_PEEL_MAX_WORKGROUPS"); return e ? (size_t)std::atoll(e) : (size_t)4096; }();
+            const size_t tiles = (size_t)((group[0].n + (int64_t)FM_BLOCK * pe.jit->elems - 1) / ((int64_t)FM_BLOCK * pe.jit->elems));
+            const size_t rows_fit = ring_cap_ / ((size_t)pe.row_words * 8 + 256);
+            if (group.size() * tiles <= PEEL_MAX_WORKGROUPS && rows_fit >= group.size()) {
+                struct TempGuard2 { Engine* e; std::vector<BigDag>& g; ~TempGuard2() { for (BigDag& b : g) if (b.described()) for (Buffer*& t : b.temp) if (t) { e->buffer_unref(t); t = nullptr; } } } guard2{ this, group };
+                run_peeled(plan.rolled, group, 0, group.size());
+                return;
+            }
+        }
     }
     bool any_described = false;
     for (const BigDag& b : group) any_described |= b.described();
@@ -1751,7 +1937,10 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
         for (size_t i = 0; i < n_ops; ++i)
             for (int k = 0; k < group[0].order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(group[0].order[i]->in[k]);
         std::string source; int elems = 0;
-        if (detect_loop(group[0], operand, plan.rolled, &source, &elems)) {
+        RolledBody body;
+        if (detect_loop(group[0], operand, plan.rolled, &source, &elems, &body)) {
+            if (plan_peel(group[0], operand, plan.rolled, body) && jit_mode != FMHIP_JIT_OFF)
+                plan.rolled.peeled.jit = jit_.request_source(plan.rolled.peeled.source, plan.rolled.peeled.elems, jit_mode == FMHIP_JIT_SYNC);
             if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
             plan.rolled.present = true;
             plan.rolled.source = source; plan.rolled.elems = elems;

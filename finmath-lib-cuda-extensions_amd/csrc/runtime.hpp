@@ -288,6 +288,18 @@ private:
             std::vector<uint32_t> carried;                              // positions whose value of the PREVIOUS iteration is read
             std::vector<std::pair<uint32_t, uint32_t>> leaf_in;         // (position, operand) of the first use of each per-iteration input
             std::vector<int32_t> iter_leaf;                             // [iteration][input]: which leaf (index into BigDag::leaves) that is
+            // PEELED form (jit.hpp: RolledBody::Peel): the whole component — the operations in front of the loop, the loop, the ones
+            // behind it — as ONE launch; used for launches of few workgroups, where a launch costs more than the bytes it moves
+            struct Peeled {
+                bool present = false;
+                std::shared_ptr<JitSlot> jit;
+                std::string source; int elems = 0;
+                uint32_t row_words = 0, n_pre_scal = 0, n_post_scal = 0, n_ops = 0;
+                std::vector<int32_t> extra_leaf;                        // leaves read by the operations outside the loop (x0, x1, …)
+                std::vector<uint32_t> pre_out, post_out;                // order positions stored from in front of / behind the loop
+                std::vector<uint32_t> pre_scal, post_scal;              // order positions of the scalar-carrying operations there
+                std::vector<char> final_store;                          // per final value: stored?
+            } peeled;
             std::vector<uint32_t> out_pos, scal_pos;                    // positions stored per iteration; positions with a scalar operand
             std::vector<uint32_t> final_pos;                            // positions whose value of the LAST iteration is stored behind the loop
         } rolled;
@@ -300,8 +312,10 @@ private:
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, Program* prog_red = nullptr);
     void run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
     void commit_described(BigDag& big, size_t pos, Buffer* b);
-    bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems);
+    bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems, RolledBody* body_out = nullptr);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
+    bool plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, const RolledBody& body);
+    void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
     int64_t n_rolled_launches_ = 0;
     // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)
     std::unordered_map<uint32_t, ReplicaGroup*> replicas_;

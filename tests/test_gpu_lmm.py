@@ -158,6 +158,21 @@ def test_caller_without_hints_gets_the_same_numbers():
     assert hinted["kernel_launches"] < 0.5 * grouped["kernel_launches"]
 
 
+def test_row_table_ring_smaller_than_a_rolled_row_table():
+    """FMHIP_RING_BYTES accepts values down to 4 KB; the row table of a rolled launch (iterations x pointers, ≈ 5 KB for the LMM's Euler
+    steps) does not fit such a ring, batched launches need several trips through it: rolled stretches fall back to their segments or
+    take fewer members per launch, ordinary launches split their batch — same numbers, no error."""
+    ensure_built()
+    def evaluate(env):
+        out = subprocess.run([LMM_HIP, "--paths", "20000", "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", "8"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, FMHIP_JIT="sync", **env))
+        assert out.returncode == 0, out.stderr[-3000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    roomy, tight = evaluate({}), evaluate({"FMHIP_RING_BYTES": "4096"})
+    assert tight["model_volatility"] == roomy["model_volatility"]
+    assert tight["kernel_launches"] > roomy["kernel_launches"]
+
+
 def test_brownian_motion_groups_time_steps_for_a_plain_scheme(gpu):
     """Time-step grouping by the engine (fmhip_set_step_grouping; BrownianMotionHip.setGroupSteps forwards to it): an Euler scheme
     written against the interfaces only (montecarlo.py) runs in groups of time steps — same price bit for bit, fewer launches."""

@@ -114,3 +114,58 @@ def test_monte_carlo_time_loop_rolls(gpu):
     finally:
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def swaption_like_chain(x_of, periods, numeraire, strike, delta):
+    """SwaptionSimple's backward induction (host/lmm.hpp: swaptionValue): a short head (the last period has no running value yet), a
+    periodic stretch, a short tail (floor at 0, division by the numeraire)."""
+    value = None
+    for p in range(periods - 1, -1, -1):
+        libor = x_of(p)
+        payoff = libor.v1s1("SUB_S", strike).v1s1("MULT_S", delta)
+        value = (payoff if value is None else value.v2s0("ADD", payoff)).v2s1("DISCOUNT", libor, delta)
+    return value.v1s1("FLOOR_S", 0.0).v2s0("DIV", numeraire)
+
+
+def test_head_loop_and_tail_in_one_launch(gpu, oracle):
+    """The PEELED form of a rolled component (runtime.cpp: plan_peel; jit.hpp: RolledBody::Peel): when the operations in front of the
+    loop and behind it are few, a launch of few workgroups runs the whole component — head, loop, tail — as ONE kernel; the values
+    between the parts stay in registers.  Same bits as the segmented launches (interpreter tier) and as the oracle."""
+    n, periods = 50_021, 40
+    rng = np.random.default_rng(77)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods)]
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    strike, delta = 0.02, 0.5
+    value = None
+    for p in range(periods - 1, -1, -1):
+        payoff = oracle.f_v1s1("MULT_S", oracle.f_v1s1("SUB_S", libors[p], strike), delta)
+        value = oracle.f_v2s1("DISCOUNT", payoff if value is None else oracle.f_v2s0("ADD", value, payoff), libors[p], delta)
+    want = oracle.f_v2s0("DIV", oracle.f_v1s1("FLOOR_S", value, 0.0), num)
+    prev_fusion = gpu.set_fusion(True)
+    try:
+        dev = [gpu.DeviceVector.from_host(x) for x in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+        launches = {}
+        for mode, name in ((gpu.JIT_OFF, "segments"), (gpu.JIT_SYNC, "discovery"), (gpu.JIT_SYNC, "peeled"), (gpu.JIT_SYNC, "peeled again")):
+            prev_jit = gpu.set_jit(mode)
+            if name == "segments":
+                gpu.purge()
+            try:
+                with gpu.holding():
+                    got = swaption_like_chain(lambda p: dev[p], periods, dnum, strike, delta)
+                before = gpu.pool_stats().n_kernel_launches
+                gpu.flush()
+                launches[name] = gpu.pool_stats().n_kernel_launches - before
+                assert_bits_equal(got.to_float32(), want, name)
+            finally:
+                gpu.set_jit(prev_jit)
+        assert launches["segments"] >= 4 and launches["peeled"] == 1 and launches["peeled again"] == 1, launches
+        # … and as rows of one launch for several chains at once, their expectations included
+        with gpu.holding():
+            chains = [swaption_like_chain(lambda p, k=k: dev[(p + k) % periods], periods, dnum, strike + 0.001 * k, delta) for k in range(3)]
+        before = gpu.pool_stats().n_kernel_launches
+        gpu.flush()
+        assert gpu.pool_stats().n_kernel_launches - before == 1
+        assert np.isfinite([c.moments().sum for c in chains]).all()
+    finally:
+        gpu.set_fusion(prev_fusion)
