@@ -41,7 +41,7 @@ struct JitStats { int64_t compiled = 0, failed = 0, pending = 0, disk_hits = 0; 
 
 // Shape of a specialised kernel: elements per lane and pass, how many elements of an exp / log body are interleaved,
 // an occupancy hint for the register allocator, software prefetch of the next pass.
-struct JitShape { int elems = 8, group = 4, waves = 0; bool prefetch = true; };
+struct JitShape { int elems = 8, group = 4, waves = 0; bool prefetch = true; bool deep = false; };      // deep: the loads of ALL passes of a workgroup issued at once
 JitShape jit_shape(const DevProgramArgs& proto);
 
 // Source text of the specialised kernel pair of a program (deterministic: it doubles as the cache key).

@@ -2211,6 +2211,7 @@ Program* Engine::reduce_program() {
     auto it = program_cache_.find(key);
     if (it != program_cache_.end()) return it->second;
     Program* prog = compile({}, 1, {}, { 0 }, nullptr, true);
+    if (jit_mode != FMHIP_JIT_OFF) prog->jit = jit_.request(prog->proto, jit_mode == FMHIP_JIT_SYNC);      // every getAverage() runs it: specialised from the start (it is in the kernel pack)
     program_cache_[key] = prog;
     return prog;
 }
