@@ -23,7 +23,7 @@ def program():
 
 results = []
 p = program()
-for n, B in ((1_000, 1), (1_000, 64), (10_000, 1), (10_000, 64), (100_000, 1), (100_000, 64), (1_000_000, 1), (1_000_000, 8), (1_000_000, 64),
+for n, B in ((1_000, 1), (1_000, 64), (10_000, 1), (10_000, 64), (100_000, 1), (100_000, 64), (1_000_000, 1), (1_000_000, 2), (1_000_000, 4), (1_000_000, 8), (1_000_000, 16), (1_000_000, 64),
              (1 << 20, 64), (1 << 26, 1), (8_000_000, 8)):
     bm = fm.BrownianMotionHip(fm.TimeDiscretization(0.0, B, 1.0), 3, n, 31415)
     rows = []
