@@ -68,7 +68,7 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
 {
     if (pass_full && shift == 0.0) {        // getAverage / first pass of getVariance: no subtraction
         // No per-element NaN test here: Σx² is NaN exactly when some x is NaN (inf² = +inf, and a sum of non-negative
-        // terms cannot produce one otherwise); red_finish() reads that off the accumulator once per workgroup.
+        // terms cannot produce one otherwise); red_unit_end() reads that off the accumulator once per unit.
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const double dv = (double)x[j];
@@ -101,11 +101,102 @@ __device__ __forceinline__ void red_accumulate(const float (&x)[E], const double
     }
 }
 
-// After the last pass of a workgroup: NaN detection of the unshifted fast path (see red_accumulate).  With a shift the
-// accumulator can also be NaN from inf - inf, so those paths keep their per-element test.
-__device__ __forceinline__ void red_finish(const double shift, const double acc_sq, unsigned long long& nan_mask)
+// ---- The tree of a fused reduction.  A vector is cut into UNITS of FM_UNIT_ELEMS = 2048 consecutive elements (256 lanes x two
+// float4, lane l holding the elements 4l…4l+3 of each half) and into SPANS of FM_SPAN_UNITS = 4 consecutive units (more for vectors
+// beyond 2^29 elements: runtime.cpp, launch).  Its moments are, by definition,
+//   lane value   = the lane's 8 elements, accumulated in element order                                (red_accumulate)
+//   unit partial = lanes l, l+64, l+128, l+192 added in this order, then the wave64 DPP tree over l    (red_span_fold)
+//   span partial = its unit partials added in unit order                                             (red_span_fold / wave_sum_span_partials)
+//   row          = span partials, lane l of one wave taking the spans l, l+64, …, then the DPP tree   (block_combine)
+// — a function of the data and of the vector's length, NOT of the launch: a workgroup may take a whole span (the kernels of large
+// launches: fewest partials, fewest arrivals) or a single unit (loop kernels, which keep one tile in registers; small launches, which
+// want four times the workgroups); 4 or 8 elements per lane and pass; either execution tier.  Until round 3 a lane accumulated across
+// the passes of its workgroup first, which tied the value to the workgroup's span; the transposition below — lane values of a unit
+// through LDS, one WAVE per unit instead of one wave per quarter of every unit — costs two LDS stores per unit and lane.
+// LDS: 24 bytes per lane, unit slot and reduction; 4 slots for one reduction, 2 for two (24 KB either way).  The workgroup adds unit
+// partials to its running value one after the other, so how many units it collects before it does so changes nothing.
+template <int NRED> struct RedShared {
+    static constexpr int SLOTS = FM_SPAN_UNITS / NRED >= 1 ? FM_SPAN_UNITS / NRED : 1;
+    f64x2 lane_sums[NRED][SLOTS][FM_BLOCK];         // {Σ, Σ²} of a lane over one unit
+    f32x2 lane_ext[NRED][SLOTS][FM_BLOCK];          // {min, max}
+    f64x2 unit_sums[NRED][SLOTS];
+    f32x2 unit_ext[NRED][SLOTS];
+};
+template <int NRED> __device__ __forceinline__ RedShared<NRED>& red_shared() { __shared__ RedShared<NRED> s; return s; }
+
+// End of a unit: the lane's values go to LDS slot `slot` (the unit's place among those the workgroup is collecting) and the accumulators
+// start again.  NaN: with shift 0 the unmasked path of red_accumulate does not test elements — Σx² of a lane is NaN exactly when
+// one of its x is (inf² = +inf, and a sum of non-negative terms cannot produce one otherwise); the other paths collect a wave-level
+// ballot.  Either way min and max of the lane become NaN here and stay NaN through every jmin / jmax above.
+template <int NRED>
+__device__ __forceinline__ void red_unit_end(double (&acc_sum)[NRED], double (&acc_sq)[NRED], float (&acc_min)[NRED], float (&acc_max)[NRED],
+                                             unsigned long long (&nan_mask)[NRED], const double (&shift)[NRED], const uint32_t slot)
 {
-    if (shift == 0.0) nan_mask |= __ballot(acc_sq != acc_sq);
+    RedShared<NRED>& S = red_shared<NRED>();
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+        const bool nan = nan_mask[r] != 0ull || (shift[r] == 0.0 && acc_sq[r] != acc_sq[r]);
+        const float q = __builtin_nanf("");
+        S.lane_sums[r][slot][threadIdx.x] = f64x2{ acc_sum[r], acc_sq[r] };
+        S.lane_ext[r][slot][threadIdx.x] = f32x2{ nan ? q : acc_min[r], nan ? q : acc_max[r] };
+        acc_sum[r] = 0.0; acc_sq[r] = 0.0; nan_mask[r] = 0ull;
+        acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
+    }
+}
+
+// `units` slots are filled (a span's worth, or what the workgroup has).  Wave w turns slot w into the unit partial; every lane
+// then adds the unit partials, in unit order, to the workgroup's running value wg_* (`first`: it starts with them).  Workgroup-uniform
+// arguments; two barriers.
+template <int NRED>
+__device__ __forceinline__ void red_span_fold(const uint32_t units, const bool first,
+                                              double (&wg_sum)[NRED], double (&wg_sq)[NRED], float (&wg_min)[NRED], float (&wg_max)[NRED])
+{
+    RedShared<NRED>& S = red_shared<NRED>();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (wave < units) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) {
+            f64x2 a[FM_BLOCK / 64]; f32x2 x[FM_BLOCK / 64];
+#pragma unroll
+            for (int k = 0; k < FM_BLOCK / 64; ++k) { a[k] = S.lane_sums[r][wave][lane + 64u * k]; x[k] = S.lane_ext[r][wave][lane + 64u * k]; }
+            double s1 = a[0].x, s2 = a[0].y; float mn = x[0].x, mx = x[0].y;
+#pragma unroll
+            for (int k = 1; k < FM_BLOCK / 64; ++k) { s1 += a[k].x; s2 += a[k].y; mn = jmin(mn, x[k].x); mx = jmax(mx, x[k].y); }
+            wave_reduce(s1, s2, mn, mx);
+            if (lane == 63u) { S.unit_sums[r][wave] = f64x2{ s1, s2 }; S.unit_ext[r][wave] = f32x2{ mn, mx }; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) {
+#pragma unroll
+        for (uint32_t u = 0; u < (uint32_t)RedShared<NRED>::SLOTS; ++u) {
+            if (u < units) {
+                const f64x2 a = S.unit_sums[r][u]; const f32x2 x = S.unit_ext[r][u];
+                if (first && u == 0u) { wg_sum[r] = a.x; wg_sq[r] = a.y; wg_min[r] = x.x; wg_max[r] = x.y; }
+                else { wg_sum[r] += a.x; wg_sq[r] += a.y; wg_min[r] = jmin(wg_min[r], x.x); wg_max[r] = jmax(wg_max[r], x.y); }
+            }
+        }
+    }
+}
+
+// The bookkeeping of the three calls above for a kernel that walks its tiles in order: call after the red_accumulate of every tile.
+// TPU = tiles per unit (1 at 8 elements per lane, 2 at 4); rel = the tile's index within the workgroup's stretch; last = it is the
+// workgroup's last tile.
+template <int NRED, int E>
+__device__ __forceinline__ void red_tile_end(const uint32_t rel, const bool last,
+                                             double (&acc_sum)[NRED], double (&acc_sq)[NRED], float (&acc_min)[NRED], float (&acc_max)[NRED],
+                                             unsigned long long (&nan_mask)[NRED], const double (&shift)[NRED],
+                                             double (&wg_sum)[NRED], double (&wg_sq)[NRED], float (&wg_min)[NRED], float (&wg_max)[NRED])
+{
+    constexpr uint32_t TPU = (uint32_t)(FM_UNIT_ELEMS / (FM_BLOCK * E));
+    static_assert(TPU == 1u || TPU == 2u, "a reduction unit is one pass at 8 elements per lane, two at 4");
+    if ((rel % TPU) != TPU - 1u && !last) return;
+    constexpr uint32_t SLOTS = (uint32_t)RedShared<NRED>::SLOTS;
+    const uint32_t unit = rel / TPU, slot = unit % SLOTS;
+    red_unit_end<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift, slot);
+    if (slot == SLOTS - 1u || last) red_span_fold<NRED>(slot + 1u, unit < SLOTS, wg_sum, wg_sq, wg_min, wg_max);
 }
 
 // FM_HANDOFF_RELEASE: 1 = the arrival counter's add is an agent-scope release (see block_combine); 0 = relaxed behind sc1 stores
@@ -153,56 +244,69 @@ __device__ __forceinline__ void wave_sum_partials(const double* __restrict__ p, 
     wave_reduce(s1, s2, mn, mx);
 }
 
-// Workgroup combine: wave64 DPP reduction, the 4 waves of the workgroup through LDS, one partial per workgroup and reduction:
-// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  Waves 1-3 are finished after the LDS hand-off: the rest — the coherent
-// stores, the wait for them, the arrival counter and its round trip, ≈ 3-4 µs — keeps ONE wave slot of the workgroup busy, not
-// four (measured on the bench launch: see DESIGN.md §4.2).
+// As wave_sum_partials, for a launch whose workgroups take a QUARTER (or half) of a span each: the partials of span k of the group are
+// p[(first + k * stride) * Q + q], q = 0 … Q-1 (as many as the row has: `blocks` workgroups), added in this order before the span
+// joins the lane's sum.  Small launches only (a row of at most a few thousand workgroups): two spans in flight per lane.
+__device__ __forceinline__ void wave_sum_span_partials(const double* __restrict__ p, uint32_t first, uint32_t stride, uint32_t count,
+                                                       uint32_t Q, uint32_t blocks, double& s1, double& s2, float& mn, float& mx)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    s1 = 0.0; s2 = 0.0; mn = __builtin_huge_valf(); mx = -__builtin_huge_valf();
+    for (uint32_t k = lane; k < count; k += 64u) {
+        const uint32_t b0 = (first + k * stride) * Q;
+        double v[FM_SPAN_UNITS][4];
+#pragma unroll
+        for (uint32_t q = 0; q < (uint32_t)FM_SPAN_UNITS; ++q) {
+            const double* src = p + (size_t)((q < Q && b0 + q < blocks) ? b0 + q : b0) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[q][c] = load_coherent(src + c);
+        }
+        double t1 = v[0][0], t2 = v[0][1]; float tn = (float)v[0][2], tx = (float)v[0][3];
+#pragma unroll
+        for (uint32_t q = 1; q < (uint32_t)FM_SPAN_UNITS; ++q)
+            if (q < Q && b0 + q < blocks) { t1 += v[q][0]; t2 += v[q][1]; tn = jmin(tn, (float)v[q][2]); tx = jmax(tx, (float)v[q][3]); }
+        s1 += t1; s2 += t2; mn = jmin(mn, tn); mx = jmax(mx, tx);
+    }
+    wave_reduce(s1, s2, mn, mx);
+}
+
+// Workgroup combine.  wg_* = the workgroup's value (red_span_fold: the same in every lane); one partial per workgroup and reduction:
+// partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  Q = workgroups per span (1: a workgroup took a whole span; 4: one unit each).
+// Waves other than one are finished here: the rest — the coherent stores, the wait for them, the arrival counter and its round
+// trip, ≈ 3-4 µs — keeps ONE wave slot of the workgroup busy, not four (measured on the bench launch: see DESIGN.md §4.2).
 // Arrival counting: device-scope atomics execute at the memory side, ≈ 11-13 ns apiece on one cache line, so a row of
 // thousands of workgroups (one vector of 2^26 paths: 8192) would queue on a single counter for longer than the kernel runs
-// (measured: 128 µs instead of 45).  A row therefore counts in G = combine_groups(gridDim.x) groups (workgroup b belongs to
-// group b mod G; each group counter in a cache line — a plane — of its own: 32 B apart was not enough).  The LAST workgroup
-// of a group adds the group's partials in a fixed order (wave_sum_partials) and, if G > 1, stores the group partial behind
+// (measured: 128 µs instead of 45).  A row therefore counts in G = combine_groups(spans) groups (span s belongs to group
+// s mod G; each group counter in a cache line — a plane — of its own: 32 B apart was not enough).  The LAST workgroup
+// of a group adds the group's span partials in a fixed order (wave_sum_partials) and, if G > 1, stores the group partial behind
 // the row's workgroup partials and moves the second-level counter; the last of those adds the G group partials.  The final
-// moments are a deterministic function of the data and of gridDim.x: no float atomics, no second launch.
+// moments are a deterministic function of the data and of the number of spans: no float atomics, no second launch.
 template <int NRED>
-__device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], const double (&acc_sq)[NRED],
-                                              const float (&acc_min)[NRED], const float (&acc_max)[NRED],
-                                              const unsigned long long (&nan_mask)[NRED],
+__device__ __forceinline__ void block_combine(const double (&wg_sum)[NRED], const double (&wg_sq)[NRED],
+                                              const float (&wg_min)[NRED], const float (&wg_max)[NRED],
                                               double* __restrict__ partials, const uint32_t row,
                                               double* __restrict__ results, uint32_t* __restrict__ counter,       // counter: this row's arrival counter
-                                              uint64_t* done_flag, const uint64_t done_value)                       // see DevProgramArgs::done_flag
+                                              uint64_t* done_flag, const uint64_t done_value,                       // see DevProgramArgs::done_flag
+                                              const uint32_t Q)
 {
-    __shared__ double lds_sum[NRED][FM_BLOCK / 64], lds_sq[NRED][FM_BLOCK / 64];
-    __shared__ float  lds_min[NRED][FM_BLOCK / 64], lds_max[NRED][FM_BLOCK / 64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < NRED; ++r) {
-        double s1 = acc_sum[r], s2 = acc_sq[r];
-        float mn = acc_min[r], mx = acc_max[r];
-        if (nan_mask[r] != 0ull) { mn = __builtin_nanf(""); mx = mn; }      // wave-uniform
-        wave_reduce(s1, s2, mn, mx);
-        if (lane == 63u) { lds_sum[r][wave] = s1; lds_sq[r][wave] = s2; lds_min[r][wave] = mn; lds_max[r][wave] = mx; }
-    }
-    __syncthreads();
     // the wave that stays rotates with the workgroup index: the waves of a workgroup sit on different SIMDs, and a new
     // workgroup needs a free slot on every one of them — lingering waves all on the same SIMD would block it just the same
     if (wave != (blockIdx.x & 3u)) return;
 
     const uint32_t slots = gridDim.x + FM_COMBINE_GROUP_SLOTS;             // per (row, reduction)
-    const uint32_t G = combine_groups(gridDim.x);
-    const uint32_t g = blockIdx.x % G;
-    const uint32_t members = (gridDim.x - g + G - 1u) / G;
+    const uint32_t spans = (gridDim.x + Q - 1u) / Q;
+    const uint32_t G = combine_groups(spans);
+    const uint32_t g = (blockIdx.x / Q) % G;
+    const uint32_t group_spans = (spans - g + G - 1u) / G;
+    // workgroups of the group: Q per span, except that the row's last span may have fewer
+    const uint32_t members = group_spans * Q - (((spans - 1u) % G == g) ? spans * Q - gridDim.x : 0u);
     uint32_t group_last = 0u;
     if (lane == 0u) {
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
-            double s1 = lds_sum[r][0], s2 = lds_sq[r][0];
-            float mn = lds_min[r][0], mx = lds_max[r][0];
-#pragma unroll
-            for (int wv = 1; wv < FM_BLOCK / 64; ++wv) {
-                s1 += lds_sum[r][wv]; s2 += lds_sq[r][wv];
-                mn = jmin(mn, lds_min[r][wv]); mx = jmax(mx, lds_max[r][wv]);
-            }
+            const double s1 = wg_sum[r], s2 = wg_sq[r];
+            const float mn = wg_min[r], mx = wg_max[r];
             double* out = partials + (((size_t)row * NRED + r) * slots + blockIdx.x) * 4;
             store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
         }
@@ -233,7 +337,8 @@ __device__ __forceinline__ void block_combine(const double (&acc_sum)[NRED], con
     for (int r = 0; r < NRED; ++r) {
         double* base = partials + ((size_t)row * NRED + r) * slots * 4;
         double s1, s2; float mn, mx;
-        wave_sum_partials(base, g, G, members, s1, s2, mn, mx);
+        if (Q == 1u) wave_sum_partials(base, g, G, group_spans, s1, s2, mn, mx);
+        else wave_sum_span_partials(base, g, G, group_spans, Q, gridDim.x, s1, s2, mn, mx);
         if (lane == 63u) {
             if (G == 1u) {
                 double* o = results + ((size_t)row * NRED + r) * 4;

@@ -31,6 +31,8 @@ constexpr int FM_MAX_RED  = 2;     // fused reductions per launch
 constexpr int FM_MAX_SCAL = 64;    // scalar operand slots per launch
 constexpr int FM_BLOCK    = 256;   // threads per workgroup (4 waves)
 constexpr int FM_VEC      = 4;     // elements per thread per tile (one 128-bit access per vector)
+constexpr int FM_UNIT_ELEMS = 2048; // a unit of the reduction tree: FM_BLOCK lanes x 8 elements (fm_kernel_parts.hpp)
+constexpr int FM_SPAN_UNITS = 4;    // units per span of the reduction tree
 
 // Micro-ops.  "_A/_B/_T/_P/_N" name which operand of the public opcode sits in the accumulator.
 enum UOp : uint32_t {
@@ -99,6 +101,8 @@ struct DevProgramArgs {
     uint32_t n_scal, row_words;          // row stride in 8-byte words
     uint32_t tiles_per_row, use_inline;  // passes of FM_BLOCK*E elements; use_inline: the row blocks of the whole batch are in inline_row
     uint32_t variant, flags;             // kernel variant (FM_VARIANT_*); FM_ARGS_* bits
+    uint32_t block_tiles, span_blocks;   // passes a workgroup takes (workgroup b: tiles [b·block_tiles, (b+1)·block_tiles)); with reductions: workgroups per
+                                         //   span of the reduction tree (fm_kernel_parts.hpp: 1 = a workgroup takes a whole span, 4 = one unit each)
     int64_t  n;                          // elements per vector
     double*   results;                   // [batch][n_red][4] final {Σ, Σ², min, max} (written by the last workgroup of a row)
     uint32_t* counters;                  // [batch] arrival counters of the fused final combine, zero between launches
@@ -122,7 +126,17 @@ struct DevRolledArgs {
     uint32_t iterations;
     uint32_t pad;
     uint64_t dump;                       // FM_DUMP_BYTES of device memory nobody reads: where lanes past the end of a vector put their stores
+    // kernels with a fused reduction of one of their values (one unit of the reduction tree per workgroup: fm_kernel_parts.hpp), else unused
+    double    shift;                     // subtracted from every element before it is added (getVariance's second pass)
+    double*   partials;                  // [rows][tiles + 8][4]
+    double*   results;                   // [rows][4] final {Σ, Σ², min, max}
+    uint32_t* counters;                  // arrival counters, as DevProgramArgs::counters
+    uint64_t* done_flag;                 // as DevProgramArgs::done_flag
+    uint64_t  done_value;
+    // peeled kernels (launches of few rows): the row table travels here when rows x row_words fits — no in-stream copy in front of the launch
+    uint64_t  inline_row[FM_INLINE_WORDS];
 };
+static_assert(sizeof(DevRolledArgs) <= 4096, "kernel arguments are limited to 4 KB");
 constexpr size_t FM_DUMP_BYTES = (size_t)FM_BLOCK * 16 * 4;      // one float4 per lane and per float4-per-lane of the widest kernel (E = 16)
 static_assert(FM_INLINE_WORDS >= FM_ROW_WORDS_MAX, "one row always fits");
 

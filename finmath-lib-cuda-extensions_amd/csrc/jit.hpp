@@ -79,6 +79,10 @@ struct RolledBody {
         std::vector<std::string> carried_init;
         std::vector<uint32_t> pre_out, post_out;                        // operations (indices into pre / post) whose result is stored
         std::vector<uint32_t> final_store;                              // per final value: 1 = stored (somebody outside the component reads it)
+        // The variant that also takes the moments of one of its values (the component's root: `chain.getAverage()`): "q<i>" = result of
+        // post[i], "F<k>" = final value k; empty = none.  8 elements per lane only: a workgroup's tile is then one unit of the reduction
+        // tree (fm_kernel_parts.hpp), so the moments are those of the stand-alone reduction to the last bit.
+        std::string reduce;
     } peel;
 };
 std::string jit_generate_rolled_source(const RolledBody& body);

@@ -84,13 +84,16 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     const float* __restrict__ scal = reinterpret_cast<const float*>(rowp + n_in + n_out + A.n_red);
     if (A.flags & FM_ARGS_LOG_TABLE) log_table_init();          // wave- and workgroup-uniform
 
-    double acc_sum[NRED > 0 ? NRED : 1], acc_sq[NRED > 0 ? NRED : 1];
-    float  acc_min[NRED > 0 ? NRED : 1], acc_max[NRED > 0 ? NRED : 1];
-    unsigned long long nan_mask[NRED > 0 ? NRED : 1];
+    constexpr int NR = NRED > 0 ? NRED : 1;
+    double acc_sum[NR], acc_sq[NR], wg_sum[NR], wg_sq[NR], shift[NR];
+    float  acc_min[NR], acc_max[NR], wg_min[NR], wg_max[NR];
+    unsigned long long nan_mask[NR];
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
         acc_sum[r] = 0.0; acc_sq[r] = 0.0; nan_mask[r] = 0ull;
         acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
+        wg_sum[r] = 0.0; wg_sq[r] = 0.0; wg_min[r] = acc_min[r]; wg_max[r] = acc_max[r];
+        shift[r] = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
     }
 
     // Virtual register file, one vector per element lane (static indices only).  Deliberately NOT zero-initialised:
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 
     // A.tiles_per_row counts passes of FM_BLOCK*E elements.
     // workgroup b takes the tiles [b·P, (b+1)·P) — the same assignment as the specialised kernels (jit.cpp)
-    const uint32_t tiles_per_block = (A.tiles_per_row + gridDim.x - 1u) / gridDim.x;
+    const uint32_t tiles_per_block = A.block_tiles;
     const uint32_t tile_begin = blockIdx.x * tiles_per_block;
     const uint32_t tile_end = tile_begin + tiles_per_block < A.tiles_per_row ? tile_begin + tiles_per_block : A.tiles_per_row;
     for (uint32_t tile = tile_begin; tile < tile_end; ++tile) {
@@ -202,19 +205,17 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
             const uint32_t reg = A.red_reg[r];
-            const double shift = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
             float x[E];
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = R[j][reg];
-            red_accumulate<E>(x, shift, pass_full, i4, n, acc_sum[r], acc_sq[r], acc_min[r], acc_max[r], nan_mask[r]);
+            red_accumulate<E>(x, shift[r], pass_full, i4, n, acc_sum[r], acc_sq[r], acc_min[r], acc_max[r], nan_mask[r]);
         }
+        // ---- the reduction tree's unit / span bookkeeping (fm_kernel_parts.hpp): lane values through LDS, one wave per unit
+        if constexpr (NRED > 0) red_tile_end<NRED, E>(tile - tile_begin, tile + 1u == tile_end, acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift, wg_sum, wg_sq, wg_min, wg_max);
     }
 
-#pragma unroll
-    for (int r = 0; r < NRED; ++r) red_finish(reinterpret_cast<const double*>(rowp)[n_in + n_out + r], acc_sq[r], nan_mask[r]);
-
-    // ---- workgroup combine: wave64 DPP reduction, then 4 waves through LDS, one partial per workgroup
-    if constexpr (NRED > 0) block_combine<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE, A.done_flag, A.done_value);
+    // ---- one partial per workgroup; the last workgroup of the row adds them
+    if constexpr (NRED > 0) block_combine<NRED>(wg_sum, wg_sq, wg_min, wg_max, partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE, A.done_flag, A.done_value, A.span_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -156,6 +156,7 @@ void Engine::init(int device_index) {
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     hip_check(hipMalloc(&dump_dev_, FM_DUMP_BYTES), "hipMalloc(dump)");
+    { const char* e = std::getenv("FMHIP_UNIT_WORKGROUPS"); unit_workgroups_ = e ? std::atoll(e) : 128; }
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
     hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
@@ -640,8 +641,21 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     const int64_t elems_per_block = ELEMS_PER_BLOCK_ENV ? ELEMS_PER_BLOCK_ENV : ((n_red > 0 || log_table) ? 8192 : 0);      // the variable: for benchmarks/jit_knobs.py
     int64_t passes_per_block = std::max<int64_t>(1, elems_per_block / elems_per_pass);
     if (n_red == 0) while (passes_per_block > 1 && ((tiles + passes_per_block - 1) / passes_per_block) * batch < 4096) passes_per_block /= 2;
-    int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
-    bpr = std::min<int64_t>(std::max<int64_t>(bpr, 1), 65536);
+    int64_t span_blocks = 1;
+    if (n_red > 0) {
+        // The reduction tree (fm_kernel_parts.hpp) is defined on units of 2048 elements and spans of four units — more for vectors of
+        // more than 65536 spans, so that a row never has more workgroups than that.  A workgroup takes a whole span, or, where the
+        // launch would leave most of the chip idle that way (one row of 1 M paths: 123 spans on 256 CUs), a single unit: four times
+        // the workgroups, the same tree, the same moments.
+        const int64_t unit_tiles = std::max<int64_t>(1, FM_UNIT_ELEMS / elems_per_pass);
+        const int64_t units = (n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS;
+        const int64_t span_units = ELEMS_PER_BLOCK_ENV ? std::max<int64_t>(1, ELEMS_PER_BLOCK_ENV / FM_UNIT_ELEMS) : std::max<int64_t>(FM_SPAN_UNITS, (units + 65535) / 65536);
+        if (!ELEMS_PER_BLOCK_ENV && unit_launch(n, batch)) span_blocks = FM_SPAN_UNITS;
+        passes_per_block = span_units / span_blocks * unit_tiles;
+    } else if ((tiles + passes_per_block - 1) / passes_per_block > 65536) passes_per_block = (tiles + 65535) / 65536;
+    const int64_t bpr = (tiles + passes_per_block - 1) / passes_per_block;
+    args.block_tiles = (uint32_t)passes_per_block;
+    args.span_blocks = (uint32_t)span_blocks;
     args.n = n;
     args.tiles_per_row = (uint32_t)tiles;
     const size_t rw = args.row_words;
@@ -679,35 +693,12 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
         }
     }
 
-    void* partials = nullptr; size_t partials_cap = 0;
-    void* results = nullptr;  size_t results_cap = 0;
-    // Results wanted on the host only: the last workgroup of a row stores its 32 bytes straight into the pinned staging buffer
-    // (host memory is mapped into the device's address space) — no device-to-host copy command between the kernel and the wait
-    // (a `chain.getAverage()` through the C++ mirror at 100 / 5 000 paths: 19.6 → 17.7 / 22.9 → 21.2 µs, benchmarks/small_n_latency.cpp).
-    const bool results_on_host = n_red > 0 && host_moments && !dev_moments;
-    if (n_red > 0) {
-        partials = pool_.alloc((size_t)batch * n_red * ((size_t)bpr + 8) * 32, &partials_cap);       // + FM_COMBINE_GROUP_SLOTS group partials per row
-        if (dev_moments) results = dev_moments;
-        else if (results_on_host) { try { results = ensure_stage((size_t)batch * n_red * 32); } catch (...) { pool_.release(partials, partials_cap); throw; } }
-        else { try { results = pool_.alloc((size_t)batch * n_red * 32, &results_cap); } catch (...) { pool_.release(partials, partials_cap); throw; } }
-    }
-    args.results = (double*)results;
+    RedLaunch red;
+    if (n_red > 0) red_begin(red, batch, n_red, (size_t)bpr, host_moments, dev_moments);
+    args.results = (double*)red.results;
     args.counters = counters_dev_;
-    // One row, results wanted on the host (`chain.getAverage()`): the kernel raises a flag in pinned memory behind the results and the
-    // host POLLS it instead of synchronising the stream.  A caller that values one product after the other (finmath-lib's
-    // calibration: 144 getAverage() per objective evaluation) pays the wake-up of hipStreamSynchronize and, measured, a launch
-    // that takes 20–25 µs instead of 5 right after it, once per product.
-    static const bool POLL = [] { const char* e = std::getenv("FMHIP_POLL"); return !(e && e[0] == '0'); }();
-    volatile uint64_t* poll_flag = nullptr;
-    if (POLL && results_on_host && batch == 1) {
-        poll_flag = reinterpret_cast<volatile uint64_t*>((char*)results + (((size_t)n_red * 32 + 63) & ~size_t(63)));      // (ensure_stage hands out at least 1 MB)
-        *poll_flag = 0;
-        args.done_flag = const_cast<uint64_t*>(poll_flag); args.done_value = ++poll_sequence_;
-    } else { args.done_flag = nullptr; args.done_value = 0; }
-    auto cleanup = [&]() {
-        if (partials) pool_.release(partials, partials_cap);
-        if (results && !dev_moments && !results_on_host) pool_.release(results, results_cap);
-    };
+    args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
+    void* const partials = red.partials;
     try {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         if (profiling_) {
@@ -728,28 +719,72 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
                           profile_tags_.push_back({ p->n_ops, p->n_in, p->n_out, n_red, batch, used_jit ? 1 : 0, n }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
         algorithmic_bytes_ += 4 * n * (int64_t)(p->n_in + p->n_out) * batch;
-        if (n_red > 0) {                     // the final combine ran inside the same launch (last workgroup of each row)
-            if (host_moments) {
-                const size_t bytes = (size_t)batch * n_red * 32;
-                void* st = ensure_stage(bytes);
-                if (!results_on_host) hip_check(hipMemcpyAsync(st, results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H");
-                bool arrived = false;
-                if (poll_flag) {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    for (uint32_t spins = 1; !(arrived = *poll_flag == args.done_value); ++spins) {
+        if (n_red > 0) red_wait(red, batch, n_red, host_moments);          // the final combine ran inside the same launch (last workgroup of each row)
+    } catch (...) { red_release(red); throw; }
+    red_release(red);
+}
+
+// The buffers a launch with fused reductions needs, and where its moments go.  Results wanted on the host only: the last workgroup of
+// a row stores its 32 bytes straight into the pinned staging buffer (host memory is mapped into the device's address space) — no
+// device-to-host copy command between the kernel and the wait (a `chain.getAverage()` through the C++ mirror at 100 / 5 000 paths:
+// 19.6 → 17.7 / 22.9 → 21.2 µs, benchmarks/small_n_latency.cpp).  One row, results wanted on the host: the kernel raises a flag in
+// pinned memory behind the results and the host POLLS it instead of synchronising the stream.  A caller that values one product after
+// the other (finmath-lib's calibration: 144 getAverage() per objective evaluation) pays the wake-up of hipStreamSynchronize and,
+// measured, a launch that takes 20–25 µs instead of 5 right after it, once per product.
+// A launch with fused reductions over `batch` rows of n elements gives every workgroup one unit of the reduction tree (instead of a span
+// of four) when it has few spans in all: such a launch has as many workgroups as one without reductions, so a chain over many vectors
+// need not fear it.
+bool Engine::unit_launch(int64_t n, int64_t batch) const
+{
+    const int64_t units = (n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS, spans = (units + FM_SPAN_UNITS - 1) / FM_SPAN_UNITS;
+    return spans <= 65536 && spans * batch <= unit_workgroups_;
+}
+
+void Engine::red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments)
+{
+    red = RedLaunch();
+    red.dev_moments = dev_moments;
+    red.on_host = host_moments && !dev_moments;
+    red.partials = pool_.alloc((size_t)batch * n_red * (blocks_per_row + 8) * 32, &red.partials_cap);       // + FM_COMBINE_GROUP_SLOTS group partials per row
+    try {
+        if (dev_moments) red.results = dev_moments;
+        else if (red.on_host) red.results = ensure_stage((size_t)batch * n_red * 32);
+        else red.results = pool_.alloc((size_t)batch * n_red * 32, &red.results_cap);
+    } catch (...) { pool_.release(red.partials, red.partials_cap); red.partials = nullptr; throw; }
+    static const bool POLL = [] { const char* e = std::getenv("FMHIP_POLL"); return !(e && e[0] == '0'); }();
+    if (POLL && red.on_host && batch == 1) {
+        red.poll_flag = reinterpret_cast<volatile uint64_t*>((char*)red.results + (((size_t)n_red * 32 + 63) & ~size_t(63)));      // (ensure_stage hands out at least 1 MB)
+        *red.poll_flag = 0;
+        red.done_value = ++poll_sequence_;
+    }
+}
+
+void Engine::red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments)
+{
+    if (!host_moments) return;
+    const size_t bytes = (size_t)batch * n_red * 32;
+    void* st = ensure_stage(bytes);
+    if (!red.on_host) hip_check(hipMemcpyAsync(st, red.results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H");
+    bool arrived = false;
+    if (red.poll_flag) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 1; !(arrived = *red.poll_flag == red.done_value); ++spins) {
 #if defined(__x86_64__)
-                        _mm_pause();
+            _mm_pause();
 #endif
-                        if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;      // a long kernel: wait the ordinary way
-                    }
-                    std::atomic_thread_fence(std::memory_order_acquire);
-                }
-                if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
-                std::memcpy(host_moments, st, bytes);
-            }
+            if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;      // a long kernel: wait the ordinary way
         }
-    } catch (...) { cleanup(); throw; }
-    cleanup();
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
+    std::memcpy(host_moments, st, bytes);
+}
+
+void Engine::red_release(RedLaunch& red)
+{
+    if (red.partials) pool_.release(red.partials, red.partials_cap);
+    if (red.results && !red.dev_moments && !red.on_host) pool_.release(red.results, red.results_cap);
+    red.partials = nullptr; red.results = nullptr;
 }
 
 // ---------------------------------------------------------------- lazy front-end
@@ -1678,6 +1713,12 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     pe.source = jit_generate_rolled_source(body);
     pe.elems = body.elems;
     pe.present = true;
+    // the variant that also takes the moments of the component's root (its last operation), for `chain.getAverage()`
+    if (body.elems == 8) {
+        if (n > end) pl.reduce = "q" + std::to_string(n - 1 - end);
+        else if (final_of[(n - 1 - begin) % P] >= 0) pl.reduce = "F" + std::to_string(final_of[(n - 1 - begin) % P]);
+        if (!pl.reduce.empty()) { jit_.record(jit_describe(body)); pe.source_red = jit_generate_rolled_source(body); }
+    }
     ro.peeled = std::move(pe);
     return true;
 }
@@ -1752,7 +1793,7 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 }
 
 // The whole component of every member of a group as ONE launch of its peeled kernel (plan_peel): row tables by index, launch, commit.
-void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count)
+void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr)
 {
     const BigPlan::Rolled::Peeled& pe = ro.peeled;
     const size_t NX = pe.extra_leaf.size(), G = ro.global_leaf.size(), CO = ro.final_pos.size(), NXO = pe.pre_out.size() + pe.post_out.size();
@@ -1796,21 +1837,37 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = (uint32_t)R;
             args.dump = (uint64_t)(uintptr_t)dump_dev_;
             const size_t table_bytes = table.size() * 8;
-            const size_t ring_off = ring_reserve(table_bytes);
-            std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
-            hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "peeled row table H2D");
-            const uint64_t* rows_arg = (const uint64_t*)((char*)ring_dev_ + ring_off);
+            const bool inline_rows = table.size() <= (size_t)FM_INLINE_WORDS;      // few rows: the table travels in the kernel arguments
+            const uint64_t* rows_arg = nullptr;
+            if (inline_rows) std::memcpy(args.inline_row, table.data(), table_bytes);
+            else {
+                const size_t ring_off = ring_reserve(table_bytes);
+                std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
+                hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "peeled row table H2D");
+                rows_arg = (const uint64_t*)((char*)ring_dev_ + ring_off);
+            }
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
             void* params[] = { &args, &rows_arg };
-            hip_check(hipModuleLaunchKernel(pe.jit->fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
-            const size_t stored = R * LO + NXO + (size_t)std::count(pe.final_store.begin(), pe.final_store.end(), (char)1);
-            if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
-                              profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, 0, (int)count, 2, n }); }
-            n_launches_++; n_jit_launches_++; n_rolled_launches_++;
-            n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
-            algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
-        }
+            RedLaunch red;
+            if (rr) {                           // (one row; the kernel with the fused reduction of the root)
+                red_begin(red, 1, 1, (size_t)tiles, rr->host_out, rr->dev_out);
+                args.shift = rr->shift; args.partials = (double*)red.partials; args.results = (double*)red.results; args.counters = counters_dev_;
+                args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
+            }
+            try {
+                const JitSlot& slot = rr ? *pe.jit_red : *pe.jit;
+                hip_check(hipModuleLaunchKernel(inline_rows ? slot.fn_inline : slot.fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
+                const size_t stored = R * LO + NXO + (size_t)std::count(pe.final_store.begin(), pe.final_store.end(), (char)1);
+                if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                                  profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, rr ? 1 : 0, (int)count, 2, n }); }
+                n_launches_++; n_jit_launches_++; n_rolled_launches_++;
+                n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
+                algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
+                if (rr) { red_wait(red, 1, 1, rr->host_out); rr->done = true; }
+            } catch (...) { red_release(red); throw; }
+            red_release(red);
+        } else if (rr) rr = nullptr;
     } catch (...) { for (Out& o : outs) buffer_unref(o.buf); throw; }
     // commit: every stored value becomes a materialised vector; the rest of the component goes away with their expressions
     std::vector<Node*> done;
@@ -1851,7 +1908,16 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
             const size_t rows_fit = ring_cap_ / ((size_t)pe.row_words * 8 + 256);
             if (group.size() * tiles <= PEEL_MAX_WORKGROUPS && rows_fit >= group.size()) {
                 struct TempGuard2 { Engine* e; std::vector<BigDag>& g; ~TempGuard2() { for (BigDag& b : g) if (b.described()) for (Buffer*& t : b.temp) if (t) { e->buffer_unref(t); t = nullptr; } } } guard2{ this, group };
-                run_peeled(plan.rolled, group, 0, group.size());
+                // `chain.getAverage()` on the component's root: the same launch takes the moments (a workgroup's tile is one unit of the
+                // reduction tree) — a product of a caller that values one after the other is ONE launch, and its value is not read again
+                ReduceRequest* fused = nullptr;
+                if (rr && group.size() == 1 && !group[0].described() && !pe.source_red.empty() && group[0].order.back() == group[0].roots[0] &&
+                    tiles <= (size_t)FM_SPAN_UNITS * 65536) {
+                    if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
+                        pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+                    if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) fused = rr;
+                }
+                run_peeled(plan.rolled, group, 0, group.size(), fused);
                 return;
             }
         }
@@ -1881,7 +1947,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
         // (the size gate of reduce(): a launch with a fused reduction has one workgroup per 8192 elements of a row — fine for a segment
         // over two input vectors, a starved launch for one over eleven)
         if (!(rolled && last.zone == 1) && !last.no_red && !last.ssa.empty() && k_root < last.out.size() && group[0].order[(size_t)root_pos] == group[0].roots[0] &&
-            group[0].n * (int64_t)last.n_in <= (int64_t(1) << 21)) {
+            (group[0].n * (int64_t)last.n_in <= (int64_t(1) << 21) || unit_launch(group[0].n, 1))) {
             if (!last.prog_red) {
                 try { last.prog_red = compile(last.ssa, last.n_in, last.out_ids, { last.out_ids[k_root] }, nullptr, false); }
                 catch (const Error& e) { if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw; last.no_red = true; }
@@ -2228,7 +2294,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
         expand_replicas_below({ nd });
         std::vector<Dag> one(1);
-        if (fusion && build_dag({ nd }, one[0]) && nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) && run_dags(one, &shift, host_out, dev_out)) return;
+        if (fusion && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) return;
         // … and of one that takes several launches, in the LAST of them (when its plan exists: from the second time a shape is seen)
         if (fusion && !nd->buf && nd->n > 0) {
             std::vector<BigDag> big(1);

@@ -171,6 +171,10 @@ public:
     fmhip_gather_fn comm_gather = nullptr;
     void* comm_context = nullptr;
     int group_steps = 2;
+    // Launches with a fused reduction of at most this many spans in all give every workgroup one UNIT of the reduction tree instead of a
+    // span (runtime.cpp: launch); FMHIP_UNIT_WORKGROUPS.
+    int64_t unit_workgroups_ = 128;
+    bool unit_launch(int64_t n, int64_t batch) const;
     void end_step_group() { group_hold_ = false; group_steps_pending_ = 0; }      // a value is read, or the caller flushes: whatever was being grouped has run
     void flush_all();
     void materialize(const std::vector<Node*>& targets);
@@ -299,6 +303,8 @@ private:
                 std::vector<uint32_t> pre_out, post_out;                // order positions stored from in front of / behind the loop
                 std::vector<uint32_t> pre_scal, post_scal;              // order positions of the scalar-carrying operations there
                 std::vector<char> final_store;                          // per final value: stored?
+                // the variant that also takes the moments of the component's root (RolledBody::Peel::reduce); compiled when first asked for
+                std::string source_red; std::shared_ptr<JitSlot> jit_red;
             } peeled;
             std::vector<uint32_t> out_pos, scal_pos;                    // positions stored per iteration; positions with a scalar operand
             std::vector<uint32_t> final_pos;                            // positions whose value of the LAST iteration is stored behind the loop
@@ -308,6 +314,12 @@ private:
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
     struct ReduceRequest { double shift; fmhip_moments* host_out; void* dev_out; bool done; };
+    // what a launch with fused reductions holds while it runs (runtime.cpp: red_begin / red_wait / red_release)
+    struct RedLaunch { void* partials = nullptr; size_t partials_cap = 0; void* results = nullptr; size_t results_cap = 0; void* dev_moments = nullptr;
+                       bool on_host = false; volatile uint64_t* poll_flag = nullptr; uint64_t done_value = 0; };
+    void red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments);
+    void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);
+    void red_release(RedLaunch& red);
     void run_big_group(std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, Program* prog_red = nullptr);
     void run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
@@ -315,7 +327,7 @@ private:
     bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems, RolledBody* body_out = nullptr);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
     bool plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, const RolledBody& body);
-    void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
+    void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr);
     int64_t n_rolled_launches_ = 0;
     // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)
     std::unordered_map<uint32_t, ReplicaGroup*> replicas_;

@@ -278,3 +278,38 @@ def test_kernel_pack_serves_a_cold_machine(tmp_path):
     q = json.loads(off.stdout.strip().splitlines()[-1])
     assert q["specialisations_from_disk_cache"] == 0
     assert q["model_volatility"] == r["model_volatility"]                                          # same kernels either way
+
+
+def test_moments_do_not_depend_on_the_shape_of_the_launch(gpu, oracle):
+    """The reduction tree (fm_kernel_parts.hpp) is a function of the data and of the vector's length: a launch of few rows gives every
+    workgroup ONE unit of it (runtime.cpp: unit_launch — four times the workgroups), a launch of many rows a span of four units; both
+    tiers, 4 or 8 elements per lane.  Outputs and moments of a row must not depend on which launch computed it."""
+    import importlib
+    fusion = importlib.import_module("test_gpu_fusion")
+    for n in (100_003, 2048 * 4 * 3 + 1, 2047):
+        many = 1 + (128 * 8192 + n - 1) // n                 # rows x spans > 128: the launch over all rows takes whole spans
+        rows = [[gpu.DeviceVector.from_host(a) for a in fusion.inputs(oracle, n, k % 5)] for k in range(min(many, 40))]
+        rows = [rows[k % len(rows)] for k in range(many)]
+        results = {}
+        for tier in (gpu.JIT_OFF, gpu.JIT_SYNC):
+            prev = gpu.set_jit(tier)
+            try:
+                for name, p in (("stream S", fusion.stream_s_program(gpu)), ("4 elements per lane", four_per_lane_program(gpu))):
+                    single, m1 = p.run([rows[3]])
+                    batch, mb = p.run(rows)
+                    results[tier, name] = (single[0][0].to_float32().view(np.uint32), m1[0].tobytes(), batch[3][0].to_float32().view(np.uint32), mb[3].tobytes())
+            finally:
+                gpu.set_jit(prev)
+        for (tier, name), r in results.items():
+            ref = results[gpu.JIT_OFF, name]
+            assert (r[0] == ref[0]).all() and (r[2] == ref[0]).all(), (n, tier, name)
+            assert r[1] == ref[1] and r[3] == ref[1], (n, tier, name)
+
+
+def four_per_lane_program(gpu):
+    """pow calls out-of-line library code: such programs run 4 elements per lane (a unit of the reduction tree is two of their passes)."""
+    p = gpu.Program(3)
+    w = p.op("MULT", p.op("POW_S", p.op("ADD_S", p.op("ABS", 0), s=1.0), s=1.5), 1)
+    v = p.op("SUB", w, 2)
+    p.output(v); p.reduce(v); p.reduce(w)
+    return p.compile()

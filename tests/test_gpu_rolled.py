@@ -169,3 +169,42 @@ def test_head_loop_and_tail_in_one_launch(gpu, oracle):
         assert np.isfinite([c.moments().sum for c in chains]).all()
     finally:
         gpu.set_fusion(prev_fusion)
+
+
+@pytest.mark.parametrize("n", [50_021, 1_000_000, 2049])
+def test_expectation_in_the_launch_of_the_peeled_chain(gpu, oracle, n):
+    """`chain.getAverage()` on a pending component with a peeled form: the launch that computes the chain also takes its moments (jit.hpp:
+    RolledBody::Peel::reduce) — ONE launch per product for a caller that values one after the other.  A workgroup of that kernel holds
+    one unit of the reduction tree (fm_kernel_parts.hpp), the stand-alone reduction a span of four: the tree is the same, so the moments
+    are the same to the last bit, shifted (getVariance's second pass) or not; and so is the stored value."""
+    periods = 24
+    rng = np.random.default_rng(n)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods)]
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    strike, delta = 0.02, 0.5
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        dev = [gpu.DeviceVector.from_host(x) for x in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+
+        def chain():
+            with gpu.holding():
+                return swaption_like_chain(lambda p: dev[p], periods, dnum, strike, delta)
+        first = chain()
+        gpu.flush()                                       # discovery: the plan and its kernels exist from here on
+        plain = chain()
+        gpu.flush()
+        want = plain.moments()                            # the stand-alone reduction of the materialised value
+        want_shifted = plain.moments(shift=want.sum / n)
+        for shift, ref in ((0.0, want), (want.sum / n, want_shifted)):
+            c = chain()
+            before = gpu.pool_stats().n_kernel_launches
+            got = c.moments(shift=shift)
+            assert gpu.pool_stats().n_kernel_launches - before == 1, "chain and expectation are one launch"
+            for f in ("sum", "sumsq", "min", "max"):
+                assert np.float64(getattr(got, f)).tobytes() == np.float64(getattr(ref, f)).tobytes(), (f, shift, getattr(got, f), getattr(ref, f))
+            assert_bits_equal(c.to_float32(), plain.to_float32(), "the value the fused launch stored")
+        del first
+    finally:
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)

@@ -123,7 +123,7 @@ def test_cross_workgroup_hand_off_in_the_machine_code(tmp_path):
     text = out.read_text()
     for kernel in ("fm_jit_inline", "fm_jit_table"):
         body = text[text.index(kernel + ":"):]
-        body = body[:body.index("s_endpgm")]
+        body = body[:body.index(".Lfunc_end")]                         # (the kernel has several exits: waves that are done leave early)
         ins = [ln.strip() for ln in body.splitlines() if re.match(r"\s+[a-z]", ln)]
         adds = [i for i, x in enumerate(ins) if x.startswith("global_atomic_add")]
         assert len(adds) == 2, (kernel, len(adds))                      # the group counter and the second-level counter
