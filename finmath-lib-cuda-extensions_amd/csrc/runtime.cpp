@@ -719,7 +719,14 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
                           profile_tags_.push_back({ p->n_ops, p->n_in, p->n_out, n_red, batch, used_jit ? 1 : 0, n }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
         algorithmic_bytes_ += 4 * n * (int64_t)(p->n_in + p->n_out) * batch;
-        if (n_red > 0) red_wait(red, batch, n_red, host_moments);          // the final combine ran inside the same launch (last workgroup of each row)
+        if (n_red > 0) {                     // the final combine ran inside the same launch (last workgroup of each row)
+            if (defer_red_ && !defer_red_->pending && host_moments && red.on_host) {
+                red.pending = true; red.batch = batch; red.n_red = n_red; red.host = host_moments;
+                *defer_red_ = red;              // reduce() waits and releases
+                return;
+            }
+            red_wait(red, batch, n_red, host_moments);
+        }
     } catch (...) { red_release(red); throw; }
     red_release(red);
 }
@@ -1864,7 +1871,13 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
                 n_launches_++; n_jit_launches_++; n_rolled_launches_++;
                 n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
                 algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
-                if (rr) { red_wait(red, 1, 1, rr->host_out); rr->done = true; }
+                if (rr) {
+                    rr->done = true;
+                    if (defer_red_ && !defer_red_->pending && rr->host_out && red.on_host) {
+                        red.pending = true; red.batch = 1; red.n_red = 1; red.host = rr->host_out;
+                        *defer_red_ = red; red = RedLaunch();      // reduce() waits and releases
+                    } else red_wait(red, 1, 1, rr->host_out);
+                }
             } catch (...) { red_release(red); throw; }
             red_release(red);
         } else if (rr) rr = nullptr;
@@ -2287,6 +2300,13 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     end_step_group();
     Node* nd = node(h);
     if (!nd->buf) {
+        RedLaunch deferred;
+        struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
+            Engine* e; RedLaunch* r;
+            Defer(Engine* e_, RedLaunch* r_) : e(e_), r(r_) { e->defer_red_ = r; }
+            ~Defer() { e->defer_red_ = nullptr; if (r->pending) { r->pending = false; (void)hipStreamSynchronize(e->stream_); e->red_release(*r); } }      // (an error behind the launch: its buffers go back when it has finished)
+            void finish() { e->defer_red_ = nullptr; if (r->pending) { e->red_wait(*r, r->batch, r->n_red, r->host); r->pending = false; e->red_release(*r); } }
+        } defer(this, &deferred);
         // `chain.getAverage()`: the expectation of a pending expression that fits one launch is taken in THAT launch (the kernel's
         // fused reduction) instead of a second launch that reads the vector again — one launch and 4 B per path less
         // Only while the launch is small: a launch with a fused reduction has ONE workgroup per 8192 elements of a row (the span
@@ -2294,16 +2314,17 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
         expand_replicas_below({ nd });
         std::vector<Dag> one(1);
-        if (fusion && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) return;
+        if (fusion && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) { defer.finish(); return; }
         // … and of one that takes several launches, in the LAST of them (when its plan exists: from the second time a shape is seen)
         if (fusion && !nd->buf && nd->n > 0) {
             std::vector<BigDag> big(1);
             if (build_big({ nd }, big[0])) {
                 ReduceRequest rr{ shift, host_out, dev_out, false };
                 run_big_group(big, &rr);
-                if (rr.done) return;
+                if (rr.done) { defer.finish(); return; }
             }
         }
+        defer.finish();
         if (!nd->buf) materialize({ nd });
     }
     Program* prog = reduce_program();

@@ -316,7 +316,11 @@ private:
     struct ReduceRequest { double shift; fmhip_moments* host_out; void* dev_out; bool done; };
     // what a launch with fused reductions holds while it runs (runtime.cpp: red_begin / red_wait / red_release)
     struct RedLaunch { void* partials = nullptr; size_t partials_cap = 0; void* results = nullptr; size_t results_cap = 0; void* dev_moments = nullptr;
-                       bool on_host = false; volatile uint64_t* poll_flag = nullptr; uint64_t done_value = 0; };
+                       bool on_host = false; volatile uint64_t* poll_flag = nullptr; uint64_t done_value = 0;
+                       bool pending = false; int batch = 0, n_red = 0; fmhip_moments* host = nullptr; };       // pending: launched, not yet waited for (defer_red_)
+    // reduce() of a pending expression: the launch that takes the moments leaves its wait to reduce() — the bookkeeping behind the launch
+    // (outputs become vectors, expressions are dismantled) happens while the device works, not after it
+    RedLaunch* defer_red_ = nullptr;
     void red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments);
     void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);
     void red_release(RedLaunch& red);
