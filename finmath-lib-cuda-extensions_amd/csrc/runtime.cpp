@@ -2314,7 +2314,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
         expand_replicas_below({ nd });
         std::vector<Dag> one(1);
-        if (fusion && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) { defer.finish(); return; }
+        if (fusion && nd->weight <= 4 * FM_MAX_OPS && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) { defer.finish(); return; }
         // … and of one that takes several launches, in the LAST of them (when its plan exists: from the second time a shape is seen)
         if (fusion && !nd->buf && nd->n > 0) {
             std::vector<BigDag> big(1);
