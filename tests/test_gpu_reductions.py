@@ -122,3 +122,61 @@ def test_hand_off_with_warm_caches_and_many_workgroups_per_cu(gpu, oracle):
                     assert m[r][2] == want[s][r][2] and m[r][3] == want[s][r][3], (tier, s, r)
         finally:
             gpu.set_jit(prev)
+
+
+def test_special_values_in_both_launch_shapes_and_inside_a_loop_kernel(gpu, oracle):
+    """NaN, ±inf, −0 anywhere in a vector: the moments of the twin's loops whatever computes them — a unit-shaped launch (few rows), a
+    span-shaped one (many rows: 600 spans > 128), shifted or not, both tiers, and the fused expectation of a peeled chain."""
+    import importlib
+    rolled = importlib.import_module("test_gpu_rolled")
+    n = 70_001                                              # 9 spans; the last unit is ragged
+    base = oracle.f_from_double(oracle.java_random_doubles(5, n) - 0.5)
+    specials = {"nan in the last unit": (n - 3, np.nan), "nan in lane 0": (0, np.nan), "+inf": (2048 * 5 + 17, np.inf), "-inf": (8191, -np.inf),
+                "-0 among zeros": None}
+    for name, where in specials.items():
+        x = base.copy()
+        if where is None:
+            x[:] = 0.0; x[4097] = -0.0
+        else:
+            x[where[0]] = where[1]
+        want_min, want_max = oracle.f_min(x), oracle.f_max(x)
+        v = dv(gpu, x)
+        for tier in (gpu.JIT_OFF, gpu.JIT_SYNC):
+            prev = gpu.set_jit(tier)
+            try:
+                few = v.moments()
+                import ctypes as C
+                handles = (C.c_int64 * 70)(*[v.handle] * 70)
+                out = (gpu.Moments * 70)()
+                gpu._native.check(gpu.lib().fmhip_reduce_moments_batch(handles, 70, None, out))
+                many = out[33]
+                with np.errstate(invalid="ignore"):
+                    want_sum = np.sum(x.astype(np.float64))
+                for m in (few, many):
+                    assert np.float64(m.sum).tobytes() == np.float64(few.sum).tobytes() and np.float64(m.sumsq).tobytes() == np.float64(few.sumsq).tobytes(), (name, tier)
+                    assert (math.isnan(m.sum) and math.isnan(want_sum)) or m.sum == want_sum or abs(m.sum - want_sum) <= 1e-13 * np.sum(np.abs(x.astype(np.float64))), (name, tier)
+                    for got, want in ((m.min, want_min), (m.max, want_max)):
+                        assert (math.isnan(got) and math.isnan(want)) or (got == want and math.copysign(1, got) == math.copysign(1, want)), (name, tier, got, want)
+            finally:
+                gpu.set_jit(prev)
+    # … and through the fused expectation of a peeled chain: a NaN in one period's rate makes the product's value NaN on that path
+    periods, strike, delta = 24, 0.02, 0.5
+    rng = np.random.default_rng(9)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods)]
+    libors[7][n - 1] = np.nan
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        dev = [gpu.DeviceVector.from_host(a) for a in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+        results = []
+        for _ in range(3):                                   # discovery, then the peeled kernel with its reduction
+            with gpu.holding():
+                c = rolled.swaption_like_chain(lambda p: dev[p], periods, dnum, strike, delta)
+            results.append((c.moments(), c.to_float32()))
+        for m, values in results:
+            assert math.isnan(m.sum) and math.isnan(m.sumsq) and math.isnan(m.min) and math.isnan(m.max)
+            assert np.isnan(values[n - 1]) and np.isfinite(values[: n - 1]).all()
+    finally:
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)
