@@ -183,8 +183,18 @@ int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int coun
     });
 }
 
+// The one call of a caller that values product after product: the engine lock is held for the bookkeeping (graph → launch → commit),
+// NOT while the device computes — other threads record and launch meanwhile.  The moments arrive in a slot of pinned memory of their
+// own; this thread polls its flag, then takes the lock again to copy them out and give the launch's buffers back.
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
-    return guarded([&] { need(out, "out"); Engine& e = Engine::get(); e.reduce(v, shift, out, nullptr); exchange_moments(e, out, 1); });
+    Engine::RedLaunch pending;
+    int rc = guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr, &pending); });
+    if (rc == FMHIP_OK && pending.pending) {
+        const bool arrived = Engine::red_poll(pending);
+        rc = guarded([&] { Engine::get().red_complete(pending, arrived); });
+    }
+    if (rc == FMHIP_OK) rc = guarded([&] { exchange_moments(Engine::get(), out, 1); });
+    return rc;
 }
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
     return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine& e = Engine::get(); e.reduce_batch(vectors, count, shifts, out, nullptr); exchange_moments(e, out, count); });

@@ -156,6 +156,9 @@ void Engine::init(int device_index) {
     hip_check(hipHostMalloc(&ring_host_, ring_cap_, hipHostMallocDefault), "hipHostMalloc(ring)");
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     hip_check(hipMalloc(&dump_dev_, FM_DUMP_BYTES), "hipMalloc(dump)");
+    hip_check(hipHostMalloc((void**)&result_slots_, (size_t)RESULT_SLOTS * 128, hipHostMallocDefault), "hipHostMalloc(result slots)");
+    free_slots_.clear();
+    for (int i = RESULT_SLOTS; i-- > 0;) free_slots_.push_back(i);
     { const char* e = std::getenv("FMHIP_UNIT_WORKGROUPS"); unit_workgroups_ = e ? std::atoll(e) : 128; }
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
     hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
@@ -203,6 +206,8 @@ void Engine::shutdown() {
     pool_.purge();
     pool_ = Pool();
     if (stage_) (void)hipHostFree(stage_);
+    if (result_slots_) (void)hipHostFree(result_slots_);
+    result_slots_ = nullptr; free_slots_.clear();
     if (ring_host_) (void)hipHostFree(ring_host_);
     if (ring_dev_) (void)hipFree(ring_dev_);
     if (counters_dev_) (void)hipFree(counters_dev_);
@@ -753,45 +758,65 @@ void Engine::red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_r
     red.dev_moments = dev_moments;
     red.on_host = host_moments && !dev_moments;
     red.partials = pool_.alloc((size_t)batch * n_red * (blocks_per_row + 8) * 32, &red.partials_cap);       // + FM_COMBINE_GROUP_SLOTS group partials per row
+    static const bool POLL = [] { const char* e = std::getenv("FMHIP_POLL"); return !(e && e[0] == '0'); }();
     try {
         if (dev_moments) red.results = dev_moments;
+        else if (red.on_host && POLL && batch == 1 && n_red <= 2 && !free_slots_.empty()) {       // a slot of its own: results [0, 64), flag at 64
+            red.slot = free_slots_.back(); free_slots_.pop_back();
+            red.results = result_slots_ + (size_t)red.slot * 128;
+        }
         else if (red.on_host) red.results = ensure_stage((size_t)batch * n_red * 32);
         else red.results = pool_.alloc((size_t)batch * n_red * 32, &red.results_cap);
     } catch (...) { pool_.release(red.partials, red.partials_cap); red.partials = nullptr; throw; }
-    static const bool POLL = [] { const char* e = std::getenv("FMHIP_POLL"); return !(e && e[0] == '0'); }();
-    if (POLL && red.on_host && batch == 1) {
-        red.poll_flag = reinterpret_cast<volatile uint64_t*>((char*)red.results + (((size_t)n_red * 32 + 63) & ~size_t(63)));      // (ensure_stage hands out at least 1 MB)
+    if (red.slot >= 0) {
+        red.poll_flag = reinterpret_cast<volatile uint64_t*>((char*)red.results + 64);
         *red.poll_flag = 0;
         red.done_value = ++poll_sequence_;
     }
+}
+
+bool Engine::red_poll(const RedLaunch& red)
+{
+    if (!red.poll_flag) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool arrived = false;
+    for (uint32_t spins = 1; !(arrived = *red.poll_flag == red.done_value); ++spins) {
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+        if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;      // a long kernel: wait the ordinary way
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return arrived;
+}
+
+void Engine::red_complete(RedLaunch& red, bool arrived)
+{
+    if (!red.pending) return;
+    red.pending = false;
+    try {
+        if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
+        std::memcpy(red.host, red.results, (size_t)red.batch * red.n_red * 32);
+    } catch (...) { red_release(red); throw; }
+    red_release(red);
 }
 
 void Engine::red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments)
 {
     if (!host_moments) return;
     const size_t bytes = (size_t)batch * n_red * 32;
-    void* st = ensure_stage(bytes);
-    if (!red.on_host) hip_check(hipMemcpyAsync(st, red.results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H");
-    bool arrived = false;
-    if (red.poll_flag) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 1; !(arrived = *red.poll_flag == red.done_value); ++spins) {
-#if defined(__x86_64__)
-            _mm_pause();
-#endif
-            if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;      // a long kernel: wait the ordinary way
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
-    std::memcpy(host_moments, st, bytes);
+    void* src = red.results;
+    if (!red.on_host) { src = ensure_stage(bytes); hip_check(hipMemcpyAsync(src, red.results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H"); }
+    if (!red_poll(red)) hip_check(hipStreamSynchronize(stream_), "moments sync");
+    std::memcpy(host_moments, src, bytes);
 }
 
 void Engine::red_release(RedLaunch& red)
 {
     if (red.partials) pool_.release(red.partials, red.partials_cap);
     if (red.results && !red.dev_moments && !red.on_host) pool_.release(red.results, red.results_cap);
-    red.partials = nullptr; red.results = nullptr;
+    if (red.slot >= 0) { free_slots_.push_back(red.slot); red.slot = -1; }
+    red.partials = nullptr; red.results = nullptr; red.poll_flag = nullptr;
 }
 
 // ---------------------------------------------------------------- lazy front-end
@@ -2325,23 +2350,28 @@ Program* Engine::reduce_program() {
     return prog;
 }
 
-void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out) {
+void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out, RedLaunch* hand_over) {
     require_init();
     end_step_group();
     Node* nd = node(h);
+    RedLaunch deferred;
+    struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
+        Engine* e; RedLaunch* r; RedLaunch* hand_over;
+        Defer(Engine* e_, RedLaunch* r_, RedLaunch* h_) : e(e_), r(r_), hand_over(h_) { e->defer_red_ = r; }
+        ~Defer() { e->defer_red_ = nullptr; if (r->pending) { r->pending = false; (void)hipStreamSynchronize(e->stream_); e->red_release(*r); } }      // (an error behind the launch: its buffers go back when it has finished)
+        // the moments: waited for here, or — results in a slot of their own, a caller that can wait without the engine lock — by the caller
+        void finish() {
+            e->defer_red_ = nullptr;
+            if (!r->pending) return;
+            if (hand_over && r->slot >= 0) { *hand_over = *r; r->pending = false; return; }
+            e->red_wait(*r, r->batch, r->n_red, r->host); r->pending = false; e->red_release(*r);
+        }
+    } defer(this, &deferred, hand_over);
     if (!nd->buf) {
-        RedLaunch deferred;
-        struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
-            Engine* e; RedLaunch* r;
-            Defer(Engine* e_, RedLaunch* r_) : e(e_), r(r_) { e->defer_red_ = r; }
-            ~Defer() { e->defer_red_ = nullptr; if (r->pending) { r->pending = false; (void)hipStreamSynchronize(e->stream_); e->red_release(*r); } }      // (an error behind the launch: its buffers go back when it has finished)
-            void finish() { e->defer_red_ = nullptr; if (r->pending) { e->red_wait(*r, r->batch, r->n_red, r->host); r->pending = false; e->red_release(*r); } }
-        } defer(this, &deferred);
         // `chain.getAverage()`: the expectation of a pending expression that fits one launch is taken in THAT launch (the kernel's
-        // fused reduction) instead of a second launch that reads the vector again — one launch and 4 B per path less
-        // Only while the launch is small: a launch with a fused reduction has ONE workgroup per 8192 elements of a row (the span
-        // fixes the order of the partial sums, §4.1) — a single row of 1 M paths is 122 workgroups on 256 CUs, fine for one
-        // input vector (8 MB) but 115 µs instead of 25 for a chain over eleven.
+        // fused reduction) instead of a second launch that reads the vector again — one launch and 4 B per path less.  A launch with a
+        // fused reduction of a large row has one workgroup per 8192 elements (fine for a chain over two vectors, a starved launch for one
+        // over eleven) unless it is small enough to take one UNIT of the reduction tree per workgroup (unit_launch).
         expand_replicas_below({ nd });
         std::vector<Dag> one(1);
         if (fusion && nd->weight <= 4 * FM_MAX_OPS && build_dag({ nd }, one[0]) && (nd->n * (int64_t)one[0].leaves.size() <= (int64_t(1) << 21) || unit_launch(nd->n, 1)) && run_dags(one, &shift, host_out, dev_out)) { defer.finish(); return; }
@@ -2355,6 +2385,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
             }
         }
         defer.finish();
+        defer_red_ = &deferred;
         if (!nd->buf) materialize({ nd });
     }
     Program* prog = reduce_program();
@@ -2363,6 +2394,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     rows[0].scalars = nullptr;
     rows[0].shifts = &shift;
     launch(prog, nd->n, rows, host_out, dev_out);
+    defer.finish();
 }
 
 void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out) {

@@ -183,7 +183,16 @@ public:
     int graph_scalars(const fmhip_vec* roots, int n_roots, double* out, int capacity);
 
     // reductions
-    void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out);
+    // what a launch with fused reductions holds while it runs (runtime.cpp: red_begin / red_wait / red_release)
+    struct RedLaunch { void* partials = nullptr; size_t partials_cap = 0; void* results = nullptr; size_t results_cap = 0; void* dev_moments = nullptr;
+                       bool on_host = false; volatile uint64_t* poll_flag = nullptr; uint64_t done_value = 0; int slot = -1;
+                       bool pending = false; int batch = 0, n_red = 0; fmhip_moments* host = nullptr; };       // pending: launched, not yet waited for (defer_red_)
+    // hand_over: a caller that can wait WITHOUT the engine lock (abi.cpp) receives the launch whose moments are still on their way
+    // (pending, slot >= 0: results and completion flag in a slot of their own in pinned memory) instead of having reduce() wait for
+    // it: red_poll() without the lock, red_complete() with it.
+    void reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* dev_out, RedLaunch* hand_over = nullptr);
+    static bool red_poll(const RedLaunch& red);              // spins on the flag (≤ 2 ms); true = the moments have arrived
+    void red_complete(RedLaunch& red, bool arrived);         // copies the moments out (waits for the stream first if they have not arrived), releases
     void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out);
 
     // programs
@@ -240,6 +249,9 @@ private:
 
     // pinned staging for H2D/D2H and the row-table ring
     void*  stage_ = nullptr;  size_t stage_cap_ = 0;
+    // results + completion flag of single-row reductions wanted on the host: 128-byte slots in pinned memory, one per launch in flight
+    char* result_slots_ = nullptr; std::vector<int> free_slots_;
+    static constexpr int RESULT_SLOTS = 64;
     void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
     uint64_t ring_generation_ = 1;          // bumped on every wrap: device copies of older tables may be overwritten
     uint32_t* counters_dev_ = nullptr;      // arrival counters of the fused final combine (65536 rows, zero between launches)
@@ -318,10 +330,6 @@ private:
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
     struct ReduceRequest { double shift; fmhip_moments* host_out; void* dev_out; bool done; };
-    // what a launch with fused reductions holds while it runs (runtime.cpp: red_begin / red_wait / red_release)
-    struct RedLaunch { void* partials = nullptr; size_t partials_cap = 0; void* results = nullptr; size_t results_cap = 0; void* dev_moments = nullptr;
-                       bool on_host = false; volatile uint64_t* poll_flag = nullptr; uint64_t done_value = 0;
-                       bool pending = false; int batch = 0, n_red = 0; fmhip_moments* host = nullptr; };       // pending: launched, not yet waited for (defer_red_)
     // reduce() of a pending expression: the launch that takes the moments leaves its wait to reduce() — the bookkeeping behind the launch
     // (outputs become vectors, expressions are dismantled) happens while the device works, not after it
     RedLaunch* defer_red_ = nullptr;
