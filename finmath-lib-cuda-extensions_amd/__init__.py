@@ -82,6 +82,23 @@ def fusion_hold(hold) -> int:
     return prev.value
 
 
+def reduce_moments_batch_begin(vectors, shifts=None) -> int:
+    """Enqueues ONE launch that takes {Σ, Σ², min, max} of every vector and returns a ticket at once (include/fmhip.h:
+    fmhip_reduce_moments_batch_begin); reduce_moments_batch_end(ticket, len(vectors)) waits for that launch only."""
+    k = len(vectors)
+    handles = (_C.c_int64 * k)(*[getattr(v, "handle", v) for v in vectors])
+    sh = (_C.c_double * k)(*[float(x) for x in shifts]) if shifts is not None else None
+    ticket = _C.c_int64(0)
+    _native.check(lib().fmhip_reduce_moments_batch_begin(handles, k, sh, _C.byref(ticket)))
+    return ticket.value
+
+
+def reduce_moments_batch_end(ticket: int, count: int):
+    out = (_native.Moments * count)()
+    _native.check(lib().fmhip_reduce_moments_batch_end(int(ticket), out, count))
+    return list(out)
+
+
 _expectation_gather = None          # keeps the ctypes callback of the expectation communicator alive
 
 

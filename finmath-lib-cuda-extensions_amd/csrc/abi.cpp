@@ -202,6 +202,29 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
     return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch(vectors, count, shifts, nullptr, device_out); });
 }
+int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out) {
+    return guarded([&] { need(vectors, "vectors"); need(ticket_out, "ticket_out"); *ticket_out = Engine::get().reduce_batch_begin(vectors, count, shifts); });
+}
+int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count) {
+    Engine::MomentsTicket t;
+    int rc = guarded([&] {
+        need(out, "out");
+        Engine& e = Engine::get();
+        e.require_init();
+        t = e.ticket_take(ticket);
+        if (t.count != count) { const int have = t.count; e.ticket_retire(t); throw Error(FMHIP_ERR_SIZE_MISMATCH, "the ticket holds " + std::to_string(have) + " expectations, the caller asks for " + std::to_string(count)); }
+    });
+    if (rc != FMHIP_OK) return rc;
+    const hipError_t waited = hipEventSynchronize(t.event);           // without the engine lock: other threads (and this one's next parameter set) are not held up
+    if (waited == hipSuccess) std::memcpy(out, t.host, (size_t)count * sizeof(fmhip_moments));
+    rc = guarded([&] {
+        Engine& e = Engine::get();
+        e.ticket_retire(t);
+        if (waited != hipSuccess) throw Error(FMHIP_ERR_HIP, std::string("waiting for the expectations failed: ") + hipGetErrorString(waited));
+        exchange_moments(e, out, count);
+    });
+    return rc;
+}
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
 }

@@ -207,6 +207,10 @@ void Engine::shutdown() {
     pool_ = Pool();
     if (stage_) (void)hipHostFree(stage_);
     if (result_slots_) (void)hipHostFree(result_slots_);
+    for (auto& kv : tickets_) free_tickets_.push_back(kv.second);
+    tickets_.clear();
+    for (MomentsTicket& t : free_tickets_) { if (t.event) (void)hipEventDestroy(t.event); if (t.host) (void)hipHostFree(t.host); }
+    free_tickets_.clear();
     result_slots_ = nullptr; free_slots_.clear();
     if (ring_host_) (void)hipHostFree(ring_host_);
     if (ring_dev_) (void)hipFree(ring_dev_);
@@ -2395,6 +2399,41 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     rows[0].shifts = &shift;
     launch(prog, nd->n, rows, host_out, dev_out);
     defer.finish();
+}
+
+int64_t Engine::reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts) {
+    require_init();
+    if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+    const size_t bytes = (size_t)count * 32;
+    MomentsTicket t;
+    for (size_t i = 0; i < free_tickets_.size(); ++i)
+        if (free_tickets_[i].cap >= bytes) { t = free_tickets_[i]; free_tickets_[i] = free_tickets_.back(); free_tickets_.pop_back(); break; }
+    try {
+        if (!t.host) {
+            t.cap = std::max(bytes, size_t(8192));
+            hip_check(hipHostMalloc(&t.host, t.cap, hipHostMallocDefault), "hipHostMalloc(moments ticket)");
+            hip_check(hipEventCreateWithFlags(&t.event, hipEventDisableTiming), "hipEventCreate(moments ticket)");
+        }
+        t.count = count;
+        reduce_batch(hs, count, shifts, nullptr, t.host);     // the last workgroup of every row stores its moments straight into the block
+        hip_check(hipEventRecord(t.event, stream_), "hipEventRecord(moments ticket)");
+    } catch (...) { if (t.host) free_tickets_.push_back(t); throw; }
+    const int64_t id = next_ticket_++;
+    tickets_[id] = t;
+    return id;
+}
+
+Engine::MomentsTicket Engine::ticket_take(int64_t id) {
+    auto it = tickets_.find(id);
+    if (it == tickets_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "unknown (or already ended) expectation ticket");
+    MomentsTicket t = it->second;
+    tickets_.erase(it);
+    return t;
+}
+
+void Engine::ticket_retire(MomentsTicket& t) {
+    if (t.host) free_tickets_.push_back(t);
+    t = MomentsTicket();
 }
 
 void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out) {

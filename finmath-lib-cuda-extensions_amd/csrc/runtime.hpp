@@ -194,6 +194,12 @@ public:
     static bool red_poll(const RedLaunch& red);              // spins on the flag (≤ 2 ms); true = the moments have arrived
     void red_complete(RedLaunch& red, bool arrived);         // copies the moments out (waits for the stream first if they have not arrived), releases
     void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out);
+    // fmhip_reduce_moments_batch_begin / _end: the moments land in a block of pinned memory of the ticket's own, an event behind the
+    // launch tells when (waited for WITHOUT the engine lock: abi.cpp).
+    struct MomentsTicket { void* host = nullptr; size_t cap = 0; hipEvent_t event = nullptr; int count = 0; };
+    int64_t reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts);
+    MomentsTicket ticket_take(int64_t id);                   // removes it from the table (under the lock)
+    void ticket_retire(MomentsTicket& t);                    // block and event back to their free lists (under the lock)
 
     // programs
     fmhip_program program_create(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out,
@@ -251,6 +257,8 @@ private:
     void*  stage_ = nullptr;  size_t stage_cap_ = 0;
     // results + completion flag of single-row reductions wanted on the host: 128-byte slots in pinned memory, one per launch in flight
     char* result_slots_ = nullptr; std::vector<int> free_slots_;
+    std::unordered_map<int64_t, MomentsTicket> tickets_; int64_t next_ticket_ = 1;
+    std::vector<MomentsTicket> free_tickets_;                // retired tickets: their pinned block and event are used again
     static constexpr int RESULT_SLOTS = 64;
     void*  ring_host_ = nullptr; void* ring_dev_ = nullptr; size_t ring_cap_ = 0, ring_off_ = 0;
     uint64_t ring_generation_ = 1;          // bumped on every wrap: device copies of older tables may be overwritten

@@ -67,16 +67,22 @@ inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const B
                 h.push_back(p->deviceVector().handle()); n = p->size();
             }
             const int count = (int)h.size();
-            fmhip_vec buf = 0;
-            check(fmhip_vec_create_uninitialized((int64_t)count * 8, &buf));     // count x {Σ, Σ², min, max} doubles, written by the reduction launch
-            void* dev = nullptr; check(fmhip_vec_device_ptr(buf, &dev));
-            check(fmhip_reduce_moments_batch_device(h.data(), count, nullptr, dev));       // enqueued; nobody waits
-            auto owner = std::make_shared<DeviceVector>(buf);
+            // enqueued; nobody waits.  The ticket is ended when the expectations are read: that waits for THIS reduction only — the next
+            // parameter sets, enqueued in between, keep the device busy meanwhile (a blocking read of a result buffer would wait for
+            // them too: one in-order stream).
+            fmhip_ticket ticket = 0;
+            check(fmhip_reduce_moments_batch_begin(h.data(), count, nullptr, &ticket));
+            struct Owner { fmhip_ticket t = 0; int count = 0; bool ended = false;       // never read (an exception in between): the ticket is ended all the same
+                           Owner() = default; Owner(const Owner&) = delete; Owner& operator=(const Owner&) = delete;
+                           ~Owner() { if (!ended && t) { std::vector<fmhip_moments> drop((size_t)count); (void)fmhip_reduce_moments_batch_end(t, drop.data(), count); } } };
+            auto owner = std::make_shared<Owner>();
+            owner->t = ticket; owner->count = count;
             return [owner, count, n] {
-                std::vector<float> raw((size_t)count * 8);
-                check(fmhip_vec_read_float(owner->handle(), raw.data(), (int64_t)raw.size()));     // the only synchronisation of the evaluation
+                std::vector<fmhip_moments> m((size_t)count);
+                owner->ended = true;
+                check(fmhip_reduce_moments_batch_end(owner->t, m.data(), count));        // the only wait of the evaluation
                 std::vector<double> out((size_t)count);
-                for (int k = 0; k < count; ++k) { double s; std::memcpy(&s, &raw[(size_t)k * 8], 8); out[(size_t)k] = s / (double)n; }
+                for (int k = 0; k < count; ++k) out[(size_t)k] = m[(size_t)k].sum / (double)n;
                 return out;
             };
         };

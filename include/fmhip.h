@@ -246,6 +246,15 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
 /* Same, results (count x 4 doubles) left in caller-owned DEVICE memory, asynchronous on the runtime stream — the send buffer
  * of the one RCCL all-reduce per objective evaluation when paths are sharded over GPUs. */
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out);
+/* The same reduction in two halves: _begin enqueues it and returns a ticket at once; _end waits for THAT reduction — not for work
+ * enqueued after it — writes the `count` moments (the expectation communicator applied, as in fmhip_reduce_moments_batch) and
+ * retires the ticket.  A caller that evaluates one parameter set after the other records and enqueues set k+1 between the two
+ * halves of set k: the device never waits for the host at the boundary (one in-order stream: a blocking read of set k's results
+ * AFTER set k+1 was enqueued would wait for set k+1 as well).  The reference has no counterpart: its getAverage() synchronises
+ * the context (RandomVariableCuda.java:869-878).  A ticket must be ended exactly once. */
+typedef int64_t fmhip_ticket;
+int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out);
+int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count);
 
 /* Expectation communicator: Monte-Carlo paths sharded over processes (one GPU each) behind an UNCHANGED caller.
  * Every vector of this process holds the paths [rank·n, (rank+1)·n) of a global vector of world·n paths; all element-wise

@@ -66,6 +66,9 @@ final class Native {
 	static native int reduceMomentsDevice(long vector, double shift, long deviceOut4Doubles);
 	static native int reduceMomentsBatch(long[] vectors, double[] shiftsOrNull, double[] moments4PerVector);
 	static native int reduceMomentsBatchDevice(long[] vectors, double[] shiftsOrNull, long deviceOut);
+	// the same reduction in two halves: begin enqueues and returns a ticket (ticket[0]); end waits for that reduction only and retires the ticket
+	static native int reduceMomentsBatchBegin(long[] vectors, double[] shiftsOrNull, long[] ticket);
+	static native int reduceMomentsBatchEnd(long ticket, double[] moments4PerVector, int count);
 	// expectation communicator (paths sharded over processes): gatherFunction = address of a C function of type fmhip_gather_fn,
 	// e.g. from an MPI / RCCL helper library; context is handed back to it.  0 removes the communicator.
 	static native int setExpectationComm(int world, int rank, long gatherFunction, long context);

@@ -154,6 +154,19 @@ FMJ(jint, reduceMomentsBatchDevice)(JNIEnv* env, jclass, jlongArray vectors, jdo
     if (!pv.p || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_reduce_moments_batch_device((const fmhip_vec*)pv.p, pv.length(), ps.p, (void*)(intptr_t)deviceOut);
 }
+FMJ(jint, reduceMomentsBatchBegin)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jlongArray ticket) {
+    Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT);
+    if (!pv.p || !ticket || env->GetArrayLength(ticket) < 1 || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
+    fmhip_ticket t = 0;
+    const int st = fmhip_reduce_moments_batch_begin((const fmhip_vec*)pv.p, pv.length(), ps.p, &t);
+    if (st == FMHIP_OK) { const jlong v = (jlong)t; env->SetLongArrayRegion(ticket, 0, 1, &v); }
+    return st;
+}
+FMJ(jint, reduceMomentsBatchEnd)(JNIEnv* env, jclass, jlong ticket, jdoubleArray moments4PerVector, jint count) {
+    Pin<jdouble> pm(env, moments4PerVector);
+    if (!pm.p || count <= 0 || (int64_t)pm.length() < 4 * (int64_t)count) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_reduce_moments_batch_end((fmhip_ticket)ticket, (fmhip_moments*)pm.p, count);
+}
 FMJ(jint, setExpectationComm)(JNIEnv*, jclass, jint world, jint rank, jlong gatherFunction, jlong context) {
     return fmhip_set_expectation_comm(world, rank, (fmhip_gather_fn)(intptr_t)gatherFunction, (void*)(intptr_t)context);
 }

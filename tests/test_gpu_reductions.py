@@ -180,3 +180,33 @@ def test_special_values_in_both_launch_shapes_and_inside_a_loop_kernel(gpu, orac
     finally:
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def test_expectations_in_two_halves(gpu, oracle):
+    """fmhip_reduce_moments_batch_begin / _end: the reduction is enqueued at once, the second half waits for THAT reduction (work enqueued
+    in between does not hold it up, and is not lost), the moments are those of the blocking call; a ticket ends once, with its count."""
+    import ctypes as C
+    n, k = 300_007, 9
+    xs = [oracle.f_from_double(oracle.java_random_doubles(900 + i, n) - 0.4) for i in range(k)]
+    vecs = [dv(gpu, x) for x in xs]
+    prev = gpu.set_fusion(True)
+    try:
+        pending = [v.v1s1("MULT_S", 1.5).v1s1("ADD_S", 0.25) for v in vecs]                 # lazily recorded inputs: the first half runs them
+        first = gpu.reduce_moments_batch_begin(pending, shifts=[0.01 * i for i in range(k)])
+        later = [p.v1s0("EXP").v2s0("MULT", p) for p in pending]                              # more work behind the first reduction …
+        second = gpu.reduce_moments_batch_begin(later)                                        # … and a second ticket in flight
+        got_second = gpu.reduce_moments_batch_end(second, k)                                  # ended out of order
+        got_first = gpu.reduce_moments_batch_end(first, k)
+        for i in range(k):
+            for got, vec, shift in ((got_first[i], pending[i], 0.01 * i), (got_second[i], later[i], 0.0)):
+                m = vec.moments(shift)
+                assert (got.sum, got.sumsq, got.min, got.max) == (m.sum, m.sumsq, m.min, m.max), i
+        lib, out = gpu.lib(), (gpu.Moments * k)()
+        assert lib.fmhip_reduce_moments_batch_end(first, out, k) == gpu._native.ERR_INVALID_HANDLE            # ended already
+        third = gpu.reduce_moments_batch_begin(vecs)
+        assert lib.fmhip_reduce_moments_batch_end(third, out, k - 1) == gpu._native.ERR_SIZE_MISMATCH         # (and the ticket is gone)
+        assert lib.fmhip_reduce_moments_batch_end(third, out, k) == gpu._native.ERR_INVALID_HANDLE
+        ticket = C.c_int64(0)
+        assert lib.fmhip_reduce_moments_batch_begin(None, 1, None, C.byref(ticket)) == gpu._native.ERR_INVALID_ARGUMENT
+    finally:
+        gpu.set_fusion(prev)
