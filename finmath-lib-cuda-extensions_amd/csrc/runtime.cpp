@@ -1711,7 +1711,7 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     static const bool PEEL = [] { const char* e = std::getenv("FMHIP_PEEL"); return !(e && e[0] == '0'); }();
     if (!PEEL) return false;
     const size_t n = g.order.size(), P = ro.period, R = ro.iterations, begin = ro.begin, end = begin + P * R;
-    static const size_t MAX_OPS = [] { const char* e = std::getenv("FMHIP_PEEL_MAX_OPS"); return e ? (size_t)std::atoll(e) : (size_t)128; }();
+    static const size_t MAX_OPS = [] { const char* e = std::getenv("FMHIP_PEEL_MAX_OPS"); return e ? (size_t)std::atoll(e) : (size_t)192; }();
     const size_t MAX_EXTRA = 16;
     if (begin > MAX_OPS || n - end > MAX_OPS || begin == 0) return false;
     RolledBody body = loop_body;

@@ -170,7 +170,7 @@ public:
     int comm_world = 1, comm_rank = 0;
     fmhip_gather_fn comm_gather = nullptr;
     void* comm_context = nullptr;
-    int group_steps = 2;
+    int group_steps = 4;
     // Launches with a fused reduction of at most this many spans in all give every workgroup one UNIT of the reduction tree instead of a
     // span (runtime.cpp: launch); FMHIP_UNIT_WORKGROUPS.
     int64_t unit_workgroups_ = 128;

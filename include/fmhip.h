@@ -199,7 +199,7 @@ int fmhip_fusion_hold(int hold, int* previous);
  * boundaries pending (as under a soft hold), then executes them together — whole time steps, scheduled component by component,
  * their periodic stretch as one rolled-loop launch — instead of cutting the stream every ≈ 40 methods.  The last time index of a
  * generation ends the grouping.  Only while the fusion front-end is on and the caller holds nothing itself (fmhip_fusion_hold).
- * steps = 0 switches it off; default 2 (environment: FMHIP_GROUP_STEPS).  Results never depend on it.
+ * steps = 0 switches it off; default 4 (environment: FMHIP_GROUP_STEPS).  Results never depend on it.
  * Replaces what BrownianMotionCudaWithRandomVariableCuda's callers get from the reference: nothing (one launch per method).
  * Returns the previous setting through *previous (may be NULL). */
 int fmhip_set_step_grouping(int steps, int* previous);

@@ -37,7 +37,7 @@ public class BrownianMotionHip implements BrownianMotion, Serializable {
 	 * EulerSchemeFromProcessModel reads the increments of time index i exactly while it computes step i, the engine watches for the
 	 * first use of an increment with a new time index and executes the methods recorded between S such boundaries together (whole
 	 * time steps, their periodic part as one rolled-loop launch) instead of cutting the stream every ~40 methods.  The system
-	 * property net.finmath.hip.groupTimeSteps overrides the engine's default (2; 0 = off).
+	 * property net.finmath.hip.groupTimeSteps overrides the engine's default (4; 0 = off).
 	 */
 	static {
 		final Integer steps = Integer.getInteger("net.finmath.hip.groupTimeSteps");

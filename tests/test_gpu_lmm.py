@@ -143,7 +143,7 @@ def test_caller_without_hints_gets_the_same_numbers():
     """lmm_hip --finmath-like: the driver as code that knows nothing about the engine (no hold / flush / replication / lock-step
     batches, every state kept, one getAverage per product — finmath-lib's Euler scheme and optimizer through the Java interface).
     Same model volatilities as the driver with all its hints — with the engine grouping the time steps on the caller's behalf
-    (fmhip_set_step_grouping, default 2; FMHIP_GROUP_STEPS=0 switches it off) and without, the grouped run in fewer launches."""
+    (fmhip_set_step_grouping, default 4; FMHIP_GROUP_STEPS=0 switches it off) and without, the grouped run in fewer launches."""
     ensure_built()
     def evaluate(*extra, env=None):
         out = subprocess.run([LMM_HIP, "--paths", "20000", "--mode", "evaluate", "--evaluations", "2", *map(str, extra)], capture_output=True, text=True, timeout=600,
@@ -183,7 +183,7 @@ def test_brownian_motion_groups_time_steps_for_a_plain_scheme(gpu):
     prev = gpu.set_fusion(True)
     try:
         default_steps = gpu.set_step_grouping(0)
-        assert default_steps == 2
+        assert default_steps == 4
         before = gpu.pool_stats().n_kernel_launches
         plain, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.3, -0.5, 2.0, 1.05)
         mid = gpu.pool_stats().n_kernel_launches
@@ -194,7 +194,7 @@ def test_brownian_motion_groups_time_steps_for_a_plain_scheme(gpu):
         by_default, _ = mc.heston_call_mc(bm, 1.0, 0.05, 0.09, 1.0, 0.09, 0.3, -0.5, 2.0, 1.05)
         assert by_default == plain and gpu.pool_stats().n_kernel_launches - after < mid - before
     finally:
-        gpu.set_step_grouping(2)
+        gpu.set_step_grouping(4)
         gpu.fusion_hold(False)
         gpu.set_fusion(prev)
     assert grouped == plain
