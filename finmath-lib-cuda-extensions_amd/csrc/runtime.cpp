@@ -393,6 +393,7 @@ void* Engine::device_ptr(fmhip_vec h) {
     end_step_group();
     Node* nd = node(h);
     if (!nd->buf) materialize({nd});
+    nd->has_moments = false; nd->moments_blocked = true;       // the caller may write through the pointer
     return nd->buf->ptr;
 }
 
@@ -1223,18 +1224,42 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
 // Execute structurally identical, mutually independent DAGs as ONE launch (one batch row per DAG).
 // proto: the member that carries the structure (signature, operations); nullptr = dags[0].  Members that are copies existing as a
 // description (flush_all: replica_dag) carry vectors, outputs and scalars only.
+bool Engine::run_dags_plain(std::vector<Dag>& dags, const Dag* proto) {
+    struct Off { bool& w; bool was; ~Off() { w = was; } } off{ want_root_moments_, want_root_moments_ };
+    want_root_moments_ = false;
+    return run_dags(dags, nullptr, nullptr, nullptr, proto);
+}
+
 bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_moments* host_moments, void* dev_moments, const Dag* proto) {
     HostTimer timer(HostProfile::RUN_DAGS);
     const Dag& d0 = proto ? *proto : dags[0];
     const int64_t n = dags[0].outs[0]->n;
     Program* prog = nullptr;
     if (reduce_shift && dags.size() != 1) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a fused expectation belongs to one expression");
+    // a flush that collects the moments of all pending roots (Engine::reduce): expressions of one value each, all rows of this launch
+    static const double no_shift = 0.0;
+    std::vector<fmhip_moments> all;
+    { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
+      if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] launchable group of %zu, %zu ops, %zu outs, proto %d\n", dags.size(), d0.ops.size(), d0.out_ids.size(), proto ? 1 : 0); }
+    if (want_root_moments_ && !reduce_shift && !host_moments && !dev_moments && d0.out_ids.size() == 1) {
+        bool roots_only = true;
+        for (const Dag& d : dags) roots_only &= d.outs.size() == 1 && d.outs[0]->refs_ext > 0 && !d.outs[0]->moments_blocked;
+        if (roots_only && (dags.size() >= 4 || n * (int64_t)d0.leaves.size() <= (int64_t(1) << 21) || unit_launch(n, (int64_t)dags.size()))) {
+            all.resize(dags.size());
+            reduce_shift = &no_shift; host_moments = all.data();
+        }
+    }
     const std::string key = reduce_shift ? d0.sig + "\xfeR" : d0.sig;       // the program that also reduces its root is a different program
     auto it = program_cache_.find(key);
     if (it != program_cache_.end()) prog = it->second;
     else {
         try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, reduce_shift ? std::vector<int>{ d0.out_ids[0] } : std::vector<int>{}, nullptr, false); }
-        catch (const Error& e) { if (e.code == FMHIP_ERR_PROGRAM_LIMIT) return false; throw; }
+        catch (const Error& e) {
+            if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw;
+            if (all.empty()) return false;
+            all.clear(); reduce_shift = nullptr; host_moments = nullptr;       // without the moments, then
+            return run_dags_plain(dags, proto);
+        }
         program_cache_[key] = prog;
     }
     std::vector<std::vector<Buffer*>> out_bufs(dags.size());
@@ -1254,6 +1279,10 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     } catch (...) {
         for (auto& v : out_bufs) for (Buffer* b : v) buffer_unref(b);
         throw;
+    }
+    for (size_t i = 0; i < all.size(); ++i) {
+        Node* r = dags[i].outs[0];
+        r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
     }
     // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t i = 0; i < dags.size(); ++i)
@@ -1915,8 +1944,8 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
             void* params[] = { &args, &rows_arg };
             RedLaunch red;
-            if (rr) {                           // (one row; the kernel with the fused reduction of the root)
-                red_begin(red, 1, 1, (size_t)tiles, rr->host_out, rr->dev_out);
+            if (rr) {                           // the kernel with the fused reduction of the root (rr->host_out: one entry per row)
+                red_begin(red, (int)count, 1, (size_t)tiles, rr->host_out, rr->dev_out);
                 args.shift = rr->shift; args.partials = (double*)red.partials; args.results = (double*)red.results; args.counters = counters_dev_;
                 args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
             }
@@ -1931,10 +1960,10 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
                 algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
                 if (rr) {
                     rr->done = true;
-                    if (defer_red_ && !defer_red_->pending && rr->host_out && red.on_host) {
+                    if (count == 1 && defer_red_ && !defer_red_->pending && rr->host_out && red.on_host) {
                         red.pending = true; red.batch = 1; red.n_red = 1; red.host = rr->host_out;
                         *defer_red_ = red; red = RedLaunch();      // reduce() waits and releases
-                    } else red_wait(red, 1, 1, rr->host_out);
+                    } else red_wait(red, (int)count, 1, rr->host_out);
                 }
             } catch (...) { red_release(red); throw; }
             red_release(red);
@@ -1955,6 +1984,8 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 // exists), ≤ 1024 members per launch.
 void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr) {
     const size_t max_batch = 1024;
+    { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
+      if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] plan for a group of %zu, %zu nodes, %zu roots: rolled %d peeled %d segs %zu\n", group.size(), group[0].order.size(), group[0].roots.size(), plan.rolled.present ? 1 : 0, plan.rolled.peeled.present ? 1 : 0, plan.segs.size()); }
     if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
         plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
     bool rolled = plan.rolled.present && jit_mode != FMHIP_JIT_OFF && plan.rolled.jit && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::READY;
@@ -1989,7 +2020,28 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                         pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
                     if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) fused = rr;
                 }
+                // … and with a flush that collects the moments of all pending roots (Engine::reduce): of every member, as rows of this launch
+                std::vector<fmhip_moments> all;
+                ReduceRequest every{ 0.0, nullptr, nullptr, false };
+                static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
+                if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] peeled group of %zu, %zu nodes: rr %d source_red %d roots %zu root_last %d\n", group.size(), group[0].order.size(), rr ? 1 : 0, pe.source_red.empty() ? 0 : 1, group[0].roots.size(), (int)(group[0].order.back() == group[0].roots[0]));
+                if (!fused && want_root_moments_ && !rr && !pe.source_red.empty() && tiles <= (size_t)FM_SPAN_UNITS * 65536) {
+                    bool roots_only = true;
+                    for (const BigDag& b : group) roots_only &= !b.described() && b.roots.size() == 1 && b.order.back() == b.roots[0] && !b.roots[0]->moments_blocked;
+                    if (roots_only) {
+                        if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
+                            pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+                        if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) { all.resize(group.size()); every.host_out = all.data(); fused = &every; }
+                    }
+                }
+                std::vector<Node*> root_nodes;
+                if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(b.roots[0]);
                 run_peeled(plan.rolled, group, 0, group.size(), fused);
+                if (fused == &every && every.done)
+                    for (size_t i = 0; i < root_nodes.size(); ++i) {
+                        Node* r = root_nodes[i];
+                        r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
+                    }
                 return;
             }
         }
@@ -2358,6 +2410,24 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     require_init();
     end_step_group();
     Node* nd = node(h);
+    auto cached = [&]() {
+        if (!(nd->has_moments && shift == 0.0 && host_out && !dev_out)) return false;
+        host_out->sum = nd->moments[0]; host_out->sumsq = nd->moments[1]; host_out->min = nd->moments[2]; host_out->max = nd->moments[3];
+        return true;
+    };
+    if (cached()) return;
+    // One expectation is asked for while much else is pending (a caller that records the payoffs of all its products and then takes
+    // their averages one by one — 144 per objective evaluation of the LIBOR market model calibration): everything pending runs NOW,
+    // components of equal shape as rows of the same launches, and those launches take the moments of their roots along.  The other
+    // products' getAverage() calls are answered from what is left with their nodes; the moments are those of the stand-alone
+    // reduction to the last bit (one reduction tree per vector: fm_kernel_parts.hpp).
+    static const size_t BATCH_PENDING = [] { const char* e = std::getenv("FMHIP_BATCH_EXPECTATIONS"); return e ? (size_t)std::atoll(e) : (size_t)256; }();   // 0 = off
+    if (BATCH_PENDING && fusion && fusion_hold != 1 && !nd->buf && shift == 0.0 && host_out && !dev_out && n_pending_ >= BATCH_PENDING && n_pending_ >= 4 * (size_t)std::max(1, nd->weight)) {
+        struct Want { bool& w; ~Want() { w = false; } } want{ want_root_moments_ };
+        want_root_moments_ = true;
+        flush_all();
+    }
+    if (cached()) return;
     RedLaunch deferred;
     struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
         Engine* e; RedLaunch* r; RedLaunch* hand_over;
@@ -2529,6 +2599,7 @@ void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fm
                     Node* o = node(outputs[(size_t)b * p->n_out + k]);
                     if (o->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program output differs in size");
                     if (!o->buf) materialize({ o });
+                    o->has_moments = false;                    // overwritten
                     rows[b].out.push_back(o->buf->ptr);
                 } else {
                     Buffer* bf = new_buffer(n);

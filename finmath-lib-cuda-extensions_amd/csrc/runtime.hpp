@@ -70,6 +70,11 @@ struct Node {
     Node*   in[3] = { nullptr, nullptr, nullptr };
     double  scalar = 0.0;
     int     weight = 0;         // upper bound of pending ops below this node (fusion budget)
+    // {Σ, Σ², min, max} of the vector when somebody has computed them already (a batched flush that took the expectations of all
+    // pending roots along: Engine::reduce); vectors are immutable — the two ways to write into one (fmhip_program_run_into, a raw device
+    // pointer handed out) clear and block this
+    bool    has_moments = false, moments_blocked = false;
+    double  moments[4] = { 0.0, 0.0, 0.0, 0.0 };
     // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
     uint64_t mark = 0;
     int     tmp_id = 0, tmp_uses = 0;
@@ -341,6 +346,9 @@ private:
     // reduce() of a pending expression: the launch that takes the moments leaves its wait to reduce() — the bookkeeping behind the launch
     // (outputs become vectors, expressions are dismantled) happens while the device works, not after it
     RedLaunch* defer_red_ = nullptr;
+    // reduce() with much other work pending: the flush that follows takes the moments of EVERY pending root in the launches that compute
+    // them (rows of the same launches) and leaves them with the nodes — the next getAverage() calls find them there
+    bool want_root_moments_ = false;
     void red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments);
     void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);
     void red_release(RedLaunch& red);
@@ -372,6 +380,7 @@ private:
     std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);
     // reduce_shift != nullptr (one DAG only): the root is ALSO reduced in the same launch — {Σ, Σ(x-shift)², min, max} into host_moments / dev_moments
+    bool run_dags_plain(std::vector<Dag>& dags, const Dag* proto);
     bool run_dags(std::vector<Dag>& dags, const double* reduce_shift = nullptr, fmhip_moments* host_moments = nullptr, void* dev_moments = nullptr, const Dag* proto = nullptr);
     Dag replica_dag(const Dag& d, ReplicaGroup* g, int copy);
     ReplicaGroup* clean_replica_group(uint32_t rep_id, bool uniform) const { if (!rep_id || !uniform) return nullptr; auto it = replicas_.find(rep_id); return it == replicas_.end() ? nullptr : it->second; }

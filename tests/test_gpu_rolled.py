@@ -208,3 +208,71 @@ def test_expectation_in_the_launch_of_the_peeled_chain(gpu, oracle, n):
     finally:
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def test_one_expectation_asked_many_pending(gpu, oracle):
+    """A caller records the payoffs of many products and then takes their averages one by one (what an optimiser over calibration products
+    does).  At the first getAverage() the engine runs everything pending — components of equal shape as rows of the same launches — and
+    those launches take the moments of their roots along (runtime.cpp: Engine::reduce, want_root_moments_); the other averages are
+    answered from what was left with the nodes: no further launch.  Same bits as asking one at a time; nothing of the kind under a
+    caller's own hold; a vector that is written into afterwards forgets its moments."""
+    n, periods, products = 40_009, 24, 12
+    rng = np.random.default_rng(31)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods + products)]
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        dev = [gpu.DeviceVector.from_host(x) for x in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+
+        def record(k, short=False):
+            return swaption_like_chain(lambda p: dev[p + k], 3 if short else periods, dnum, 0.02 + 0.001 * k, 0.5)
+        # reference: one product at a time
+        want = []
+        for k in range(products):
+            for _ in range(2 if k == 0 else 1):              # (the first one twice: discovery, then the kernels)
+                c = record(k)
+                m = c.moments()
+            want.append((m.sum, m.sumsq, m.min, m.max, c.to_float32()))
+        short_want = []
+        for k in range(products):
+            c = record(k, short=True); m = c.moments(); short_want.append((m.sum, m.sumsq, m.min, m.max))
+        # all recorded first (long chains: loop kernels; short ones: one launch each), then asked one by one
+        for attempt in range(2):
+            soft = gpu.fusion_hold(2)                        # (a soft hold: chains stay pending as they do while the engine groups time steps)
+            chains = [record(k) for k in range(products)] + [record(k, short=True) for k in range(products)]
+            gpu.fusion_hold(soft)
+            before = gpu.pool_stats().n_kernel_launches
+            first = chains[0].moments()
+            after_first = gpu.pool_stats().n_kernel_launches
+            got = [first] + [c.moments() for c in chains[1:]]
+            after_all = gpu.pool_stats().n_kernel_launches
+            for k in range(products):
+                assert (got[k].sum, got[k].sumsq, got[k].min, got[k].max) == want[k][:4], (attempt, k)
+                assert_bits_equal(chains[k].to_float32(), want[k][4], "the stored value")
+                g = got[products + k]
+                assert (g.sum, g.sumsq, g.min, g.max) == short_want[k], (attempt, "short", k)
+            if attempt == 1:                                 # (attempt 0 meets the batched shapes for the first time)
+                assert after_first - before <= 4, "everything pending ran as rows of a few launches"
+                assert after_all == after_first, "the other expectations came from the nodes"
+        # a value somebody writes into forgets what was known about it
+        assert chains[1].moments().sum == want[1][0]
+        p = gpu.Program(1)
+        v = p.op("MULT_S", 0, s=2.0)
+        p.output(v)
+        prog = p.compile()
+        prog.run_into([[dev[0]]], [[chains[1]]], want_moments=False)
+        m = chains[1].moments()
+        twice = dev[0].v1s1("MULT_S", 2.0).moments()
+        assert (m.sum, m.min, m.max) == (twice.sum, twice.min, twice.max)
+        # under the caller's own hold only what is asked for runs
+        with gpu.holding():
+            held = [record(k) for k in range(products)]
+            before = gpu.pool_stats().n_kernel_launches
+            m0 = held[0].moments()
+            assert gpu.pool_stats().n_kernel_launches - before == 1
+            assert (m0.sum, m0.sumsq) == want[0][:2]
+        gpu.flush()
+    finally:
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)
