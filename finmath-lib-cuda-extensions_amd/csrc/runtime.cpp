@@ -186,11 +186,10 @@ void Engine::shutdown() {
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
     jit_.stop();                        // joins the compiler thread, unloads the specialised kernels
-    for (auto& kv : nodes_) {           // leak-safe teardown: free storage of every live vector
-        Node* nd = kv.second;
+    nodes_.for_each([&](Node* nd) {     // leak-safe teardown: free storage of every live vector
         if (nd->buf) buffer_unref(nd->buf);     // back to the pool (blocks belong to slabs); purge() below frees the slabs
         delete nd;
-    }
+    });
     nodes_.clear();
     for (auto& kv : replicas_) delete kv.second;
     replicas_.clear();
@@ -286,14 +285,14 @@ Node* Engine::new_node(int64_t n) {
     nd->id = next_id_++;
     nd->n = n;
     nd->refs_ext = 1;
-    nodes_[nd->id] = nd;
+    nodes_.put(nd->id, nd);
     return nd;
 }
 
 Node* Engine::node(fmhip_vec h) {
-    auto it = nodes_.find(h);
-    if (it == nodes_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid vector handle " + std::to_string(h));
-    return it->second;
+    Node* nd = nodes_.get(h);
+    if (!nd) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid vector handle " + std::to_string(h));
+    return nd;
 }
 
 void Engine::drop_expression(Node* nd) {
@@ -870,8 +869,7 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
         const fmhip_vec id = nd->id;
         try { flush_all(); }
         catch (...) {                       // the caller never receives this handle: take the node (and whatever still hangs below it) back
-            auto it = nodes_.find(id);
-            if (it != nodes_.end() && it->second == nd) { nd->refs_ext = 0; nodes_.erase(it); node_maybe_free(nd); }
+            if (nodes_.get(id) == nd) { nd->refs_ext = 0; nodes_.erase(id); node_maybe_free(nd); }
             throw;
         }
         return id;
@@ -988,7 +986,7 @@ void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, cons
     auto shared_root = [&](Node* root, int j) {                      // a root that is a vector already: the copy shares it (or its substitute)
         Node* c = root->mark == ep_leaf && n_map > 0 ? to[(size_t)j * n_map + root->tmp_id] : root;
         c->refs_ext++;
-        if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+        if (c->refs_ext == 1 && !nodes_.get(c->id)) nodes_.put(c->id, c);
         return c->id;
     };
     // The copies as a DESCRIPTION (ReplicaGroup): only when every operand a copy would read exists as a vector already and no part of
@@ -1010,7 +1008,7 @@ void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, cons
                 if (root->mark != ep_graph) { out[(size_t)j * n_roots + r] = shared_root(root, j); continue; }
                 Node* c = copies[(size_t)j][(size_t)root->tmp_id];
                 c->refs_ext++;
-                if (c->refs_ext == 1 && !nodes_.count(c->id)) nodes_[c->id] = c;
+                if (c->refs_ext == 1 && !nodes_.get(c->id)) nodes_.put(c->id, c);
                 out[(size_t)j * n_roots + r] = c->id;
             }
             // copies of values nobody holds and nothing uses cannot exist: every graph node is below a root
@@ -1052,7 +1050,7 @@ void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, cons
             c->id = g->id_base + (int64_t)j * g->graph_size + root->rep_index;
             c->n = root->n; c->refs_ext = 1; c->refs_int = 1;        // refs_int: the group's hold
             c->rep_id = g->id; c->rep_copy = (uint32_t)j + 1u; c->rep_root = r; c->rep_index = root->rep_index;
-            nodes_[c->id] = c;
+            nodes_.put(c->id, c);
             pend_insert(c);
             g->copy_roots[(size_t)j * n_roots + r] = c;
             out[(size_t)j * n_roots + r] = c->id;

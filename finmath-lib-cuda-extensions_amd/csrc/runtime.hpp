@@ -137,6 +137,53 @@ struct Program {
 };
 
 
+// Handle → node.  Handles are consecutive integers, most of them short-lived (a Monte-Carlo calibration hands out tens of millions):
+// pages of 4096 entries indexed directly, allocated when the first handle of a page is issued and freed when its last one is gone —
+// no hashing and no allocation per handle on the path of every recorded method (a hash map was a third of its 80 ns).
+class HandleTable {
+public:
+    Node* get(int64_t id) const {
+        if (id <= 0) return nullptr;
+        const size_t page = (size_t)(id >> BITS);
+        if (page >= pages_.size() || !pages_[page].slot) return nullptr;
+        return pages_[page].slot[(size_t)id & MASK];
+    }
+    void put(int64_t id, Node* nd) {
+        const size_t page = (size_t)(id >> BITS);
+        if (page >= pages_.size()) pages_.resize(page + 1);
+        Page& pg = pages_[page];
+        if (!pg.slot) { pg.slot = new Node*[(size_t)1 << BITS](); pg.live = 0; }
+        Node*& s = pg.slot[(size_t)id & MASK];
+        if (!s) { ++pg.live; ++size_; }
+        s = nd;
+    }
+    void erase(int64_t id) {
+        if (id <= 0) return;
+        const size_t page = (size_t)(id >> BITS);
+        if (page >= pages_.size() || !pages_[page].slot) return;
+        Page& pg = pages_[page];
+        Node*& s = pg.slot[(size_t)id & MASK];
+        if (!s) return;
+        s = nullptr; --size_;
+        if (--pg.live == 0) { delete[] pg.slot; pg.slot = nullptr; }
+    }
+    size_t size() const { return size_; }
+    template <typename F> void for_each(F&& f) const {
+        for (const Page& pg : pages_) if (pg.slot) for (size_t i = 0; i < ((size_t)1 << BITS); ++i) if (pg.slot[i]) f(pg.slot[i]);
+    }
+    void clear() { for (Page& pg : pages_) { delete[] pg.slot; pg.slot = nullptr; pg.live = 0; } pages_.clear(); size_ = 0; }
+    ~HandleTable() { clear(); }
+    HandleTable() = default;
+    HandleTable(const HandleTable&) = delete;
+    HandleTable& operator=(const HandleTable&) = delete;
+private:
+    static constexpr int BITS = 12;
+    static constexpr size_t MASK = ((size_t)1 << BITS) - 1;
+    struct Page { Node** slot = nullptr; uint32_t live = 0; };
+    std::vector<Page> pages_;
+    size_t size_ = 0;
+};
+
 class Engine {
 public:
     static Engine& get();
@@ -242,7 +289,7 @@ private:
     Pool pool_;
     Jit jit_;
     int64_t next_id_ = 1;
-    std::unordered_map<int64_t, Node*> nodes_;
+    HandleTable nodes_;
     Node pending_head_;                                          // circular list of the nodes without storage (lazy expressions)
     void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; ++n_pending_; }
     void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr; --n_pending_; }
