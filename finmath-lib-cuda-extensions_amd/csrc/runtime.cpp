@@ -157,6 +157,8 @@ void Engine::init(int device_index) {
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     hip_check(hipMalloc(&dump_dev_, FM_DUMP_BYTES), "hipMalloc(dump)");
     hip_check(hipHostMalloc((void**)&result_slots_, (size_t)RESULT_SLOTS * 128, hipHostMallocDefault), "hipHostMalloc(result slots)");
+    hip_check(hipHostMalloc((void**)&moments_arena_, ARENA_BYTES, hipHostMallocDefault), "hipHostMalloc(moments arena)");
+    arena_off_ = 0; arena_outstanding_.clear();
     free_slots_.clear();
     for (int i = RESULT_SLOTS; i-- > 0;) free_slots_.push_back(i);
     { const char* e = std::getenv("FMHIP_UNIT_WORKGROUPS"); unit_workgroups_ = e ? std::atoll(e) : 128; }
@@ -206,6 +208,8 @@ void Engine::shutdown() {
     pool_ = Pool();
     if (stage_) (void)hipHostFree(stage_);
     if (result_slots_) (void)hipHostFree(result_slots_);
+    if (moments_arena_) (void)hipHostFree(moments_arena_);
+    moments_arena_ = nullptr; arena_off_ = 0; arena_outstanding_.clear();
     for (auto& kv : tickets_) free_tickets_.push_back(kv.second);
     tickets_.clear();
     for (MomentsTicket& t : free_tickets_) { if (t.event) (void)hipEventDestroy(t.event); if (t.host) (void)hipHostFree(t.host); }
@@ -392,7 +396,7 @@ void* Engine::device_ptr(fmhip_vec h) {
     end_step_group();
     Node* nd = node(h);
     if (!nd->buf) materialize({nd});
-    nd->has_moments = false; nd->moments_blocked = true;       // the caller may write through the pointer
+    nd->has_moments = false; nd->moments_slot = nullptr; nd->moments_blocked = true;       // the caller may write through the pointer
     return nd->buf->ptr;
 }
 
@@ -747,6 +751,66 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
 // pinned memory behind the results and the host POLLS it instead of synchronising the stream.  A caller that values one product after
 // the other (finmath-lib's calibration: 144 getAverage() per objective evaluation) pays the wake-up of hipStreamSynchronize and,
 // measured, a launch that takes 20–25 µs instead of 5 right after it, once per product.
+double* Engine::arena_alloc(size_t count)
+{
+    const size_t need = count * 32;
+    if (need > ARENA_BYTES) return nullptr;
+    if (arena_off_ + need > ARENA_BYTES) {                     // full: everything written so far is collected, then it starts again
+        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(moments arena)");
+        arena_collect();
+        arena_off_ = 0;
+    }
+    volatile uint64_t* p = reinterpret_cast<volatile uint64_t*>(moments_arena_ + arena_off_);
+    for (size_t i = 0; i < count * 4; ++i) p[i] = MOMENTS_SENTINEL;
+    arena_off_ += need;
+    return reinterpret_cast<double*>(const_cast<uint64_t*>(p));
+}
+
+void Engine::arena_assign(Node* nd, double* slot)
+{
+    nd->has_moments = false;
+    nd->moments_slot = reinterpret_cast<volatile uint64_t*>(slot);
+    arena_outstanding_.push_back({ nd->id, nd->moments_slot });
+}
+
+void Engine::arena_collect()
+{
+    for (const auto& o : arena_outstanding_) {
+        Node* nd = nodes_.get(o.first);
+        if (!nd || nd->moments_slot != o.second) continue;       // gone, asked for already, or written into since
+        bool arrived = true;
+        uint64_t v[4];
+        for (int c = 0; c < 4; ++c) { v[c] = o.second[c]; arrived &= v[c] != MOMENTS_SENTINEL; }
+        nd->moments_slot = nullptr;
+        if (arrived) { std::memcpy(nd->moments, v, 32); nd->has_moments = true; }
+    }
+    arena_outstanding_.clear();
+}
+
+bool Engine::slot_wait(Node* nd)
+{
+    volatile uint64_t* slot = nd->moments_slot;
+    if (!slot) return false;
+    auto complete = [&]() { return slot[0] != MOMENTS_SENTINEL && slot[1] != MOMENTS_SENTINEL && slot[2] != MOMENTS_SENTINEL && slot[3] != MOMENTS_SENTINEL; };
+    const auto t0 = std::chrono::steady_clock::now();
+    bool arrived = complete();
+    for (uint32_t spins = 1; !arrived; ++spins) {
+#if defined(__x86_64__)
+        _mm_pause();
+#endif
+        arrived = complete();
+        if (!arrived && (spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (!arrived) { hip_check(hipStreamSynchronize(stream_), "moments sync"); arrived = complete(); }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    nd->moments_slot = nullptr;
+    if (!arrived) return false;                                  // (the launch never took them: a failed launch)
+    uint64_t v[4] = { slot[0], slot[1], slot[2], slot[3] };
+    std::memcpy(nd->moments, v, 32);
+    nd->has_moments = true;
+    return true;
+}
+
 // A launch with fused reductions over `batch` rows of n elements gives every workgroup one unit of the reduction tree (instead of a span
 // of four) when it has few spans in all: such a launch has as many workgroups as one without reductions, so a chain over many vectors
 // need not fear it.
@@ -831,6 +895,7 @@ static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is
                                        // recording of the next methods, and that path is host-bound
 
 void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
+static const size_t SPECULATE_PENDING = [] { const char* e = std::getenv("FMHIP_SPECULATE_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)5000; }();   // operations recorded since the last time step; 0 = off
 static const size_t FUSION_SOFT_CAP = 32768;     // pending operations at which a SOFT hold (fmhip_fusion_hold(2)) executes everything
 // Experiment knob (off): execute everything once this many operations are pending anywhere, instead of the per-handle weight rule.
 // On the hint-free LMM calibration (lmm_hip --finmath-like) 1000 … 16000 gave 15-18 ms per evaluation against 22.8 with the
@@ -861,10 +926,25 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     for (int i = 0; i < n_in; ++i) { nd->in[i] = ins[i]; ins[i]->refs_int++; w += ins[i]->buf ? 0 : ins[i]->weight; }
     nd->weight = w;
     pend_insert(nd);
+    ++ops_since_boundary_;
     const bool held = fusion_hold != 0 || group_hold_;
     if (!fusion || (w > FUSION_MAX_WEIGHT && !held)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
+    } else if (SPECULATE_PENDING && group_hold_ && fusion_hold == 0 && ops_since_boundary_ > SPECULATE_PENDING) {
+        // The engine's own hold (time steps being grouped), no new time step for thousands of operations, and a caller that keeps
+        // recording without asking for anything (the payoffs of its products, behind the simulation): what is pending runs now, without
+        // waiting for it, and the launches take the moments of their roots along — when the caller comes to ask for expectations
+        // (Engine::reduce), the device has been at work while the caller was recording.
+        const fmhip_vec id = nd->id;
+        ops_since_boundary_ = 0;
+        struct Mode { Engine* e; ~Mode() { e->want_root_moments_ = false; e->async_moments_ = false; } } mode{ this };
+        want_root_moments_ = true; async_moments_ = true;
+        try { flush_all(); }
+        catch (...) {
+            if (nodes_.get(id) == nd) { nd->refs_ext = 0; nodes_.erase(id); node_maybe_free(nd); }
+            throw;
+        }
     } else if ((FUSION_MAX_PENDING && !held && n_pending_ > FUSION_MAX_PENDING) || ((fusion_hold == 2 || (group_hold_ && fusion_hold == 0)) && n_pending_ > FUSION_SOFT_CAP)) {
         const fmhip_vec id = nd->id;
         try { flush_all(); }
@@ -882,6 +962,7 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
 // Index 0, or an index below the last one, starts a new simulation; the last index ends the grouping — what follows the
 // simulation is not the scheme's to group.
 void Engine::step_boundary(const Node* inc) {
+    ops_since_boundary_ = 0;
     const bool restart = inc->bm_id != group_bm_id_ || inc->bm_step <= group_last_step_ || inc->bm_step == 0;
     group_bm_id_ = inc->bm_id; group_last_step_ = inc->bm_step;
     if (restart) group_steps_pending_ = 0;
@@ -1237,14 +1318,16 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     // a flush that collects the moments of all pending roots (Engine::reduce): expressions of one value each, all rows of this launch
     static const double no_shift = 0.0;
     std::vector<fmhip_moments> all;
+    double* async_slots = nullptr;                                  // … or, from a flush that does not wait, into slots of the pinned arena
     { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
       if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] launchable group of %zu, %zu ops, %zu outs, proto %d\n", dags.size(), d0.ops.size(), d0.out_ids.size(), proto ? 1 : 0); }
     if (want_root_moments_ && !reduce_shift && !host_moments && !dev_moments && d0.out_ids.size() == 1) {
         bool roots_only = true;
         for (const Dag& d : dags) roots_only &= d.outs.size() == 1 && d.outs[0]->refs_ext > 0 && !d.outs[0]->moments_blocked;
         if (roots_only && (dags.size() >= 4 || n * (int64_t)d0.leaves.size() <= (int64_t(1) << 21) || unit_launch(n, (int64_t)dags.size()))) {
-            all.resize(dags.size());
-            reduce_shift = &no_shift; host_moments = all.data();
+            double* slots = async_moments_ ? arena_alloc(dags.size()) : nullptr;
+            if (slots) { async_slots = slots; reduce_shift = &no_shift; dev_moments = slots; }
+            else if (!async_moments_) { all.resize(dags.size()); reduce_shift = &no_shift; host_moments = all.data(); }
         }
     }
     const std::string key = reduce_shift ? d0.sig + "\xfeR" : d0.sig;       // the program that also reduces its root is a different program
@@ -1254,8 +1337,8 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
         try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, reduce_shift ? std::vector<int>{ d0.out_ids[0] } : std::vector<int>{}, nullptr, false); }
         catch (const Error& e) {
             if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw;
-            if (all.empty()) return false;
-            all.clear(); reduce_shift = nullptr; host_moments = nullptr;       // without the moments, then
+            if (all.empty() && !async_slots) return false;
+            all.clear(); async_slots = nullptr; reduce_shift = nullptr; host_moments = nullptr; dev_moments = nullptr;       // without the moments, then
             return run_dags_plain(dags, proto);
         }
         program_cache_[key] = prog;
@@ -1278,6 +1361,7 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
         for (auto& v : out_bufs) for (Buffer* b : v) buffer_unref(b);
         throw;
     }
+    if (async_slots) for (size_t i = 0; i < dags.size(); ++i) arena_assign(dags[i].outs[0], async_slots + i * 4);
     for (size_t i = 0; i < all.size(); ++i) {
         Node* r = dags[i].outs[0];
         r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
@@ -2029,13 +2113,18 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                     if (roots_only) {
                         if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
                             pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
-                        if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) { all.resize(group.size()); every.host_out = all.data(); fused = &every; }
+                        if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) {
+                            if (async_moments_) { every.dev_out = arena_alloc(group.size()); if (every.dev_out) fused = &every; }
+                            else { all.resize(group.size()); every.host_out = all.data(); fused = &every; }
+                        }
                     }
                 }
                 std::vector<Node*> root_nodes;
                 if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(b.roots[0]);
                 run_peeled(plan.rolled, group, 0, group.size(), fused);
-                if (fused == &every && every.done)
+                if (fused == &every && every.done && every.dev_out)
+                    for (size_t i = 0; i < root_nodes.size(); ++i) arena_assign(root_nodes[i], (double*)every.dev_out + i * 4);
+                else if (fused == &every && every.done)
                     for (size_t i = 0; i < root_nodes.size(); ++i) {
                         Node* r = root_nodes[i];
                         r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
@@ -2414,6 +2503,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         return true;
     };
     if (cached()) return;
+    if (nd->moments_slot && shift == 0.0 && host_out && !dev_out && slot_wait(nd) && cached()) return;
     // One expectation is asked for while much else is pending (a caller that records the payoffs of all its products and then takes
     // their averages one by one — 144 per objective evaluation of the LIBOR market model calibration): everything pending runs NOW,
     // components of equal shape as rows of the same launches, and those launches take the moments of their roots along.  The other
@@ -2426,6 +2516,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
         flush_all();
     }
     if (cached()) return;
+    if (nd->moments_slot && shift == 0.0 && host_out && !dev_out && slot_wait(nd) && cached()) return;
     RedLaunch deferred;
     struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
         Engine* e; RedLaunch* r; RedLaunch* hand_over;
@@ -2597,7 +2688,7 @@ void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fm
                     Node* o = node(outputs[(size_t)b * p->n_out + k]);
                     if (o->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program output differs in size");
                     if (!o->buf) materialize({ o });
-                    o->has_moments = false;                    // overwritten
+                    o->has_moments = false; o->moments_slot = nullptr;      // overwritten
                     rows[b].out.push_back(o->buf->ptr);
                 } else {
                     Buffer* bf = new_buffer(n);

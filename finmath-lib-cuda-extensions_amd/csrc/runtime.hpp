@@ -75,6 +75,7 @@ struct Node {
     // pointer handed out) clear and block this
     bool    has_moments = false, moments_blocked = false;
     double  moments[4] = { 0.0, 0.0, 0.0, 0.0 };
+    volatile uint64_t* moments_slot = nullptr;   // the same four values still on their way from a launch (pinned memory, Engine::moments_arena_)
     // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
     uint64_t mark = 0;
     int     tmp_id = 0, tmp_uses = 0;
@@ -396,6 +397,21 @@ private:
     // reduce() with much other work pending: the flush that follows takes the moments of EVERY pending root in the launches that compute
     // them (rows of the same launches) and leaves them with the nodes — the next getAverage() calls find them there
     bool want_root_moments_ = false;
+    // … and a flush the engine makes on its own while a caller is still recording (call(): many operations pending under the engine's
+    // step-group hold) takes them along WITHOUT waiting: the launches write into slots of a pinned arena, the nodes remember their slot,
+    // reduce() waits for a slot when its vector is asked for.  A slot is {Σ, Σ², min, max} as bit patterns, preset to a NaN payload
+    // no reduction produces (results are canonicalised); the arena is reused after a stream synchronisation that first collects what
+    // is still outstanding.
+    bool async_moments_ = false;
+    size_t ops_since_boundary_ = 0;                              // methods recorded since the last time-step boundary (step_boundary)
+    char* moments_arena_ = nullptr; size_t arena_off_ = 0;
+    static constexpr size_t ARENA_BYTES = size_t(1) << 20;
+    static constexpr uint64_t MOMENTS_SENTINEL = 0x7ff8dead0000beefull;
+    std::vector<std::pair<int64_t, volatile uint64_t*>> arena_outstanding_;
+    double* arena_alloc(size_t count);                           // count slots, preset; may synchronise the stream (arena full)
+    void arena_collect();                                        // stream synchronised: every outstanding slot goes to its node (if it still exists)
+    void arena_assign(Node* nd, double* slot);
+    bool slot_wait(Node* nd);                                    // the node's slot has arrived (or the stream is waited for): moments into the node
     void red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments);
     void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);
     void red_release(RedLaunch& red);
