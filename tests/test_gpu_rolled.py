@@ -276,3 +276,42 @@ def test_one_expectation_asked_many_pending(gpu, oracle):
     finally:
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def test_expectations_taken_while_the_caller_is_still_recording(gpu, oracle):
+    """Behind a simulation (the engine holds the methods of the time steps it is grouping) a caller records payoff after payoff without
+    asking for anything: after 5000 methods without a new time step the engine runs what is pending WITHOUT waiting, and those launches
+    write the moments of their roots into slots of a pinned arena (runtime.cpp: call, arena_alloc, slot_wait).  Asked later, every
+    expectation has the bits of the stand-alone reduction — also when more roots were outstanding than the arena has slots (it is
+    collected and reused), and for vectors released or overwritten in between."""
+    n = 4_099
+    rng = np.random.default_rng(5)
+    base = [oracle.f_from_double(rng.uniform(0.5, 1.5, n)) for _ in range(7)]
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        bm = gpu.BrownianMotionHip(gpu.TimeDiscretization(0.0, 8, 0.25), 1, n, 99)
+        dev = [gpu.DeviceVector.from_host(x) for x in base]
+        state = dev[0]
+        for step in range(3):                                 # "the simulation": three time steps of a scheme; the engine's hold is on afterwards
+            state = state.v2s1("ADDPRODUCT_VS", bm.getBrownianIncrement(step, 0).realizations, 0.1)
+        # 40 000 one-method payoffs (more than the arena's 32 768 slots), each with a handle; nothing is asked for
+        launches_start = gpu.pool_stats().n_kernel_launches
+        payoffs = [dev[k % 7].v1s1("MULT_S", 1.0 + 1e-4 * k) for k in range(40_000)]
+        launches_before = gpu.pool_stats().n_kernel_launches
+        assert launches_before - launches_start >= 7, "the engine ran the pending payoffs on its own while they were being recorded"
+        sample = list(range(0, 40_000, 997)) + [39_999, 5_001, 32_767, 32_768, 32_769]
+        del payoffs[123]                                      # a vector released before anybody asks
+        sample = [k if k < 123 else k - 1 for k in sample if k != 123]
+        for k in sample:
+            m = payoffs[k].moments()
+            kk = k if k < 123 else k + 1
+            want = dev[kk % 7].v1s1("MULT_S", 1.0 + 1e-4 * kk)
+            gpu.flush()
+            w = want.moments()
+            assert (m.sum, m.sumsq, m.min, m.max) == (w.sum, w.sumsq, w.min, w.max), k
+        assert gpu.pool_stats().n_kernel_launches > launches_before
+    finally:
+        gpu.fusion_hold(0)
+        gpu.flush()
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)
