@@ -234,7 +234,14 @@ int fmhip_set_math_mode(int mode, int* previous);
 
 /* One pass over v on the device: Σ(x-shift), Σ(x-shift)², min, max with fp64 accumulation; 32 bytes
  * come back.  Replaces the reference's D2H of the whole vector + host loops
- * (RandomVariableCuda.java:830-901 → RandomVariableFromFloatArray.java:284-382). */
+ * (RandomVariableCuda.java:830-901 → RandomVariableFromFloatArray.java:284-382).
+ * The moments of a vector are a function of its elements and its length alone (one reduction tree per vector): the same bits
+ * whether a launch of their own computes them, the launch that computes the vector, or a launch over many vectors.  With fusion
+ * on (fmhip_set_fusion) and v pending among much other pending work, the call may execute ALL pending work — expressions of equal
+ * shape as rows of the same launches — and keep the unshifted moments of every vector those launches produce: later calls for
+ * those vectors return them without a launch (vectors are immutable; fmhip_program_run_into and fmhip_vec_device_ptr make the
+ * engine forget).  Never under the caller's hard hold (fmhip_fusion_hold(1)).  The calling thread waits for the device without
+ * holding the engine: other threads keep recording and launching. */
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out);
 /* Same, but the 4 doubles are written to caller-owned DEVICE memory (e.g. a torch tensor that is then
  * all-reduced with RCCL); asynchronous on the runtime stream. */
