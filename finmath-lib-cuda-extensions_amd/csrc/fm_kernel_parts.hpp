@@ -121,7 +121,13 @@ template <int NRED> struct RedShared {
     f32x2 lane_ext[NRED][SLOTS][FM_BLOCK];          // {min, max}
     f64x2 unit_sums[NRED][SLOTS];
     f32x2 unit_ext[NRED][SLOTS];
+    f64x2 wg_sums[NRED];                            // the workgroup's running value (red_span_fold → block_combine), kept by ONE lane
+    f32x2 wg_ext[NRED];
 };
+// The wave of a workgroup that stays for the hand-off (block_combine) — it also keeps the workgroup's running value.  It rotates with the
+// workgroup index: the waves of a workgroup sit on different SIMDs, and a new workgroup needs a free slot on every one of them —
+// lingering waves all on the same SIMD would block it just the same.
+__device__ __forceinline__ uint32_t red_keeper_wave() { return blockIdx.x & 3u; }
 template <int NRED> __device__ __forceinline__ RedShared<NRED>& red_shared() { __shared__ RedShared<NRED> s; return s; }
 
 // End of a unit: the lane's values go to LDS slot `slot` (the unit's place among those the workgroup is collecting) and the accumulators
@@ -144,12 +150,12 @@ __device__ __forceinline__ void red_unit_end(double (&acc_sum)[NRED], double (&a
     }
 }
 
-// `units` slots are filled (a span's worth, or what the workgroup has).  Wave w turns slot w into the unit partial; every lane
-// then adds the unit partials, in unit order, to the workgroup's running value wg_* (`first`: it starts with them).  Workgroup-uniform
-// arguments; two barriers.
+// `units` slots are filled (a span's worth, or what the workgroup has).  Wave w turns slot w into the unit partial; ONE lane (lane 0 of
+// the wave that stays for the hand-off) then adds the unit partials, in unit order, to the workgroup's running value in LDS (`first`:
+// it starts with them) — in LDS, not in registers: six registers per reduction through the whole kernel were the difference between
+// three and four waves per SIMD for the interpreter.  Workgroup-uniform arguments; two barriers.
 template <int NRED>
-__device__ __forceinline__ void red_span_fold(const uint32_t units, const bool first,
-                                              double (&wg_sum)[NRED], double (&wg_sq)[NRED], float (&wg_min)[NRED], float (&wg_max)[NRED])
+__device__ __forceinline__ void red_span_fold(const uint32_t units, const bool first)
 {
     RedShared<NRED>& S = red_shared<NRED>();
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -168,15 +174,19 @@ __device__ __forceinline__ void red_span_fold(const uint32_t units, const bool f
         }
     }
     __syncthreads();
+    if (wave == red_keeper_wave() && lane == 0u) {
 #pragma unroll
-    for (int r = 0; r < NRED; ++r) {
+        for (int r = 0; r < NRED; ++r) {
+            f64x2 w = first ? S.unit_sums[r][0] : S.wg_sums[r];
+            f32x2 e = first ? S.unit_ext[r][0] : S.wg_ext[r];
 #pragma unroll
-        for (uint32_t u = 0; u < (uint32_t)RedShared<NRED>::SLOTS; ++u) {
-            if (u < units) {
-                const f64x2 a = S.unit_sums[r][u]; const f32x2 x = S.unit_ext[r][u];
-                if (first && u == 0u) { wg_sum[r] = a.x; wg_sq[r] = a.y; wg_min[r] = x.x; wg_max[r] = x.y; }
-                else { wg_sum[r] += a.x; wg_sq[r] += a.y; wg_min[r] = jmin(wg_min[r], x.x); wg_max[r] = jmax(wg_max[r], x.y); }
+            for (uint32_t u = 0; u < (uint32_t)RedShared<NRED>::SLOTS; ++u) {
+                if (u < units && !(first && u == 0u)) {
+                    const f64x2 a = S.unit_sums[r][u]; const f32x2 x = S.unit_ext[r][u];
+                    w.x += a.x; w.y += a.y; e.x = jmin(e.x, x.x); e.y = jmax(e.y, x.y);
+                }
             }
+            S.wg_sums[r] = w; S.wg_ext[r] = e;
         }
     }
 }
@@ -187,8 +197,7 @@ __device__ __forceinline__ void red_span_fold(const uint32_t units, const bool f
 template <int NRED, int E>
 __device__ __forceinline__ void red_tile_end(const uint32_t rel, const bool last,
                                              double (&acc_sum)[NRED], double (&acc_sq)[NRED], float (&acc_min)[NRED], float (&acc_max)[NRED],
-                                             unsigned long long (&nan_mask)[NRED], const double (&shift)[NRED],
-                                             double (&wg_sum)[NRED], double (&wg_sq)[NRED], float (&wg_min)[NRED], float (&wg_max)[NRED])
+                                             unsigned long long (&nan_mask)[NRED], const double (&shift)[NRED])
 {
     constexpr uint32_t TPU = (uint32_t)(FM_UNIT_ELEMS / (FM_BLOCK * E));
     static_assert(TPU == 1u || TPU == 2u, "a reduction unit is one pass at 8 elements per lane, two at 4");
@@ -196,7 +205,7 @@ __device__ __forceinline__ void red_tile_end(const uint32_t rel, const bool last
     constexpr uint32_t SLOTS = (uint32_t)RedShared<NRED>::SLOTS;
     const uint32_t unit = rel / TPU, slot = unit % SLOTS;
     red_unit_end<NRED>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift, slot);
-    if (slot == SLOTS - 1u || last) red_span_fold<NRED>(slot + 1u, unit < SLOTS, wg_sum, wg_sq, wg_min, wg_max);
+    if (slot == SLOTS - 1u || last) red_span_fold<NRED>(slot + 1u, unit < SLOTS);
 }
 
 // FM_HANDOFF_RELEASE: 1 = the arrival counter's add is an agent-scope release (see block_combine); 0 = relaxed behind sc1 stores
@@ -270,7 +279,7 @@ __device__ __forceinline__ void wave_sum_span_partials(const double* __restrict_
     wave_reduce(s1, s2, mn, mx);
 }
 
-// Workgroup combine.  wg_* = the workgroup's value (red_span_fold: the same in every lane); one partial per workgroup and reduction:
+// Workgroup combine.  The workgroup's value is in LDS (red_span_fold); one partial per workgroup and reduction:
 // partials[row][r][blockIdx.x] = {Σ, Σ², min, max}.  Q = workgroups per span (1: a workgroup took a whole span; 4: one unit each).
 // Waves other than one are finished here: the rest — the coherent stores, the wait for them, the arrival counter and its round
 // trip, ≈ 3-4 µs — keeps ONE wave slot of the workgroup busy, not four (measured on the bench launch: see DESIGN.md §4.2).
@@ -282,17 +291,14 @@ __device__ __forceinline__ void wave_sum_span_partials(const double* __restrict_
 // the row's workgroup partials and moves the second-level counter; the last of those adds the G group partials.  The final
 // moments are a deterministic function of the data and of the number of spans: no float atomics, no second launch.
 template <int NRED>
-__device__ __forceinline__ void block_combine(const double (&wg_sum)[NRED], const double (&wg_sq)[NRED],
-                                              const float (&wg_min)[NRED], const float (&wg_max)[NRED],
-                                              double* __restrict__ partials, const uint32_t row,
+__device__ __forceinline__ void block_combine(double* __restrict__ partials, const uint32_t row,
                                               double* __restrict__ results, uint32_t* __restrict__ counter,       // counter: this row's arrival counter
                                               uint64_t* done_flag, const uint64_t done_value,                       // see DevProgramArgs::done_flag
                                               const uint32_t Q)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // the wave that stays rotates with the workgroup index: the waves of a workgroup sit on different SIMDs, and a new
-    // workgroup needs a free slot on every one of them — lingering waves all on the same SIMD would block it just the same
-    if (wave != (blockIdx.x & 3u)) return;
+    if (wave != red_keeper_wave()) return;
+    RedShared<NRED>& S = red_shared<NRED>();
 
     const uint32_t slots = gridDim.x + FM_COMBINE_GROUP_SLOTS;             // per (row, reduction)
     const uint32_t spans = (gridDim.x + Q - 1u) / Q;
@@ -305,8 +311,9 @@ __device__ __forceinline__ void block_combine(const double (&wg_sum)[NRED], cons
     if (lane == 0u) {
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
-            const double s1 = wg_sum[r], s2 = wg_sq[r];
-            const float mn = wg_min[r], mx = wg_max[r];
+            const f64x2 w = S.wg_sums[r]; const f32x2 e = S.wg_ext[r];      // (written by this very lane: red_span_fold)
+            const double s1 = w.x, s2 = w.y;
+            const float mn = e.x, mx = e.y;
             double* out = partials + (((size_t)row * NRED + r) * slots + blockIdx.x) * 4;
             store_coherent(out + 0, s1); store_coherent(out + 1, s2); store_coherent(out + 2, (double)mn); store_coherent(out + 3, (double)mx);
         }

@@ -69,7 +69,7 @@ typedef float f32x9 __attribute__((ext_vector_type(9)));   // > 8 elements: dyna
 //   variant 1: E = 8,  9 registers  — short programs: twice the work per instruction dispatch and twice the bytes in flight
 // NIN_T = compile-time bound of the number of preloaded inputs (the preload loop is unrolled NIN_T times).
 template <int NRED, bool INLINE_ROW, int E, int NREG, int NIN_T, typename RegVec>
-__global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramArgs A,
+__global__ void __launch_bounds__(FM_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) fm_program_kernel(const DevProgramArgs A,
                                                                const uint64_t* __restrict__ rows,     // [batch][row_words]
                                                                double* __restrict__ partials)         // [batch][NRED][grid.x][4]
 {
@@ -85,14 +85,13 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
     if (A.flags & FM_ARGS_LOG_TABLE) log_table_init();          // wave- and workgroup-uniform
 
     constexpr int NR = NRED > 0 ? NRED : 1;
-    double acc_sum[NR], acc_sq[NR], wg_sum[NR], wg_sq[NR], shift[NR];
-    float  acc_min[NR], acc_max[NR], wg_min[NR], wg_max[NR];
+    double acc_sum[NR], acc_sq[NR], shift[NR];
+    float  acc_min[NR], acc_max[NR];
     unsigned long long nan_mask[NR];
 #pragma unroll
     for (int r = 0; r < NRED; ++r) {
         acc_sum[r] = 0.0; acc_sq[r] = 0.0; nan_mask[r] = 0ull;
         acc_min[r] = __builtin_huge_valf(); acc_max[r] = -__builtin_huge_valf();
-        wg_sum[r] = 0.0; wg_sq[r] = 0.0; wg_min[r] = acc_min[r]; wg_max[r] = acc_max[r];
         shift[r] = reinterpret_cast<const double*>(rowp)[n_in + n_out + r];
     }
 
@@ -211,11 +210,11 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_program_kernel(const DevProgramAr
             red_accumulate<E>(x, shift[r], pass_full, i4, n, acc_sum[r], acc_sq[r], acc_min[r], acc_max[r], nan_mask[r]);
         }
         // ---- the reduction tree's unit / span bookkeeping (fm_kernel_parts.hpp): lane values through LDS, one wave per unit
-        if constexpr (NRED > 0) red_tile_end<NRED, E>(tile - tile_begin, tile + 1u == tile_end, acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift, wg_sum, wg_sq, wg_min, wg_max);
+        if constexpr (NRED > 0) red_tile_end<NRED, E>(tile - tile_begin, tile + 1u == tile_end, acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift);
     }
 
     // ---- one partial per workgroup; the last workgroup of the row adds them
-    if constexpr (NRED > 0) block_combine<NRED>(wg_sum, wg_sq, wg_min, wg_max, partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE, A.done_flag, A.done_value, A.span_blocks);
+    if constexpr (NRED > 0) block_combine<NRED>(partials, row, A.results, A.counters + (size_t)row * FM_COUNTER_STRIDE, A.done_flag, A.done_value, A.span_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
