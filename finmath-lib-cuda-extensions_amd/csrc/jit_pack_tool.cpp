@@ -3,6 +3,7 @@
 // stores the code object where Jit::compile looks behind the user's cache.     usage: jit_pack_tool <descriptions> <output dir>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <set>
 #include <string>
@@ -23,7 +24,11 @@ int main(int argc, char** argv)
         std::printf("%d descriptions, %d round-trip differences\n", n, bad);
         return bad ? 1 : 0;
     }
-    if (argc != 3) { std::fprintf(stderr, "usage: %s <descriptions> <output dir>  |  %s --check <descriptions>\n", argv[0], argv[0]); return 2; }
+    // <descriptions> <output dir> [K N]: only the descriptions K, K + N, K + 2N, … (the build runs N tools side by side: hiprtc compiles
+    // one kernel at a time per process)
+    int slice = 0, slices = 1;
+    if (argc == 5) { slice = std::atoi(argv[3]); slices = std::atoi(argv[4]); if (slices < 1 || slice < 0 || slice >= slices) { std::fprintf(stderr, "jit_pack_tool: bad slice\n"); return 2; } }
+    else if (argc != 3) { std::fprintf(stderr, "usage: %s <descriptions> <output dir> [K N]  |  %s --check <descriptions>\n", argv[0], argv[0]); return 2; }
     std::ifstream in(argv[1]);
     if (!in) { std::fprintf(stderr, "jit_pack_tool: cannot read %s\n", argv[1]); return 2; }
     const auto t0 = std::chrono::steady_clock::now();
@@ -33,6 +38,7 @@ int main(int argc, char** argv)
     while (std::getline(in, line)) {
         ++lineno;
         if (line.empty() || line[0] == '#' || !seen.insert(line).second) continue;
+        if ((int)((seen.size() - 1) % (size_t)slices) != slice) continue;
         fm::DevProgramArgs proto;
         fm::RolledBody body;
         std::string source, log;
