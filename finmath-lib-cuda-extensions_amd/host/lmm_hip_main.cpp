@@ -71,7 +71,50 @@ int main(int argc, char** argv) {
             void* stream = nullptr; check(fmhip_get_stream(&stream));
             const int64_t totalPaths = (int64_t)o.world * o.paths;
             const int world = o.world, rank = o.rank;
-            be.averagesAsync = nullptr;                  // sharded: the gather buffer is shared between evaluations, expectations are read at once
+            // Sharded and pipelined: reduce → all-gather → copy to pinned memory → event, all enqueued; the expectations are read when the
+            // NEXT parameter sets have been enqueued, by waiting for that event only (a blocking read of the gather buffer would wait for
+            // everything enqueued since: one in-order stream).  Every flight has a gather buffer, a pinned block and an event of its own.
+            struct Flight {
+                fmhip_vec dev = 0; double* host = nullptr; hipEvent_t ev = nullptr;
+                std::vector<std::pair<double*, hipEvent_t>>* spare = nullptr;          // pinned blocks and events are used again (allocating them costs ≈ 0.2 ms)
+                ~Flight() { if (dev) fmhip_vec_release(dev); if (host && ev && spare) spare->push_back({ host, ev }); }
+            };
+            static std::vector<std::pair<double*, hipEvent_t>> spare;                  // (all of one size: count x world)
+            be.averagesAsync = [=, &collectives, &collective_seconds](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
+                std::vector<fmhip_vec> h;
+                for (const RV& x : v) {
+                    auto p = dynamic_cast<const RandomVariableHip*>(x.get());
+                    if (!p || p->isDeterministic()) throw std::runtime_error("sharded expectation of a non-device value");
+                    h.push_back(p->deviceVector().handle());
+                }
+                if ((int)h.size() != count) throw std::runtime_error("sharded expectation: unexpected product count");
+                auto f = std::make_shared<Flight>();
+                const size_t doubles = (size_t)count * 4 * (size_t)world;
+                check(fmhip_vec_create_uninitialized((int64_t)doubles * 2, &f->dev));
+                f->spare = &spare;
+                if (!spare.empty()) { f->host = spare.back().first; f->ev = spare.back().second; spare.pop_back(); }
+                else if (hipHostMalloc((void**)&f->host, doubles * 8, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&f->ev, hipEventDisableTiming) != hipSuccess)
+                    throw std::runtime_error("pinned memory / event for a sharded expectation");
+                void* dev = nullptr; check(fmhip_vec_device_ptr(f->dev, &dev));
+                double* all = (double*)dev;
+                check(fmhip_reduce_moments_batch_device(h.data(), count, nullptr, all + (size_t)rank * count * 4));
+                ncclCheck(ncclAllGather(all + (size_t)rank * count * 4, all, (size_t)count * 4, ncclDouble, comm, (hipStream_t)stream), "ncclAllGather");
+                if (hipMemcpyAsync(f->host, all, doubles * 8, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess || hipEventRecord(f->ev, (hipStream_t)stream) != hipSuccess)
+                    throw std::runtime_error("enqueueing the read-back of a sharded expectation");
+                ++collectives;
+                return [f, count, world, totalPaths, &collective_seconds] {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (hipEventSynchronize(f->ev) != hipSuccess) throw std::runtime_error("waiting for a sharded expectation");
+                    collective_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();      // (what is left to wait for when the result is needed)
+                    std::vector<double> out((size_t)count);
+                    for (int k = 0; k < count; ++k) {
+                        double total = 0.0;
+                        for (int r = 0; r < world; ++r) total += f->host[((size_t)r * count + k) * 4];      // sums added in rank order: the same bits on every rank
+                        out[(size_t)k] = total / (double)totalPaths;
+                    }
+                    return out;
+                };
+            };
             be.averages = [=, &collectives, &collective_seconds](const std::vector<RV>& v) {
                 std::vector<fmhip_vec> h;
                 for (const RV& x : v) {

@@ -79,6 +79,11 @@ def test_sharded_driver_path_with_rccl_world_of_one(tmp_path):
     assert not (tmp_path / "id").exists()                                              # removed once the communicator exists
     a, b = np.array(plain["model_volatility"]), np.array(dist["model_volatility"])
     assert np.max(np.abs(a - b) / a) <= 1e-12
+    # … and a calibration: the Jacobian batches in flight one behind the other (reduce → all-gather → pinned copy → event per parameter
+    # set, read when the next sets are enqueued): the same optimiser path as the unsharded run
+    plain = run(LMM_HIP, "--paths", 4000, "--mode", "calibrate", "--max-iterations", 2, "--jacobian-batch", 4)
+    dist = run(LMM_HIP, "--paths", 4000, "--mode", "calibrate", "--max-iterations", 2, "--jacobian-batch", 4, "--world", 1, "--rank", 0, "--nccl-id-file", tmp_path / "id2", "--nccl-nonce", 777)
+    assert dist["rccl_collectives"] == dist["evaluations"] and dist["parameters"] == plain["parameters"] and dist["evaluations"] == plain["evaluations"]
 
 
 def test_lock_step_jacobian_batches_give_the_same_calibration():
