@@ -202,6 +202,7 @@ void Engine::shutdown() {
     programs_.clear();
     for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) { if (--seg.prog->refs == 0) delete seg.prog; delete seg.prog_red; }
     plan_cache_.clear();
+    schedule_cache_.clear(); schedule_cache_bytes_ = 0;
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
     program_cache_.clear();
     pool_.purge();
@@ -1530,9 +1531,11 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
     for (size_t i = 0; i < m; ++i) big.order[i]->tmp_id = (int)i;
     big.hash = sign(big.order, big.sig, &big.escapes);
     if (!memoise) return true;
-    if (schedule_cache_.size() >= 4096) schedule_cache_.clear();
+    if (schedule_cache_.size() >= 4096 || schedule_cache_bytes_ > (size_t(64) << 20)) { schedule_cache_.clear(); schedule_cache_bytes_ = 0; }     // (shapes that never repeat: start again)
     ScheduleMemo& memo = schedule_cache_[walk_hash];
+    schedule_cache_bytes_ -= std::min(schedule_cache_bytes_, memo.walk_sig.size() * 2 + memo.perm.size() * 5);       // (the same walk hash again: replaced)
     memo.walk_sig = walk_sig_; memo.perm.swap(perm); memo.escapes = big.escapes; memo.sig = big.sig; memo.hash = big.hash;
+    schedule_cache_bytes_ += memo.walk_sig.size() * 2 + memo.perm.size() * 5;
     return true;
 }
 

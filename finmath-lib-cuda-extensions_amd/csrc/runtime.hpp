@@ -387,6 +387,7 @@ private:
     // build_big: how a shape (the signature of the walk) was scheduled when it was first seen
     struct ScheduleMemo { std::string walk_sig, sig; std::vector<uint32_t> perm; std::vector<char> escapes; uint64_t hash = 0; };
     std::unordered_map<uint64_t, ScheduleMemo> schedule_cache_;
+    size_t schedule_cache_bytes_ = 0;
     std::string walk_sig_;
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
     // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
