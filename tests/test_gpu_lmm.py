@@ -164,9 +164,10 @@ def test_caller_without_hints_gets_the_same_numbers():
     one_by_one = evaluate("--finmath-like", env={"FMHIP_SPECULATE_PENDING": "0", "FMHIP_BATCH_EXPECTATIONS": "0"})
     at_first_ask = evaluate("--finmath-like", env={"FMHIP_SPECULATE_PENDING": "0"})
     assert one_by_one["model_volatility"] == at_first_ask["model_volatility"] == grouped["model_volatility"]
-    for run in (grouped, at_first_ask, one_by_one):          # (how many launches each takes depends on which kernels are compiled yet)
-        assert run["kernel_launches"] < 0.6 * plain["kernel_launches"]
-    assert hinted["kernel_launches"] < 0.6 * min(grouped["kernel_launches"], at_first_ask["kernel_launches"])
+    if os.environ.get("FMHIP_JIT", "") != "off":              # (loop kernels exist on the specialised tier only; how many launches a run takes
+        for run in (grouped, at_first_ask, one_by_one):      #  also depends on which kernels are compiled yet)
+            assert run["kernel_launches"] < 0.6 * plain["kernel_launches"]
+        assert hinted["kernel_launches"] < 0.6 * min(grouped["kernel_launches"], at_first_ask["kernel_launches"])
 
 
 def test_row_table_ring_smaller_than_a_rolled_row_table():
