@@ -215,8 +215,9 @@ int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int 
         if (t.count != count) { const int have = t.count; e.ticket_retire(t); throw Error(FMHIP_ERR_SIZE_MISMATCH, "the ticket holds " + std::to_string(have) + " expectations, the caller asks for " + std::to_string(count)); }
     });
     if (rc != FMHIP_OK) return rc;
-    const hipError_t waited = hipEventSynchronize(t.event);           // without the engine lock: other threads (and this one's next parameter set) are not held up
-    if (waited == hipSuccess) std::memcpy(out, t.host, (size_t)count * sizeof(fmhip_moments));
+    // (a ticket whose moments came with the launches that computed the vectors has them already: ticket_take waited for their slots)
+    const hipError_t waited = t.event && t.ready.empty() ? hipEventSynchronize(t.event) : hipSuccess;      // without the engine lock: other threads (and this one's next parameter set) are not held up
+    if (waited == hipSuccess) std::memcpy(out, t.ready.empty() ? t.host : (const void*)t.ready.data(), (size_t)count * sizeof(fmhip_moments));
     rc = guarded([&] {
         Engine& e = Engine::get();
         e.ticket_retire(t);

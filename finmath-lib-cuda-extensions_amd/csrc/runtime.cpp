@@ -786,6 +786,11 @@ void Engine::arena_collect()
         if (arrived) { std::memcpy(nd->moments, v, 32); nd->has_moments = true; }
     }
     arena_outstanding_.clear();
+    for (auto& kv : tickets_) {                                   // tickets that wait for slots: what they wait for has arrived
+        MomentsTicket& t = kv.second;
+        for (size_t i = 0; i < t.slots.size(); ++i)
+            if (volatile uint64_t* slot = t.slots[i]) { uint64_t v[4] = { slot[0], slot[1], slot[2], slot[3] }; std::memcpy(&t.ready[i], v, 32); t.slots[i] = nullptr; }
+    }
 }
 
 bool Engine::slot_wait(Node* nd)
@@ -2067,6 +2072,19 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 
 // A component shape with a plan, for every member of a group: segment by segment (the rolled stretch as one launch once its kernel
 // exists), ≤ 1024 members per launch.
+// The root of a component that has exactly one, as its LAST operation — its node (for a copy that exists as a description: the copy's
+// root node) or nullptr.  g0 = the member that carries the order.
+Node* Engine::single_root(const BigDag& b, const BigDag& g0)
+{
+    if (!b.described()) return (b.roots.size() == 1 && !b.order.empty() && b.order.back() == b.roots[0]) ? b.roots[0] : nullptr;
+    const std::vector<int32_t>& rep_root = b.view->rep_root;
+    const size_t n = g0.order.size();
+    if (rep_root.size() != n || n == 0 || rep_root[n - 1] < 0) return nullptr;
+    for (size_t i = 0; i + 1 < n; ++i) if (rep_root[i] >= 0) return nullptr;
+    const ReplicaGroup* g = b.view->g;
+    return g->copy_roots[(size_t)b.copy * g->n_roots + (size_t)rep_root[n - 1]];
+}
+
 void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr) {
     const size_t max_batch = 1024;
     { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
@@ -2112,7 +2130,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                 if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] peeled group of %zu, %zu nodes: rr %d source_red %d roots %zu root_last %d\n", group.size(), group[0].order.size(), rr ? 1 : 0, pe.source_red.empty() ? 0 : 1, group[0].roots.size(), (int)(group[0].order.back() == group[0].roots[0]));
                 if (!fused && want_root_moments_ && !rr && !pe.source_red.empty() && tiles <= (size_t)FM_SPAN_UNITS * 65536) {
                     bool roots_only = true;
-                    for (const BigDag& b : group) roots_only &= !b.described() && b.roots.size() == 1 && b.order.back() == b.roots[0] && !b.roots[0]->moments_blocked;
+                    for (const BigDag& b : group) { Node* r = single_root(b, group[0]); roots_only &= r != nullptr && !r->moments_blocked; }
                     if (roots_only) {
                         if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
                             pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
@@ -2123,7 +2141,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                     }
                 }
                 std::vector<Node*> root_nodes;
-                if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(b.roots[0]);
+                if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(single_root(b, group[0]));
                 run_peeled(plan.rolled, group, 0, group.size(), fused);
                 if (fused == &every && every.done && every.dev_out)
                     for (size_t i = 0; i < root_nodes.size(); ++i) arena_assign(root_nodes[i], (double*)every.dev_out + i * 4);
@@ -2566,6 +2584,40 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
 int64_t Engine::reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts) {
     require_init();
     if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+    // Vectors that are still pending: the flush that computes them takes their moments along (rows of the launches that compute them
+    // anyway, results into slots of the pinned arena) — no reduction launch, the vectors are not read again.  The ticket remembers the
+    // slots; ending it waits for them.  (Vectors computed already, shifts, or a component whose launches cannot take moments: the
+    // reduction launch below.)
+    static const bool FROM_LAUNCHES = [] { const char* e = std::getenv("FMHIP_MOMENTS_FROM_LAUNCHES"); return !(e && e[0] == '0'); }();
+    bool unshifted = true;
+    for (int i = 0; shifts && i < count; ++i) unshifted &= shifts[i] == 0.0;
+    if (FROM_LAUNCHES && fusion && unshifted && hs) {
+        end_step_group();
+        std::vector<Node*> nds((size_t)count);
+        bool pending = false, blocked = false;
+        for (int i = 0; i < count; ++i) { nds[(size_t)i] = node(hs[i]); pending |= !nds[(size_t)i]->buf; blocked |= nds[(size_t)i]->moments_blocked; }
+        if (!blocked) {
+            if (pending) {
+                struct Mode { Engine* e; ~Mode() { e->want_root_moments_ = false; e->async_moments_ = false; } } mode{ this };
+                want_root_moments_ = true; async_moments_ = true;
+                flush_all();
+            }
+            bool all = true;
+            for (Node* nd : nds) all &= nd->has_moments || nd->moments_slot != nullptr;
+            if (all) {
+                MomentsTicket t;
+                t.count = count; t.slots.resize((size_t)count, nullptr); t.ready.resize((size_t)count);
+                for (int i = 0; i < count; ++i) {
+                    Node* nd = nds[(size_t)i];
+                    if (nd->has_moments) t.ready[(size_t)i] = { nd->moments[0], nd->moments[1], nd->moments[2], nd->moments[3] };
+                    else t.slots[(size_t)i] = nd->moments_slot;
+                }
+                const int64_t id = next_ticket_++;
+                tickets_[id] = std::move(t);
+                return id;
+            }
+        }
+    }
     const size_t bytes = (size_t)count * 32;
     MomentsTicket t;
     for (size_t i = 0; i < free_tickets_.size(); ++i)
@@ -2588,12 +2640,33 @@ int64_t Engine::reduce_batch_begin(const fmhip_vec* hs, int count, const double*
 Engine::MomentsTicket Engine::ticket_take(int64_t id) {
     auto it = tickets_.find(id);
     if (it == tickets_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "unknown (or already ended) expectation ticket");
-    MomentsTicket t = it->second;
+    MomentsTicket t = std::move(it->second);
     tickets_.erase(it);
+    for (size_t i = 0; i < t.slots.size(); ++i) {                 // moments taken by the launches that computed the vectors: wait for their slots
+        volatile uint64_t* slot = t.slots[i];
+        if (!slot) continue;
+        auto complete = [&]() { return slot[0] != MOMENTS_SENTINEL && slot[1] != MOMENTS_SENTINEL && slot[2] != MOMENTS_SENTINEL && slot[3] != MOMENTS_SENTINEL; };
+        const auto t0 = std::chrono::steady_clock::now();
+        bool arrived = complete();
+        for (uint32_t spins = 1; !arrived; ++spins) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+            arrived = complete();
+            if (!arrived && (spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        if (!arrived) { hip_check(hipStreamSynchronize(stream_), "moments sync"); arrived = complete(); }
+        if (!arrived) throw Error(FMHIP_ERR_HIP, "the moments of a vector never arrived");
+        std::atomic_thread_fence(std::memory_order_acquire);
+        uint64_t v[4] = { slot[0], slot[1], slot[2], slot[3] };
+        std::memcpy(&t.ready[i], v, 32);
+        t.slots[i] = nullptr;
+    }
     return t;
 }
 
 void Engine::ticket_retire(MomentsTicket& t) {
+    t.slots.clear(); t.ready.clear();
     if (t.host) free_tickets_.push_back(t);
     t = MomentsTicket();
 }

@@ -249,7 +249,10 @@ public:
     void reduce_batch(const fmhip_vec* hs, int count, const double* shifts, fmhip_moments* host_out, void* dev_out);
     // fmhip_reduce_moments_batch_begin / _end: the moments land in a block of pinned memory of the ticket's own, an event behind the
     // launch tells when (waited for WITHOUT the engine lock: abi.cpp).
-    struct MomentsTicket { void* host = nullptr; size_t cap = 0; hipEvent_t event = nullptr; int count = 0; };
+    struct MomentsTicket { void* host = nullptr; size_t cap = 0; hipEvent_t event = nullptr; int count = 0;
+                           // … or, when the launches that computed the vectors took their moments along (reduce_batch_begin on pending vectors):
+                           // the slots of the pinned arena they arrive in (nullptr: in `ready` already) — no launch, no block, no event
+                           std::vector<volatile uint64_t*> slots; std::vector<fmhip_moments> ready; };
     int64_t reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts);
     MomentsTicket ticket_take(int64_t id);                   // removes it from the table (under the lock)
     void ticket_retire(MomentsTicket& t);                    // block and event back to their free lists (under the lock)
@@ -419,6 +422,7 @@ private:
     void run_big_group(std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, Program* prog_red = nullptr);
     void run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
+    Node* single_root(const BigDag& b, const BigDag& g0);
     void commit_described(BigDag& big, size_t pos, Buffer* b);
     bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems, RolledBody* body_out = nullptr);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);

@@ -58,6 +58,8 @@ inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const B
     be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
     be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
     if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))    // =0: every batch's expectations read before the next batch is recorded (A/B)
+        be.expectationsRunPending = true;
+    if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))
         be.averagesAsync = [](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
             std::vector<fmhip_vec> h;
             int64_t n = 0;

@@ -168,6 +168,9 @@ struct Backend {
     // batches of a Levenberg–Marquardt iteration are pipelined — the host records batch b+1 while the device still works on
     // batch b, and reads b's expectations afterwards — instead of idling the device at every batch boundary.
     std::function<std::function<std::vector<double>()>(const std::vector<RV>&)> averagesAsync;
+    // true: averagesAsync executes whatever is still pending below the values it is given (and may take their expectations in the
+    // launches that compute them) — the driver then does not flush between recording the products and asking for their expectations
+    bool expectationsRunPending = false;
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum); used when stepsPerLaunch == 1
     // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  The engine schedules
     // the pending graph of the group component by component (runtime.cpp: build_big, consumers first), finds that the schedule is
@@ -383,14 +386,14 @@ inline PendingValuations evaluateManyBegin(const Market& m, const std::vector<co
         const std::vector<std::vector<RV>> copies = be.clone(values[0], leafFrom, leafTo, nullptr);
         for (size_t k = 1; k < K; ++k) values[k] = copies[k - 1];
         be.hold(false);
-        be.flush();
+        if (!(be.averagesAsync && be.expectationsRunPending)) be.flush();
     } else
     for (size_t k = 0; k < K; ++k) {            // one parameter set at a time: its 144 products are rows enough per launch, and
         be.hold(true);                          // the device starts on set 0 while the host records set 1 (holding all K sets
         values[k].reserve(m.swaptions.size());  // gave the fastest op stream, 5.7 TB/s, but a 3 % slower calibration)
         for (const Swaption& s : m.swaptions) values[k].push_back(swaptionValue(m, sims[k], s));
         be.hold(false);
-        be.flush();
+        if (!(be.averagesAsync && be.expectationsRunPending)) be.flush();
     }
     for (size_t k = 0; k < K; ++k) {
         if (be.averagesAsync) pending.expectations.push_back(be.averagesAsync(values[k]));

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
         if (o.finmathLike) {
             // What finmath-lib's own classes would do through the Java interface: the Euler scheme and the optimizer call RandomVariable
             // methods and getAverage(), nothing else; every time step of the process stays referenced.
-            be.flush = [] {}; be.hold = [](bool) {}; be.clone = nullptr; be.recordedScalars = nullptr; be.averagesAsync = nullptr;
+            be.flush = [] {}; be.hold = [](bool) {}; be.clone = nullptr; be.recordedScalars = nullptr; be.averagesAsync = nullptr; be.expectationsRunPending = false;
             be.averages = [](const std::vector<RV>& v) { std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
             be.jacobianBatch = 1; be.stepsPerLaunch = 1; be.chunk = 1 << 30; be.keepAllStates = true;
         }
@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
                 ~Flight() { if (dev) fmhip_vec_release(dev); if (host && ev && spare) spare->push_back({ host, ev }); }
             };
             static std::vector<std::pair<double*, hipEvent_t>> spare;                  // (all of one size: count x world)
+            be.expectationsRunPending = false;           // (the sharded reduction leaves its partials on the device: an ordinary reduction launch)
             be.averagesAsync = [=, &collectives, &collective_seconds](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
                 std::vector<fmhip_vec> h;
                 for (const RV& x : v) {
