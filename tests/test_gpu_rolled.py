@@ -284,7 +284,7 @@ def test_expectations_taken_while_the_caller_is_still_recording(gpu, oracle):
     write the moments of their roots into slots of a pinned arena (runtime.cpp: call, arena_alloc, slot_wait).  Asked later, every
     expectation has the bits of the stand-alone reduction — also when more roots were outstanding than the arena has slots (it is
     collected and reused), and for vectors released or overwritten in between."""
-    n = 4_099
+    n, count = 67, 530_000                               # (more payoffs than the arena has slots: 2^19)
     rng = np.random.default_rng(5)
     base = [oracle.f_from_double(rng.uniform(0.5, 1.5, n)) for _ in range(7)]
     prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
@@ -294,18 +294,18 @@ def test_expectations_taken_while_the_caller_is_still_recording(gpu, oracle):
         state = dev[0]
         for step in range(3):                                 # "the simulation": three time steps of a scheme; the engine's hold is on afterwards
             state = state.v2s1("ADDPRODUCT_VS", bm.getBrownianIncrement(step, 0).realizations, 0.1)
-        # 40 000 one-method payoffs (more than the arena's 32 768 slots), each with a handle; nothing is asked for
+        # one-method payoffs, more than the arena has slots, each with a handle; nothing is asked for
         launches_start = gpu.pool_stats().n_kernel_launches
-        payoffs = [dev[k % 7].v1s1("MULT_S", 1.0 + 1e-4 * k) for k in range(40_000)]
+        payoffs = [dev[k % 7].v1s1("MULT_S", 1.0 + 1e-6 * k) for k in range(count)]
         launches_before = gpu.pool_stats().n_kernel_launches
         assert launches_before - launches_start >= 7, "the engine ran the pending payoffs on its own while they were being recorded"
-        sample = list(range(0, 40_000, 997)) + [39_999, 5_001, 32_767, 32_768, 32_769]
+        sample = list(range(0, count, 9_973)) + [count - 1, 5_001, (1 << 19) - 1, 1 << 19, (1 << 19) + 1]
         del payoffs[123]                                      # a vector released before anybody asks
         sample = [k if k < 123 else k - 1 for k in sample if k != 123]
         for k in sample:
             m = payoffs[k].moments()
             kk = k if k < 123 else k + 1
-            want = dev[kk % 7].v1s1("MULT_S", 1.0 + 1e-4 * kk)
+            want = dev[kk % 7].v1s1("MULT_S", 1.0 + 1e-6 * kk)
             gpu.flush()
             w = want.moments()
             assert (m.sum, m.sumsq, m.min, m.max) == (w.sum, w.sumsq, w.min, w.max), k
