@@ -377,6 +377,59 @@ def rendezvous_nonce(world, rank):
     return store, int(store.get(key).decode())
 
 
+def self_launch(n_gpus):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a child process on a free
+    local port, pass its stderr through, print the one JSON line of its rank 0 and return its exit code.  Called before anything
+    in this process has touched the GPU (no torch import, no libfmhip)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif child.returncode == 0:
+        print(child.stdout[-2000:], file=sys.stderr)
+        return 1
+    return child.returncode
+
+
+def dry_run(args, world, rank):
+    """FMHIP_BENCH_DRY=1 (tests/test_parallel_gloo.py, no GPU): the launch path of the real run — rendezvous through the launcher's
+    store, a process group on that store, max-over-ranks of a timed region, ONE line from rank 0 — with the GPU legs left out and gloo
+    in place of RCCL.  Never a measurement: the line says so and carries no value."""
+    import torch
+    import torch.distributed as dist
+    store, nonce = rendezvous_nonce(world, rank) if world > 1 else (None, 0)
+    if world > 1:
+        dist.init_process_group(backend="gloo", store=store, rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    mine = torch.tensor([float(nonce), float(rank)], dtype=torch.float64)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(everyone, mine)
+        dist.barrier()
+    else:
+        everyone = [mine]
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    same = all(float(v[0]) == float(nonce) for v in everyone) and [int(v[1]) for v in everyone] == list(range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the launch path (no GPU leg ran)", "value": None, "unit": "path-ops/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "dry": True, "ranks_agree_on_nonce": same,
+                          "region_s_max_over_ranks": float(elapsed.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if same else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["both", "stream", "lmm"], default="both")
@@ -394,9 +447,20 @@ def main():
     if args.cpu_worker > 0:
         print(json.dumps(cpu_baseline(args.cpu_worker, -1.0)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` typed without a launcher: this process has imported neither torch nor the library and has made
+        # no GPU call, so it starts the N ranks itself — torchrun as a CHILD process (never an exec), one rank per GPU — and relays
+        # rank 0's one JSON line and the launcher's return code.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:                     # a launcher's WORLD_SIZE is what actually runs: report that, never exit without a line
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; running and reporting n_gpus = {world}", file=sys.stderr)
+        args.gpus = world
+    if os.environ.get("FMHIP_BENCH_DRY") == "1":
+        sys.exit(dry_run(args, world, rank))
     # FMHIP_BENCH_FORCE_DIST=1 exercises the collective paths with a single rank (rehearsal on a 1-GPU box)
     use_dist = world > 1 or os.environ.get("FMHIP_BENCH_FORCE_DIST") == "1"
     store, nonce = rendezvous_nonce(world, rank) if use_dist else (None, None)
@@ -420,9 +484,6 @@ def main():
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N …")
     import torch                         # before libfmhip: one HIP runtime in the process (see _native.lib)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)

@@ -151,3 +151,34 @@ def test_engine_combination_rule_over_a_two_process_gather(oracle, fm):
     # java.lang.Math.min / max order the zeros: -0.0 (rank 1) below +0.0 (rank 0)
     zeros = fm.expectation_combine(np.array([[[0.0, 0.0, 0.0, -0.0]], [[0.0, 0.0, -0.0, 0.0]]]))
     assert np.signbit(zeros[0, 2]) and not np.signbit(zeros[0, 3])
+
+
+def test_bench_gpus_n_typed_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps K --warmup W` exactly as the driver types it for N = 1 (no torchrun, no WORLD_SIZE): bench.py must
+    start the two ranks itself as a child process and print ONE JSON line with n_gpus == 2.  The GPU legs are left out
+    (FMHIP_BENCH_DRY=1; gloo in place of RCCL): what is tested is the entry path — self-launch, the launcher's store, rendezvous, the
+    relayed line and return code."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FMHIP_BENCH_DRY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["dry"] is True and line["ranks_agree_on_nonce"] is True
+
+
+def test_bench_under_a_launcher_with_another_rank_count_still_prints_a_line():
+    """torchrun with 2 ranks but `--gpus 1` on the command line: the launcher's world is what runs and what the line reports."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FMHIP_BENCH_DRY="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
