@@ -378,9 +378,16 @@ __device__ __forceinline__ f32x2 div_pair(f32x2 a, f32x2 b) {
 //   v_div_fixup_f32 D, S0 = q, S1 = b, S2 = a returns ±|q| with the sign of a/b unless an operand is NaN, infinite or zero, the
 //     quotient underflows (exponent(a) - exponent(b) < -150) or b is huge (exponent 255) — none of which can occur; q, the value the
 //     multiply-add chain produced, is a non-zero normal number of magnitude in (2^-96, 2^96) and carries the sign of a/b already.
-// Inside the range the chain below is therefore div_pair's own chain on the same numbers: the result is the same correctly rounded
-// quotient BY CONSTRUCTION (and it is checked anyway: benchmarks/div_packed.hip, the 2^32 sweeps of the dividing methods through the
-// engine).  9 instructions per pair (2 v_rcp_f32, 7 packed multiply-adds) + the range test instead of 16.
+// Inside the range the scaled chain is therefore the same chain on the same numbers — and it is longer than it needs to be.  The
+// compiler's expansion corrects the quotient twice (q1 = q0 + r0·y1, q = q1 + r1·y1) because with scaling in play it cannot know how
+// good its reciprocal is; inside the range, after ONE Newton step on v_rcp_f32's 1-ulp reciprocal, the FIRST correction already lands on
+// the correctly rounded quotient, for every pair of operands: decided by enumeration of all 2^23 x 2^23 mantissa pairs against the
+// compiler's own `a / b` (benchmarks/div_chain_exhaustive.hip, 7.04e13 quotients in 40 s on one MI355X, 0 differences:
+// profiles/round04_div_chain_exhaustive.json).  Enumeration over mantissas is a proof for the whole range: every value of the chain is
+// a normal number there, v_rcp_f32 maps mantissa to mantissa whatever the exponent, and products and fused multiply-adds commute with
+// scaling by powers of two (checked as well: 2^31 quotients with exponents drawn over the whole range, both edges included).  Leaving
+// out the Newton step instead and keeping both corrections is WRONG for 26 621 mantissa pairs, first (0x3f80d000, 0x3fe45d41).
+// 7 instructions per pair (2 v_rcp_f32, 5 packed multiply-adds) + the range test instead of div_pair's 16 (round 3: 9).
 __device__ __forceinline__ f32x2 div_pair_in_range(f32x2 a, f32x2 b) {
     f32x2 y;
     y.x = __builtin_amdgcn_rcpf(b.x);
@@ -391,17 +398,24 @@ __device__ __forceinline__ f32x2 div_pair_in_range(f32x2 a, f32x2 b) {
     const f32x2 y1 = __builtin_elementwise_fma(e, y, y);
     const f32x2 q0 = a * y1;
     const f32x2 r0 = __builtin_elementwise_fma(nd, q0, a);
-    const f32x2 q1 = __builtin_elementwise_fma(r0, y1, q0);
-    const f32x2 r1 = __builtin_elementwise_fma(nd, q1, a);
-    return __builtin_elementwise_fma(r1, y1, q1);
+    return __builtin_elementwise_fma(r0, y1, q0);
 }
-// Range key of one operand: (bits << 1) drops the sign, the subtraction moves 2^-48 (biased exponent 79) to zero; the operand is in
-// [2^-48, 2^48) exactly when key < FM_DIV_RANGE_SPAN (unsigned).  ONE instruction (v_lshl_add_u32); the keys of a whole group of
-// elements are combined with v_max3_u32 (two operands per instruction) and tested once.  A wave-uniform operand (a scalar of the
-// row block, the constant 1) costs nothing: its key is computed on the scalar unit.
+// Range test of a group of operands: all of them lie in [2^-48, 2^48) exactly when the IEEE 754-2019 minimum of their magnitudes is
+// >= 2^-48 and the maximum < 2^48 — v_minimum3_f32 / v_maximum3_f32 with |x| source modifiers take in TWO operands per instruction and
+// let a NaN through to the comparison, which it fails: one instruction per operand and two comparisons per group (round 3: a key per
+// operand by v_lshl_add_u32 plus v_max3_u32 over the keys, 1.5 per operand).  A wave-uniform operand (a scalar of the row block, the
+// constant 1) is tested on the scalar unit through its integer key: (bits << 1) drops the sign, the subtraction moves 2^-48 (biased
+// exponent 79) to zero, in range exactly when key < FM_DIV_RANGE_SPAN (unsigned).
 constexpr uint32_t FM_DIV_RANGE_LOW = 79u << 24, FM_DIV_RANGE_SPAN = 96u << 24;
 __device__ __forceinline__ uint32_t div_range_key(float x) { return (__float_as_uint(x) << 1) - FM_DIV_RANGE_LOW; }
-__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_elementwise_max(__builtin_elementwise_max(a, b), c); }
+struct DivRange {
+    float hi = 0.0f, lo = __builtin_huge_valf();
+    __device__ __forceinline__ void take(f32x2 v) {
+        hi = __builtin_elementwise_maximum(__builtin_elementwise_maximum(hi, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+        lo = __builtin_elementwise_minimum(__builtin_elementwise_minimum(lo, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+    }
+    __device__ __forceinline__ bool outside() const { return !(lo >= 0x1p-48f) || !(hi < 0x1p48f); }
+};
 
 // Numerator and denominator of element pair j of a dividing micro-op (the additions and multiplications in front of the division
 // of accrue / discount are part of the micro-op: each rounds once, like the reference's kernels, .cu:234-244)
@@ -429,17 +443,18 @@ __device__ __forceinline__ void ueval_div_all(float (&out)[E], const float (&acc
     static_assert(E % 2 == 0 && fm_uop_divides(CODE), "pairs of elements of a dividing micro-op");
     constexpr bool num_uniform = CODE == U_INVERT || CODE == U_VID_S, den_uniform = CODE == U_DIV_S;
     f32x2 num[E / 2], den[E / 2], q[E / 2];
-    uint32_t key = 0u;
+    DivRange range;
 #pragma unroll
     for (int p = 0; p < E / 2; ++p) {
         div_operands<CODE, E>(2 * p, acc, r1, r2, s, num[p], den[p]);
         q[p] = div_pair_in_range(num[p], den[p]);
-        if constexpr (!num_uniform) key = umax3(key, div_range_key(num[p].x), div_range_key(num[p].y));
-        if constexpr (!den_uniform) key = umax3(key, div_range_key(den[p].x), div_range_key(den[p].y));
+        if constexpr (!num_uniform) range.take(num[p]);
+        if constexpr (!den_uniform) range.take(den[p]);
     }
-    if constexpr (num_uniform) key = __builtin_elementwise_max(key, div_range_key(num[0].x));       // scalar unit
-    if constexpr (den_uniform) key = __builtin_elementwise_max(key, div_range_key(den[0].x));
-    if (__builtin_amdgcn_ballot_w64(key >= FM_DIV_RANGE_SPAN) != 0ull) {        // wave-uniform and rare; the volatile asm keeps the compiler from if-converting the block
+    bool outside = range.outside();
+    if constexpr (num_uniform) outside = outside || div_range_key(num[0].x) >= FM_DIV_RANGE_SPAN;       // scalar unit
+    if constexpr (den_uniform) outside = outside || div_range_key(den[0].x) >= FM_DIV_RANGE_SPAN;
+    if (__builtin_amdgcn_ballot_w64(outside) != 0ull) {        // wave-uniform and rare; the volatile asm keeps the compiler from if-converting the block
         asm volatile("; division: IEEE expansion with scaling and fix-up for operands outside [2^-48, 2^48)");
 #pragma unroll
         for (int p = 0; p < E / 2; ++p) q[p] = div_pair(num[p], den[p]);

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -100,13 +101,18 @@ public:
     // Returns the (shared) slot of this program; compiles synchronously when `sync`, else queues it for the worker.
     std::shared_ptr<JitSlot> request(const DevProgramArgs& proto, bool sync);
     // The same for a kernel pair given as source text (rolled loops, runtime.cpp): `elems` = elements per lane and pass.
-    std::shared_ptr<JitSlot> request_source(std::string source, int elems, bool sync);
+    std::shared_ptr<JitSlot> request_source(std::string source, int elems, bool sync, bool cached_only = false);
+    // The slot of a program only if its kernel exists already (loaded in this process, in the user's cache or in the pack): looked up
+    // on the calling thread at a lazily built program's FIRST launch; nullptr = it stays on the interpreter until it has earned a compilation.
+    std::shared_ptr<JitSlot> request_cached(const DevProgramArgs& proto);
     void record(const std::string& description);              // FMHIP_JIT_RECORD: one line per kernel asked for (kernel pack)
     void wait_idle();                                          // until the queue is drained
     JitStats stats();
 private:
     void worker();
     void compile(JitSlot& s);
+    bool load_cached(JitSlot& s);
+    bool finish(JitSlot& s, std::chrono::steady_clock::time_point t0);
     int device_ = 0;
     bool running_ = false, stopping_ = false;
     std::thread thread_;

@@ -630,6 +630,10 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     DevProgramArgs args = p->proto;
     // Tier selection.  Lazy programs are promoted once the interpreter has spent JIT_HOT_WORK element-ops on them
     // (≈10 ms of device time: a compilation costs ≈0.2 s of one background host core); explicit programs at creation.
+    // A kernel that EXISTS (the user's code-object cache, the build-time pack) is used from the program's first launch: looked up once, on
+    // this thread (two hashes of the generated source and a file).  Round 3's calibration ran 563 launches on the interpreter although
+    // every one of those programs had its kernel in the pack.
+    if (jit_mode == FMHIP_JIT_AUTO && !p->jit && !p->jit_probed) { p->jit_probed = true; p->jit = jit_.request_cached(p->proto); }
     if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
         p->interpreted_work += (double)n * batch * std::max(1, p->n_ops);       // (the stand-alone reduction has no ops: it counts as one)
         if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);

@@ -134,6 +134,7 @@ struct Program {
     const uint64_t* last_dev_rows = nullptr;
     uint64_t last_ring_generation = 0;
     double interpreted_work = 0.0;          // elements x micro-ops
+    bool jit_probed = false;                // the caches have been asked for this program's kernel (once, at its first launch)
     std::shared_ptr<JitSlot> jit;
 };
 
