@@ -93,6 +93,14 @@ def reduce_moments_batch_begin(vectors, shifts=None) -> int:
     return ticket.value
 
 
+def give_up_values(vectors) -> None:
+    """The caller wants only the EXPECTATIONS of these vectors: a pending vector that nobody else references is then computed by a
+    launch that takes its moments and does not store it (include/fmhip.h: fmhip_vec_give_up_values)."""
+    k = len(vectors)
+    handles = (_C.c_int64 * k)(*[getattr(v, "handle", v) for v in vectors])
+    _native.check(lib().fmhip_vec_give_up_values(handles, k))
+
+
 def reduce_moments_batch_end(ticket: int, count: int):
     out = (_native.Moments * count)()
     _native.check(lib().fmhip_reduce_moments_batch_end(int(ticket), out, count))

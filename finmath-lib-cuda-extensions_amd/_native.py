@@ -17,7 +17,7 @@ SYMBOLS = [
     "fmhip_init", "fmhip_shutdown", "fmhip_is_initialized", "fmhip_abi_version", "fmhip_last_error",
     "fmhip_device_info", "fmhip_synchronize", "fmhip_get_stream",
     "fmhip_vec_create_from_double", "fmhip_vec_create_from_float", "fmhip_vec_create_filled",
-    "fmhip_vec_create_uninitialized", "fmhip_vec_retain", "fmhip_vec_release", "fmhip_vec_size",
+    "fmhip_vec_create_uninitialized", "fmhip_vec_retain", "fmhip_vec_release", "fmhip_vec_size", "fmhip_vec_give_up_values",
     "fmhip_vec_read_double", "fmhip_vec_read_float", "fmhip_vec_device_ptr",
     "fmhip_call_v1s0", "fmhip_call_v1s1", "fmhip_call_v2s0", "fmhip_call_v2s1", "fmhip_call_v3s0",
     "fmhip_set_fusion", "fmhip_flush", "fmhip_fusion_hold", "fmhip_set_step_grouping", "fmhip_graph_clone", "fmhip_graph_scalars", "fmhip_set_math_mode",
@@ -150,7 +150,7 @@ def lib():
         "fmhip_set_fusion": [i32, C.POINTER(i32)], "fmhip_flush": [], "fmhip_fusion_hold": [i32, C.POINTER(i32)], "fmhip_set_step_grouping": [i32, C.POINTER(i32)], "fmhip_set_math_mode": [i32, C.POINTER(i32)],
         "fmhip_graph_clone": [pv, i32, i32, pv, pv, i32, C.POINTER(dbl), i32, pv], "fmhip_graph_scalars": [pv, i32, C.POINTER(dbl), i32, C.POINTER(i32)],
         "fmhip_reduce_moments": [vec, dbl, C.POINTER(Moments)], "fmhip_reduce_moments_batch": [pv, i32, C.POINTER(dbl), C.POINTER(Moments)], "fmhip_reduce_moments_batch_device": [pv, i32, C.POINTER(dbl), vp], "fmhip_reduce_moments_device": [vec, dbl, vp],
-        "fmhip_reduce_moments_batch_begin": [pv, i32, C.POINTER(dbl), pv], "fmhip_reduce_moments_batch_end": [i64, C.POINTER(Moments), i32],
+        "fmhip_reduce_moments_batch_begin": [pv, i32, C.POINTER(dbl), pv], "fmhip_vec_give_up_values": [pv, i32], "fmhip_reduce_moments_batch_end": [i64, C.POINTER(Moments), i32],
         "fmhip_program_create": [C.POINTER(ProgOp), i32, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), i32, pv],
         "fmhip_program_release": [i64], "fmhip_program_launch_count": [i64, C.POINTER(i32)],
         "fmhip_program_shape": [i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],

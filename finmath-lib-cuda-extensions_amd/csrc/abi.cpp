@@ -205,6 +205,9 @@ int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const
 int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out) {
     return guarded([&] { need(vectors, "vectors"); need(ticket_out, "ticket_out"); *ticket_out = Engine::get().reduce_batch_begin(vectors, count, shifts); });
 }
+int fmhip_vec_give_up_values(const fmhip_vec* vectors, int count) {
+    return guarded([&] { need(vectors, "vectors"); Engine::get().give_up_values(vectors, count); });
+}
 int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count) {
     Engine::MomentsTicket t;
     int rc = guarded([&] {

@@ -2,6 +2,8 @@
 // each program's specialised-kernel source exactly as the run-time tier does, compiles it with hiprtc (no device needed) and
 // stores the code object where Jit::compile looks behind the user's cache.     usage: jit_pack_tool <descriptions> <output dir>
 #include <chrono>
+#include <cstdint>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -23,6 +25,40 @@ int main(int argc, char** argv)
         }
         std::printf("%d descriptions, %d round-trip differences\n", n, bad);
         return bad ? 1 : 0;
+    }
+    if (argc == 4 && std::string(argv[1]) == "--source") {           // the generated source of the kernel fm_jit_<hash> (as --names lists it), under the current environment's generator knobs
+        std::ifstream in(argv[2]);
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            fm::DevProgramArgs proto; fm::RolledBody body;
+            std::string source;
+            if (fm::jit_parse_description(line, proto)) source = fm::jit_generate_source(proto);
+            else if (fm::jit_parse_description(line, body)) source = fm::jit_generate_rolled_source(body);
+            else continue;
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char c : source) { h ^= c; h *= 1099511628211ull; }
+            char name[40]; std::snprintf(name, sizeof name, "fm_jit_%016llx", (unsigned long long)h);
+            if (std::string(argv[3]) == name || std::string(argv[3]) == line.substr(0, std::strlen(argv[3]))) { std::fputs(source.c_str(), stdout); return 0; }
+        }
+        std::fprintf(stderr, "no such kernel\n");
+        return 1;
+    }
+    if (argc == 3 && std::string(argv[1]) == "--names") {            // kernel name (as profilers show it) and the start of its description, one per line
+        std::ifstream in(argv[2]);
+        std::string line;
+        while (std::getline(in, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            fm::DevProgramArgs proto; fm::RolledBody body;
+            std::string source;
+            if (fm::jit_parse_description(line, proto)) source = fm::jit_generate_source(proto);
+            else if (fm::jit_parse_description(line, body)) source = fm::jit_generate_rolled_source(body);
+            else continue;
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char c : source) { h ^= c; h *= 1099511628211ull; }
+            std::printf("fm_jit_%016llx  %s\n", (unsigned long long)h, line.c_str());
+        }
+        return 0;
     }
     // <descriptions> <output dir> [K N]: only the descriptions K, K + N, K + 2N, … (the build runs N tools side by side: hiprtc compiles
     // one kernel at a time per process)

@@ -921,7 +921,10 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     if (inf.n_vec != n_in || inf.scalar != has_scalar)
         throw Error(FMHIP_ERR_INVALID_ARGUMENT, "opcode " + std::to_string(opcode) + " does not match this call shape");
     Node* ins[3] = { nullptr, nullptr, nullptr };
-    for (int i = 0; i < n_in; ++i) ins[i] = node(in[i]);
+    for (int i = 0; i < n_in; ++i) {
+        ins[i] = node(in[i]);
+        if (ins[i]->discarded && !ins[i]->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of an operand was given up (fmhip_reduce_moments_batch_begin_discarding): only its moments exist");
+    }
     if (!replicas_.empty())                                     // an operation on the root of a copy that exists as a description only: the copy becomes an expression first
         for (int i = 0; i < n_in; ++i) if (!ins[i]->buf && ins[i]->rep_copy) if (ReplicaGroup* g = replica_of(ins[i])) expand_replicas(g);
     for (int i = 1; i < n_in; ++i)
@@ -1328,6 +1331,7 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     // a flush that collects the moments of all pending roots (Engine::reduce): expressions of one value each, all rows of this launch
     static const double no_shift = 0.0;
     std::vector<fmhip_moments> all;
+    bool moments_only = false;
     double* async_slots = nullptr;                                  // … or, from a flush that does not wait, into slots of the pinned arena
     { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
       if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] launchable group of %zu, %zu ops, %zu outs, proto %d\n", dags.size(), d0.ops.size(), d0.out_ids.size(), proto ? 1 : 0); }
@@ -1338,13 +1342,16 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
             double* slots = async_moments_ ? arena_alloc(dags.size()) : nullptr;
             if (slots) { async_slots = slots; reduce_shift = &no_shift; dev_moments = slots; }
             else if (!async_moments_) { all.resize(dags.size()); reduce_shift = &no_shift; host_moments = all.data(); }
+            // … and where the caller has given the values up (fmhip_vec_give_up_values: every member's root, nobody else holds it) the
+            // launch takes the moments and stores NOTHING: a program without outputs
+            if (reduce_shift) { moments_only = true; for (const Dag& d : dags) moments_only &= d.outs[0]->discard && d.outs[0]->refs_int == 0; }
         }
     }
-    const std::string key = reduce_shift ? d0.sig + "\xfeR" : d0.sig;       // the program that also reduces its root is a different program
+    const std::string key = reduce_shift ? d0.sig + (moments_only ? "\xfeM" : "\xfeR") : d0.sig;       // the program that also reduces its root is a different program
     auto it = program_cache_.find(key);
     if (it != program_cache_.end()) prog = it->second;
     else {
-        try { prog = compile(d0.ops, (int)d0.leaves.size(), d0.out_ids, reduce_shift ? std::vector<int>{ d0.out_ids[0] } : std::vector<int>{}, nullptr, false); }
+        try { prog = compile(d0.ops, (int)d0.leaves.size(), moments_only ? std::vector<int>{} : d0.out_ids, reduce_shift ? std::vector<int>{ d0.out_ids[0] } : std::vector<int>{}, nullptr, false); }
         catch (const Error& e) {
             if (e.code != FMHIP_ERR_PROGRAM_LIMIT) throw;
             if (all.empty() && !async_slots) return false;
@@ -1358,7 +1365,7 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     try {
         for (size_t i = 0; i < dags.size(); ++i) {
             for (Node* l : dags[i].leaves) rows[i].in.push_back(l->buf->ptr);
-            for (size_t k = 0; k < dags[i].outs.size(); ++k) {
+            for (size_t k = 0; k < dags[i].outs.size() && !moments_only; ++k) {
                 Buffer* b = new_buffer(n);
                 out_bufs[i].push_back(b);
                 rows[i].out.push_back(b->ptr);
@@ -1375,6 +1382,10 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     for (size_t i = 0; i < all.size(); ++i) {
         Node* r = dags[i].outs[0];
         r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
+    }
+    if (moments_only) {         // nothing was stored: the roots keep their moments, give their expressions up and are no roots of later flushes
+        for (size_t i = 0; i < dags.size(); ++i) { Node* r = dags[i].outs[0]; r->discarded = true; r->refs_int++; drop_expression(r); r->refs_int--; }
+        return true;
     }
     // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t i = 0; i < dags.size(); ++i)
@@ -1416,6 +1427,7 @@ struct Engine::BigDag {
     int64_t n = 0;                  // elements per vector
     uint32_t rep_id = 0;            // replica descriptions: as in Dag
     bool rep_uniform = true, rep_any = false;
+    bool discard_root = false;      // its single root is wanted for its moments only (Node::discard; part of the signature)
     // A member WITHOUT nodes — a copy of another member's component that exists as a description: `leaves` holds the copy's operands
     // (same numbering as the original's), values produced by one launch for a later one live in `temp` (by position of the order),
     // root values also go to the copy's root nodes.
@@ -1447,6 +1459,7 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
         big.rep_any |= nd->rep_id != 0;
     };
     big.n = roots[0]->n;
+    big.discard_root = roots.size() == 1 && roots[0]->discard && roots[0]->refs_int == 0;
     for (Node* root : roots) {
         if (root->mark == ep) continue;
         visit(root); note_rep(root);
@@ -1473,9 +1486,13 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
             Node* nd = order[i];
             sig.push_back((char)nd->opcode);
             for (int k = 0; k < 3; ++k) put16(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0);
-            const bool escapes = nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses;                    // needed outside the component
+            // needed outside the component — unless it is a root whose VALUE the caller has given up (moments only, Node::discard): not an
+            // output of the component then ('m': a shape of its own, its peeled kernels do not store it; launches that cannot take the
+            // moments along — segments — go by the nodes' references and store it all the same)
+            const bool moments_only = nd->discard && nd->refs_int == 0;
+            const bool escapes = !moments_only && (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses);
             if (escapes_out) escapes_out->push_back(escapes ? 1 : 0);
-            sig.push_back(escapes ? 'x' : '.');
+            sig.push_back(moments_only ? 'm' : escapes ? 'x' : '.');
         }
         uint64_t h = 0x9e3779b97f4a7c15ull;
         const char* p = sig.data();
@@ -2037,6 +2054,15 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
             void* params[] = { &args, &rows_arg };
+            // Tiles per workgroup: ONE.  Measured (FMHIP_PEEL_TILES = 2 / 4, profiles/round04_peel_tiles_per_workgroup.txt): a workgroup
+            // that walks two or four tiles one after the other — a quarter of the partials, arrival counts and lingering keeper waves of a
+            // launch that takes the moments of its roots — is SLOWER on every kind of launch (valuation chains 5607 → 5527 → 5424 GB/s,
+            // simulation components −2 % and −4 %): these kernels live on the number of independent tiles in flight.  Same moments either
+            // way (the reduction tree is defined on the vector, fm_kernel_parts.hpp).
+            static const int64_t PEEL_TILES_ENV = [] { const char* e = std::getenv("FMHIP_PEEL_TILES"); const long long v = e ? std::atoll(e) : 0; return (v == 1 || v == 2 || v == 4) ? (int64_t)v : (int64_t)0; }();
+            int64_t tiles_per_wg = PEEL_TILES_ENV ? PEEL_TILES_ENV : 1;
+            int64_t grid_x = (tiles + tiles_per_wg - 1) / tiles_per_wg;
+            if ((tiles + grid_x - 1) / grid_x != tiles_per_wg) { tiles_per_wg = 1; grid_x = tiles; }       // (the kernel derives its stretch from the grid: it must come out as asked)
             RedLaunch red;
             if (rr) {                           // the kernel with the fused reduction of the root (rr->host_out: one entry per row)
                 red_begin(red, (int)count, 1, (size_t)tiles, rr->host_out, rr->dev_out);
@@ -2045,7 +2071,7 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             }
             try {
                 const JitSlot& slot = rr ? *pe.jit_red : *pe.jit;
-                hip_check(hipModuleLaunchKernel(inline_rows ? slot.fn_inline : slot.fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
+                hip_check(hipModuleLaunchKernel(inline_rows ? slot.fn_inline : slot.fn_table, (unsigned)grid_x, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
                 const size_t stored = R * LO + NXO + (size_t)std::count(pe.final_store.begin(), pe.final_store.end(), (char)1);
                 if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
                                   profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, rr ? 1 : 0, (int)count, 2, n }); }
@@ -2131,10 +2157,10 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                 std::vector<fmhip_moments> all;
                 ReduceRequest every{ 0.0, nullptr, nullptr, false };
                 static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
-                if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] peeled group of %zu, %zu nodes: rr %d source_red %d roots %zu root_last %d\n", group.size(), group[0].order.size(), rr ? 1 : 0, pe.source_red.empty() ? 0 : 1, group[0].roots.size(), (int)(group[0].order.back() == group[0].roots[0]));
+                if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] peeled group of %zu, %zu nodes: rr %d source_red %d roots %zu root_last %d\n", group.size(), group[0].order.size(), rr ? 1 : 0, pe.source_red.empty() ? 0 : 1, group[0].roots.size(), (int)(!group[0].order.empty() && !group[0].roots.empty() && group[0].order.back() == group[0].roots[0]));
                 if (!fused && want_root_moments_ && !rr && !pe.source_red.empty() && tiles <= (size_t)FM_SPAN_UNITS * 65536) {
                     bool roots_only = true;
-                    for (const BigDag& b : group) { Node* r = single_root(b, group[0]); roots_only &= r != nullptr && !r->moments_blocked; }
+                    for (const BigDag& b : group) { Node* r = single_root(b, group[0]); roots_only &= r != nullptr && !r->moments_blocked && (!plan.discards_root || r->discard); }
                     if (roots_only) {
                         if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
                             pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
@@ -2144,6 +2170,9 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                         }
                     }
                 }
+                // A plan whose root is wanted for its moments only has peeled kernels that do not store it: usable only when this launch
+                // takes the moments of every member's root; otherwise the segments below run (they go by the nodes' references and store it)
+                if (!plan.discards_root || fused == &every) {
                 std::vector<Node*> root_nodes;
                 if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(single_root(b, group[0]));
                 run_peeled(plan.rolled, group, 0, group.size(), fused);
@@ -2154,7 +2183,10 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                         Node* r = root_nodes[i];
                         r->moments[0] = all[i].sum; r->moments[1] = all[i].sumsq; r->moments[2] = all[i].min; r->moments[3] = all[i].max; r->has_moments = true;
                     }
+                if (plan.discards_root && every.done)       // moments taken, value not stored: not a root of later flushes; what it was computed from is let go
+                    for (Node* r : root_nodes) if (!r->buf) { r->discarded = true; r->refs_int++; drop_expression(r); r->refs_int--; }
                 return;
+                }
             }
         }
     }
@@ -2302,6 +2334,7 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
     if (collision) { if (!described.empty()) run_plan(plan, described); return; }
     for (BigPlan::Seg& seg : plan.segs) seg.prog->refs++;              // the plan holds its programs (pool_purge drops both caches together)
     plan.sig = group[0].sig;
+    plan.discards_root = group[0].discard_root;
     const uint64_t key = group[0].hash;
     plan_cache_[key] = std::move(plan);
     if (!described.empty()) run_plan(plan_cache_[key], described);
@@ -2314,6 +2347,8 @@ bool Engine::try_fused(const std::vector<Node*>& roots) {
 }
 
 void Engine::materialize(const std::vector<Node*>& targets) {
+    for (Node* t : targets)
+        if (t->discarded && !t->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of this vector was given up (fmhip_reduce_moments_batch_begin_discarding): only its moments exist");
     expand_replicas_below(targets);                 // a single expression is executed, not everything pending: descriptions of copies it touches become nodes first
     for (Node* t : targets) {
         if (t->buf) continue;
@@ -2334,10 +2369,10 @@ void Engine::flush_all() {
     for (int round = 0; round < 1000000; ++round) {
         std::unique_ptr<HostTimer> t_components(new HostTimer(HostProfile::FLUSH_COMPONENTS));
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
-        for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_int == 0 && nd->refs_ext > 0) roots.push_back(nd);
+        for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_int == 0 && nd->refs_ext > 0 && !nd->discarded) roots.push_back(nd);
         if (roots.empty()) {
             Node* live = nullptr;
-            for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_ext > 0) { live = nd; break; }
+            for (Node* nd = pending_head_.pend_next; nd != &pending_head_; nd = nd->pend_next) if (nd->refs_ext > 0 && !nd->discarded) { live = nd; break; }
             if (!live) return;
             materialize({ live });
             continue;
@@ -2595,33 +2630,7 @@ int64_t Engine::reduce_batch_begin(const fmhip_vec* hs, int count, const double*
     static const bool FROM_LAUNCHES = [] { const char* e = std::getenv("FMHIP_MOMENTS_FROM_LAUNCHES"); return !(e && e[0] == '0'); }();
     bool unshifted = true;
     for (int i = 0; shifts && i < count; ++i) unshifted &= shifts[i] == 0.0;
-    if (FROM_LAUNCHES && fusion && unshifted && hs) {
-        end_step_group();
-        std::vector<Node*> nds((size_t)count);
-        bool pending = false, blocked = false;
-        for (int i = 0; i < count; ++i) { nds[(size_t)i] = node(hs[i]); pending |= !nds[(size_t)i]->buf; blocked |= nds[(size_t)i]->moments_blocked; }
-        if (!blocked) {
-            if (pending) {
-                struct Mode { Engine* e; ~Mode() { e->want_root_moments_ = false; e->async_moments_ = false; } } mode{ this };
-                want_root_moments_ = true; async_moments_ = true;
-                flush_all();
-            }
-            bool all = true;
-            for (Node* nd : nds) all &= nd->has_moments || nd->moments_slot != nullptr;
-            if (all) {
-                MomentsTicket t;
-                t.count = count; t.slots.resize((size_t)count, nullptr); t.ready.resize((size_t)count);
-                for (int i = 0; i < count; ++i) {
-                    Node* nd = nds[(size_t)i];
-                    if (nd->has_moments) t.ready[(size_t)i] = { nd->moments[0], nd->moments[1], nd->moments[2], nd->moments[3] };
-                    else t.slots[(size_t)i] = nd->moments_slot;
-                }
-                const int64_t id = next_ticket_++;
-                tickets_[id] = std::move(t);
-                return id;
-            }
-        }
-    }
+    if (FROM_LAUNCHES && fusion && unshifted && hs) return reduce_batch_begin_from_launches(hs, count);
     const size_t bytes = (size_t)count * 32;
     MomentsTicket t;
     for (size_t i = 0; i < free_tickets_.size(); ++i)
@@ -2638,6 +2647,72 @@ int64_t Engine::reduce_batch_begin(const fmhip_vec* hs, int count, const double*
     } catch (...) { if (t.host) free_tickets_.push_back(t); throw; }
     const int64_t id = next_ticket_++;
     tickets_[id] = t;
+    return id;
+}
+
+// fmhip_vec_give_up_values: the caller wants the EXPECTATIONS of these vectors and will never read their values.  A vector that is
+// still pending and that nobody but the caller references is marked (Node::discard); a flush that takes the moments of its roots along
+// (reduce_batch_begin, reduce) then computes it in a launch that takes its moments and does NOT store it (run_plan: a peeled component
+// whose root is 'm' in the signature).  One 8 KB store per workgroup at the end of a read-only chain costs such a launch 8-10 % of its
+// rate (benchmarks/read_pattern.hip: 6486 → 5893 GB/s; the valuation kernel in isolation 6145 → 6617): the memory system pays for
+// turning a stream of reads around for a trickle of writes.  A marked vector that runs through a launch which cannot take its moments
+// is stored like any other.
+void Engine::give_up_values(const fmhip_vec* hs, int count) {
+    require_init();
+    if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+    static const bool DISCARD = [] { const char* e = std::getenv("FMHIP_DISCARD_VALUES"); return !(e && e[0] == '0'); }();      // =0: every value is stored (A/B measurement)
+    std::vector<Node*> nds((size_t)count);
+    for (int i = 0; i < count; ++i) nds[(size_t)i] = node(hs[i]);
+    if (!DISCARD) return;
+    // nobody but the caller references it — not counting the holds of a live replica description (fmhip_graph_clone) on the roots it
+    // replicates (one external reference on the original's root) and on the roots of its copies (one internal reference each)
+    auto sole_owner = [&](const Node* nd) {
+        int ext = nd->refs_ext, in = nd->refs_int;
+        if (nd->rep_id && replica_of(nd)) { if (nd->rep_copy) in -= 1; else if (nd->rep_root >= 0) ext -= 1; }
+        return ext == 1 && in == 0;
+    };
+    for (Node* nd : nds) if (!nd->buf && !nd->moments_blocked && sole_owner(nd)) nd->discard = true;
+}
+
+// The expectations of vectors that may still be pending, every one through a slot of the pinned arena (or at hand already): the flush
+// that computes the pending ones takes their moments along; what has none afterwards (computed earlier, a launch that could not take
+// them along, a vector somebody writes into) is reduced by ONE launch of the reduction program into arena slots.
+int64_t Engine::reduce_batch_begin_from_launches(const fmhip_vec* hs, int count) {
+    end_step_group();
+    std::vector<Node*> nds((size_t)count);
+    for (int i = 0; i < count; ++i) nds[(size_t)i] = node(hs[i]);
+    for (int i = 1; i < count; ++i)
+        if (nds[(size_t)i]->n != nds[0]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "batched reduction over vectors of different size");
+    bool pending = false;
+    for (Node* nd : nds) pending |= !nd->buf && !nd->discarded;
+    if (pending) {
+        struct Mode { Engine* e; ~Mode() { e->want_root_moments_ = false; e->async_moments_ = false; } } mode{ this };
+        want_root_moments_ = true; async_moments_ = true;
+        flush_all();
+    }
+    std::vector<fmhip_vec> rest;
+    std::vector<size_t> rest_index;
+    for (int i = 0; i < count; ++i) {
+        Node* nd = nds[(size_t)i];
+        if (nd->has_moments || nd->moments_slot) continue;
+        rest.push_back(hs[i]); rest_index.push_back((size_t)i);
+    }
+    MomentsTicket t;
+    t.count = count; t.slots.resize((size_t)count, nullptr); t.ready.resize((size_t)count);
+    if (!rest.empty()) {
+        double* slots = arena_alloc(rest.size());
+        if (!slots) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "too many expectations for one ticket");
+        reduce_batch(rest.data(), (int)rest.size(), nullptr, nullptr, slots);
+        for (size_t k = 0; k < rest.size(); ++k) t.slots[rest_index[k]] = reinterpret_cast<volatile uint64_t*>(slots + k * 4);
+    }
+    for (int i = 0; i < count; ++i) {
+        Node* nd = nds[(size_t)i];
+        if (t.slots[(size_t)i]) continue;
+        if (nd->has_moments) t.ready[(size_t)i] = { nd->moments[0], nd->moments[1], nd->moments[2], nd->moments[3] };
+        else t.slots[(size_t)i] = nd->moments_slot;
+    }
+    const int64_t id = next_ticket_++;
+    tickets_[id] = std::move(t);
     return id;
 }
 

@@ -76,6 +76,10 @@ struct Node {
     bool    has_moments = false, moments_blocked = false;
     double  moments[4] = { 0.0, 0.0, 0.0, 0.0 };
     volatile uint64_t* moments_slot = nullptr;   // the same four values still on their way from a launch (pinned memory, Engine::moments_arena_)
+    // fmhip_vec_give_up_values: the caller wants this pending value's moments and will never read the value itself.  `discard`: marked
+    // (a root nobody else references); `discarded`: a flush took the moments in the launch that computed the value and did NOT store
+    // it — the node stays without storage, is not a root of later flushes, and reading it is an error.
+    bool    discard = false, discarded = false;
     // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
     uint64_t mark = 0;
     int     tmp_id = 0, tmp_uses = 0;
@@ -255,6 +259,8 @@ public:
                            // the slots of the pinned arena they arrive in (nullptr: in `ready` already) — no launch, no block, no event
                            std::vector<volatile uint64_t*> slots; std::vector<fmhip_moments> ready; };
     int64_t reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts);
+    int64_t reduce_batch_begin_from_launches(const fmhip_vec* hs, int count);
+    void give_up_values(const fmhip_vec* hs, int count);
     MomentsTicket ticket_take(int64_t id);                   // removes it from the table (under the lock)
     void ticket_retire(MomentsTicket& t);                    // block and event back to their free lists (under the lock)
 
@@ -357,6 +363,7 @@ private:
                      std::vector<SsaOp> ssa; std::vector<int> out_ids; int n_in = 0; Program* prog_red = nullptr; bool no_red = false; };
         std::vector<Seg> segs;
         std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
+        bool discards_root = false; // the component's root is wanted for its moments only (Node::discard): the peeled kernels of this plan do not store it
         // A periodic stretch of the scheduled order — the same few operations over one component after another, each iteration
         // feeding the next (a running sum) — as ONE launch of a kernel that loops over the iterations (runtime.cpp: rolled loops).
         // Positions are offsets inside one iteration; the loop covers order[begin + r·period + q], r < iterations.

@@ -55,6 +55,14 @@ inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const B
             return sc;
         };
     }
+    // the products' payoffs are wanted for their Monte-Carlo averages only: their values are given up (fmhip.h: fmhip_vec_give_up_values),
+    // the launches that compute them take the moments and store nothing (FMHIP_LMM_DISCARD=0: not told, A/B measurement)
+    if (!(std::getenv("FMHIP_LMM_DISCARD") && std::getenv("FMHIP_LMM_DISCARD")[0] == '0'))
+        be.valuesNotNeeded = [](const std::vector<RV>& v) {
+            std::vector<fmhip_vec> h;
+            for (const RV& x : v) { auto p = dynamic_cast<const RandomVariableHip*>(x.get()); if (p && !p->isDeterministic()) h.push_back(p->deviceVector().handle()); }
+            if (!h.empty()) check(fmhip_vec_give_up_values(h.data(), (int)h.size()));
+        };
     be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
     be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
     if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))    // =0: every batch's expectations read before the next batch is recorded (A/B)

@@ -171,6 +171,10 @@ struct Backend {
     // true: averagesAsync executes whatever is still pending below the values it is given (and may take their expectations in the
     // launches that compute them) — the driver then does not flush between recording the products and asking for their expectations
     bool expectationsRunPending = false;
+    // Optional: tells the back end that only the expectations of these values will be asked for, never the values themselves (a lazily
+    // fusing back end then need not write them to memory: fmhip_vec_give_up_values).  Called for ALL parameter sets of a batch before
+    // the first expectation is enqueued: the launches carry the rows of every set.
+    std::function<void(const std::vector<RV>&)> valuesNotNeeded;
     int chunk = 7;                          // components per multi-output launch (≤ 8 outputs incl. the running sum); used when stepsPerLaunch == 1
     // Euler steps recorded back to back before the engine is asked to execute (hold + one flush per group).  The engine schedules
     // the pending graph of the group component by component (runtime.cpp: build_big, consumers first), finds that the schedule is
@@ -395,6 +399,7 @@ inline PendingValuations evaluateManyBegin(const Market& m, const std::vector<co
         be.hold(false);
         if (!(be.averagesAsync && be.expectationsRunPending)) be.flush();
     }
+    if (be.valuesNotNeeded) for (size_t k = 0; k < K; ++k) be.valuesNotNeeded(values[k]);
     for (size_t k = 0; k < K; ++k) {
         if (be.averagesAsync) pending.expectations.push_back(be.averagesAsync(values[k]));
         else { const std::vector<double> now = be.averages(values[k]); pending.expectations.push_back([now] { return now; }); }

@@ -262,6 +262,15 @@ int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const
 typedef int64_t fmhip_ticket;
 int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out);
 int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count);
+/* For a caller that wants the EXPECTATIONS of vectors and will never read their values — a Monte-Carlo product's payoff, of which
+ * getValue() returns the average.  A vector that is still a pending expression and that only the caller references need then not be
+ * written to memory at all: when a later fmhip_reduce_moments / _batch / _batch_begin runs what is pending, the launch that computes
+ * such a vector takes its moments and drops it (the one store per workgroup behind a chain of reads costs that launch 8-10 % of its
+ * rate).  After this call the values of `vectors` must not be read or used as operands again
+ * (FMHIP_ERR_INVALID_ARGUMENT where the engine has in fact not kept them); their moments stay available; the handles are released
+ * as usual.  Vectors computed already, or referenced by somebody else, are simply left as they are.  The reference has no
+ * counterpart: its getAverage() copies the whole vector to the host (RandomVariableCuda.java:869-878). */
+int fmhip_vec_give_up_values(const fmhip_vec* vectors, int count);
 
 /* Expectation communicator: Monte-Carlo paths sharded over processes (one GPU each) behind an UNCHANGED caller.
  * Every vector of this process holds the paths [rank·n, (rank+1)·n) of a global vector of world·n paths; all element-wise

@@ -68,6 +68,7 @@ final class Native {
 	static native int reduceMomentsBatchDevice(long[] vectors, double[] shiftsOrNull, long deviceOut);
 	// the same reduction in two halves: begin enqueues and returns a ticket (ticket[0]); end waits for that reduction only and retires the ticket
 	static native int reduceMomentsBatchBegin(long[] vectors, double[] shiftsOrNull, long[] ticket);
+	static native int vecGiveUpValues(long[] vectors);
 	static native int reduceMomentsBatchEnd(long ticket, double[] moments4PerVector, int count);
 	// expectation communicator (paths sharded over processes): gatherFunction = address of a C function of type fmhip_gather_fn,
 	// e.g. from an MPI / RCCL helper library; context is handed back to it.  0 removes the communicator.

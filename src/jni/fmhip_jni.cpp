@@ -162,6 +162,11 @@ FMJ(jint, reduceMomentsBatchBegin)(JNIEnv* env, jclass, jlongArray vectors, jdou
     if (st == FMHIP_OK) { const jlong v = (jlong)t; env->SetLongArrayRegion(ticket, 0, 1, &v); }
     return st;
 }
+FMJ(jint, vecGiveUpValues)(JNIEnv* env, jclass, jlongArray vectors) {
+    Pin<jlong> pv(env, vectors, JNI_ABORT);
+    if (!pv.p) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_vec_give_up_values((const fmhip_vec*)pv.p, pv.length());
+}
 FMJ(jint, reduceMomentsBatchEnd)(JNIEnv* env, jclass, jlong ticket, jdoubleArray moments4PerVector, jint count) {
     Pin<jdouble> pm(env, moments4PerVector);
     if (!pm.p || count <= 0 || (int64_t)pm.length() < 4 * (int64_t)count) return FMHIP_ERR_INVALID_ARGUMENT;

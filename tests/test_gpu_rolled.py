@@ -315,3 +315,63 @@ def test_expectations_taken_while_the_caller_is_still_recording(gpu, oracle):
         gpu.flush()
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def test_values_given_up_are_not_stored_and_their_moments_are_the_same(gpu, oracle):
+    """fmhip_vec_give_up_values: a caller that wants only the EXPECTATIONS of its products' payoffs (getValue() = getAverage()) says so; the
+    launch that computes a payoff then takes its moments and stores nothing — long chains through the peeled kernel whose root is not an
+    output, short ones through a program without outputs.  Same moments to the last bit as the stored-and-reduced value; reading a
+    given-up value is an error, asking for its moments again is not; a vector somebody else still uses is kept as it is."""
+    n, periods, products = 30_011, 24, 10
+    rng = np.random.default_rng(77)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods + products)]
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        dev = [gpu.DeviceVector.from_host(x) for x in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+
+        def record(k, short=False):
+            return swaption_like_chain(lambda p: dev[p + k], 3 if short else periods, dnum, 0.02 + 0.001 * k, 0.5)
+
+        def all_chains():
+            soft = gpu.fusion_hold(2)
+            chains = [record(k) for k in range(products)] + [record(k, short=True) for k in range(products)]
+            gpu.fusion_hold(soft)
+            return chains
+        want = None
+        for attempt in range(3):                              # reference: stored, then their moments (attempt 0 meets the shapes for the first time)
+            chains = all_chains()
+            ticket = gpu.reduce_moments_batch_begin(chains)
+            want = [(m.sum, m.sumsq, m.min, m.max) for m in gpu.reduce_moments_batch_end(ticket, len(chains))]
+            stored = [c.to_float32() for c in chains]
+        assert all(np.isfinite(w[0]) for w in want)
+        for attempt in range(3):                              # the same, values given up
+            chains = all_chains()
+            kept = chains[3].v1s1("MULT_S", 2.0)              # somebody else uses chain 3: it is NOT given up in effect
+            gpu.give_up_values(chains)
+            ticket = gpu.reduce_moments_batch_begin(chains)
+            got = [(m.sum, m.sumsq, m.min, m.max) for m in gpu.reduce_moments_batch_end(ticket, len(chains))]
+            assert [np.array(g).tobytes() for g in got] == [np.array(w).tobytes() for w in want], attempt
+            assert_bits_equal(kept.to_float32(), oracle.f_v1s1("MULT_S", stored[3], 2.0), "a consumer of a payoff that was not given up in effect")
+            assert_bits_equal(chains[3].to_float32(), stored[3], "… which is still there")
+            m = chains[5].moments()                           # asked again, one at a time: from the node
+            assert (m.sum, m.sumsq, m.min, m.max) == want[5]
+            if attempt == 2:                                  # the shapes' kernels exist: nothing was stored for the given-up payoffs …
+                gone = 0
+                for k, c in enumerate(chains):
+                    if k == 3: continue
+                    try:
+                        values = c.to_float32()               # … so reading one is an error (or, had the engine kept it, the right value)
+                        assert_bits_equal(values, stored[k], "a kept value")
+                    except gpu.FmhipError as e:
+                        assert e.code == gpu._native.ERR_INVALID_ARGUMENT and "given up" in str(e)
+                        gone += 1
+                assert gone >= products, "the long chains' payoffs, at least, were not stored"
+                with pytest.raises(gpu.FmhipError):
+                    chains[0].v1s1("ADD_S", 1.0)              # nor can it be an operand
+            del chains, kept
+        gpu.flush()
+    finally:
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)
