@@ -202,6 +202,13 @@ def jit_wait() -> None:
     _native.check(lib().fmhip_jit_wait())
 
 
+def traffic_stats() -> tuple:
+    """(algorithmic bytes of all launches so far: 4 B x paths x (vectors read + vectors stored) per launch, launches on specialised kernels)."""
+    b, l = _C.c_int64(0), _C.c_int64(0)
+    _native.check(lib().fmhip_traffic_stats(_C.byref(b), _C.byref(l)))
+    return b.value, l.value
+
+
 def jit_stats() -> dict:
     c, f, p, s, d = _C.c_int64(0), _C.c_int64(0), _C.c_int64(0), _C.c_double(0), _C.c_int64(0)
     _native.check(lib().fmhip_jit_stats(_C.byref(c), _C.byref(f), _C.byref(p), _C.byref(s), _C.byref(d)))
