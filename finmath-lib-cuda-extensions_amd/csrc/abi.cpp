@@ -5,6 +5,7 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace fm { void mersenne_increments(int32_t, int, int, int64_t, const double*, double*); double inverse_normal_cdf(double); }
@@ -39,7 +40,17 @@ static void need(const void* p, const char* what) {
 extern "C" {
 
 int fmhip_init(int device_index) { return guarded([&] { Engine::get().init(device_index); }); }
-int fmhip_shutdown(void) { return guarded([&] { Engine::get().shutdown(); }); }
+int fmhip_shutdown(void) {
+    // a thread that waits for its moments outside the lock still holds a result slot, a pinned block or an event of this engine: the
+    // teardown starts when the last such wait is over (they end by themselves: the device finishes what was launched)
+    for (;;) {
+        {
+            std::lock_guard<std::recursive_mutex> lock(Engine::get().mu);
+            if (Engine::get().waits_in_flight.load(std::memory_order_acquire) == 0) return guarded([&] { Engine::get().shutdown(); });
+        }
+        std::this_thread::yield();
+    }
+}
 int fmhip_is_initialized(void) { return Engine::get().initialized() ? 1 : 0; }
 int fmhip_abi_version(void) { return FMHIP_ABI_VERSION; }
 const char* fmhip_last_error(void) { return g_last_error.c_str(); }
@@ -188,10 +199,10 @@ int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int coun
 // own; this thread polls its flag, then takes the lock again to copy them out and give the launch's buffers back.
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     Engine::RedLaunch pending;
-    int rc = guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr, &pending); });
+    int rc = guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr, &pending); if (pending.pending) Engine::get().waits_in_flight.fetch_add(1, std::memory_order_acq_rel); });
     if (rc == FMHIP_OK && pending.pending) {
         const bool arrived = Engine::red_poll(pending);
-        rc = guarded([&] { Engine::get().red_complete(pending, arrived); });
+        rc = guarded([&] { Engine& e = Engine::get(); struct Done { Engine& e; ~Done() { e.waits_in_flight.fetch_sub(1, std::memory_order_acq_rel); } } done{ e }; e.red_complete(pending, arrived); });
     }
     if (rc == FMHIP_OK) rc = guarded([&] { exchange_moments(Engine::get(), out, 1); });
     return rc;
@@ -216,8 +227,10 @@ int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int 
         e.require_init();
         t = e.ticket_take(ticket);
         if (t.count != count) { const int have = t.count; e.ticket_retire(t); throw Error(FMHIP_ERR_SIZE_MISMATCH, "the ticket holds " + std::to_string(have) + " expectations, the caller asks for " + std::to_string(count)); }
+        e.waits_in_flight.fetch_add(1, std::memory_order_acq_rel);       // this thread holds the ticket's block and event outside the lock from here on
     });
     if (rc != FMHIP_OK) return rc;
+    struct Done { ~Done() { Engine::get().waits_in_flight.fetch_sub(1, std::memory_order_acq_rel); } } done;
     // (a ticket whose moments came with the launches that computed the vectors has them already: ticket_take waited for their slots)
     const hipError_t waited = t.event && t.ready.empty() ? hipEventSynchronize(t.event) : hipSuccess;      // without the engine lock: other threads (and this one's next parameter set) are not held up
     if (waited == hipSuccess) std::memcpy(out, t.ready.empty() ? t.host : (const void*)t.ready.data(), (size_t)count * sizeof(fmhip_moments));

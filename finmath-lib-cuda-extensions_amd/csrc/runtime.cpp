@@ -48,6 +48,10 @@ static size_t round_cap(size_t bytes) {
 void* Pool::alloc(size_t bytes, size_t* cap_out) {
     const size_t cap = round_cap(bytes);
     *cap_out = cap;
+    // test hook (tests/test_gpu_replicas.py): the N-th allocation of the process fails like a device that is out of memory
+    static const long long FAIL_AT = [] { const char* e = std::getenv("FMHIP_TEST_FAIL_ALLOC_AT"); return e ? std::atoll(e) : 0ll; }();
+    static long long calls = 0;
+    if (FAIL_AT > 0 && ++calls == FAIL_AT) throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation failed (FMHIP_TEST_FAIL_ALLOC_AT)");
     std::vector<void*>& fl = free_[cap];
     if (!fl.empty()) {
         void* p = fl.back();
@@ -177,7 +181,7 @@ void Engine::init(int device_index) {
     g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr;
     for (const char* name : { "FMHIP_BM_GROUP_STEPS", "FMHIP_GROUP_STEPS" })       // (the first: where round 2 had this, in BrownianMotionHip)
         if (const char* e = std::getenv(name)) { const int v = std::atoi(e); if (v >= 0) group_steps = v; }
-    group_bm_id_ = 0; group_last_step_ = -1; group_steps_pending_ = 0; group_hold_ = false;
+    group_bm_id_ = 0; group_last_step_ = -1; group_steps_pending_ = 0; group_hold_ = false; group_last_by_bm_.clear();
     if (const char* e = std::getenv("FMHIP_FUSION_MAX_WEIGHT")) { const int v = std::atoi(e); if (v > 0) fusion_max_weight_override(v); }
     initialized_ = true;
 }
@@ -923,7 +927,7 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     Node* ins[3] = { nullptr, nullptr, nullptr };
     for (int i = 0; i < n_in; ++i) {
         ins[i] = node(in[i]);
-        if (ins[i]->discarded && !ins[i]->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of an operand was given up (fmhip_reduce_moments_batch_begin_discarding): only its moments exist");
+        if (ins[i]->discarded && !ins[i]->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of an operand does not exist: it was given up (fmhip_vec_give_up_values), or lost in a launch that failed");
     }
     if (!replicas_.empty())                                     // an operation on the root of a copy that exists as a description only: the copy becomes an expression first
         for (int i = 0; i < n_in; ++i) if (!ins[i]->buf && ins[i]->rep_copy) if (ReplicaGroup* g = replica_of(ins[i])) expand_replicas(g);
@@ -975,13 +979,25 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
 // Index 0, or an index below the last one, starts a new simulation; the last index ends the grouping — what follows the
 // simulation is not the scheme's to group.
 void Engine::step_boundary(const Node* inc) {
-    ops_since_boundary_ = 0;
-    const bool restart = inc->bm_id != group_bm_id_ || inc->bm_step <= group_last_step_ || inc->bm_step == 0;
+    // Per generation: the time index it was last used with.  A generation that goes BACK (or starts at index 0) begins a new simulation;
+    // another generation at the time index just seen is the second Brownian motion of a hybrid model inside the same time step — not a
+    // boundary; and two simulations that take turns (two threads, two models) do not reset each other's count any more: until round 4 the
+    // state was one (generation, index) pair, every change of generation was a "restart", and such callers never reached a flush of
+    // their own (results unaffected; the work ran at the 32768-operation cap instead, in shapes that never repeat).
+    if (group_last_by_bm_.size() > 64) group_last_by_bm_.clear();
+    auto known = group_last_by_bm_.find(inc->bm_id);
+    const int32_t last_of_this = known == group_last_by_bm_.end() ? -1 : known->second;
+    if (inc->bm_step == last_of_this) { group_bm_id_ = inc->bm_id; group_last_step_ = inc->bm_step; return; }      // this generation's current time step again (the generations of a hybrid model take turns)
+    const bool restart = inc->bm_step == 0 || inc->bm_step < last_of_this;
+    const bool same_time_index = !restart && inc->bm_id != group_bm_id_ && inc->bm_step == group_last_step_;
+    group_last_by_bm_[inc->bm_id] = inc->bm_step;
     group_bm_id_ = inc->bm_id; group_last_step_ = inc->bm_step;
+    if (same_time_index) return;
+    ops_since_boundary_ = 0;
     if (restart) group_steps_pending_ = 0;
     if (group_steps_pending_ == 0) group_hold_ = true;
     if (++group_steps_pending_ > group_steps) { flush_all(); group_steps_pending_ = 1; }
-    if (inc->bm_step == inc->bm_steps - 1) { group_steps_pending_ = 0; group_last_step_ = -1; group_bm_id_ = 0; group_hold_ = false; }
+    if (inc->bm_step == inc->bm_steps - 1) { group_steps_pending_ = 0; group_last_step_ = -1; group_bm_id_ = 0; group_hold_ = false; group_last_by_bm_.erase(inc->bm_id); }
 }
 
 // ---------------------------------------------------------------- replication of pending graphs (fmhip_graph_clone)
@@ -1177,6 +1193,27 @@ void Engine::replica_roots_done(ReplicaGroup* g, const std::vector<int>& done) {
         if (--root->refs_ext == 0) { nodes_.erase(root->id); node_maybe_free(root); }
     }
     if (g->remaining == 0) destroy_replica_group(g);
+}
+
+// A launch sequence that was to execute these roots with their copies has FAILED midway (a device allocation, a HIP error): some
+// parts or segments have committed buffers, the rest has not run.  A root whose ORIGINAL has its buffer is closed here like an executed
+// one — its holds go, so the group can end and nothing leaks — and every copy of it that did NOT get its buffer is marked as lost:
+// reading it is an error from now on, never a silently wrong value (a later expansion of the description skips a materialised original
+// and would wire the copies' dependants to the original's vector).  Roots that have not run at all stay described, as before.
+void Engine::replicas_after_failure(const std::vector<std::pair<ReplicaGroup*, std::vector<int>>>& done) {
+    for (const auto& kv : done) {
+        ReplicaGroup* g = kv.first;
+        bool alive = false;
+        for (const auto& r : replicas_) alive |= r.second == g;
+        if (!alive) continue;
+        std::vector<int> closed;
+        for (int r : kv.second) {
+            if (r < 0 || r >= g->n_roots || g->root_done[(size_t)r] || !g->roots[(size_t)r] || !g->roots[(size_t)r]->buf) continue;
+            for (int j = 0; j < g->n_copies; ++j) { Node* c = g->copy_roots[(size_t)j * g->n_roots + (size_t)r]; if (c && !c->buf) c->discarded = true; }
+            closed.push_back(r);
+        }
+        if (!closed.empty()) replica_roots_done(g, closed);
+    }
 }
 
 // Fallback: the description becomes ordinary pending nodes (what graph_clone made before descriptions existed), for the roots that
@@ -2348,7 +2385,7 @@ bool Engine::try_fused(const std::vector<Node*>& roots) {
 
 void Engine::materialize(const std::vector<Node*>& targets) {
     for (Node* t : targets)
-        if (t->discarded && !t->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of this vector was given up (fmhip_reduce_moments_batch_begin_discarding): only its moments exist");
+        if (t->discarded && !t->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of this vector does not exist: it was given up (fmhip_vec_give_up_values: only its moments were taken), or lost in a launch that failed");
     expand_replicas_below(targets);                 // a single expression is executed, not everything pending: descriptions of copies it touches become nodes first
     for (Node* t : targets) {
         if (t->buf) continue;
@@ -2446,10 +2483,12 @@ void Engine::flush_all() {
             }
             const size_t max_batch = 1024;
             bool ran = true;
-            for (size_t off = 0; off < members.size(); off += max_batch) {
-                std::vector<Dag> part(std::make_move_iterator(members.begin() + off), std::make_move_iterator(members.begin() + std::min(members.size(), off + max_batch)));
-                if (!run_dags(part, nullptr, nullptr, nullptr, &proto)) { ran = false; for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r); }
-            }
+            try {
+                for (size_t off = 0; off < members.size(); off += max_batch) {
+                    std::vector<Dag> part(std::make_move_iterator(members.begin() + off), std::make_move_iterator(members.begin() + std::min(members.size(), off + max_batch)));
+                    if (!run_dags(part, nullptr, nullptr, nullptr, &proto)) { ran = false; for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r); }
+                }
+            } catch (...) { replicas_after_failure(done); throw; }
             if (ran) for (auto& kv : done) replica_roots_done(kv.first, kv.second);
         }
         // components that do not fit one launch: cut into segments; components of identical shape share the cuts and the launches
@@ -2516,7 +2555,8 @@ void Engine::flush_all() {
                         members.push_back(std::move(r));
                     }
                 }
-                run_big_group(members);
+                try { run_big_group(members); }
+                catch (...) { replicas_after_failure(done); throw; }
                 for (auto& kv : done) replica_roots_done(kv.first, kv.second);
             }
         }

@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <memory>
@@ -194,6 +195,9 @@ class Engine {
 public:
     static Engine& get();
     std::recursive_mutex mu;
+    // Callers that wait for moments WITHOUT the engine lock (abi.cpp: fmhip_reduce_moments, fmhip_reduce_moments_batch_end) hold slots,
+    // pinned blocks and events of this engine meanwhile: counted here (under the lock, before it is dropped); fmhip_shutdown waits for zero.
+    std::atomic<int> waits_in_flight{ 0 };
 
     void init(int device_index);
     void shutdown();
@@ -444,6 +448,7 @@ private:
     // the engine itself is holding pending work back for a group
     uint32_t next_bm_id_ = 1, group_bm_id_ = 0;
     int32_t  group_last_step_ = -1;
+    std::unordered_map<uint32_t, int32_t> group_last_by_bm_;     // per generation: the time index of its increment seen last (step_boundary)
     int      group_steps_pending_ = 0;
     bool     group_hold_ = false;
     void step_boundary(const Node* increment);
@@ -452,6 +457,7 @@ private:
     void expand_replicas_below(const std::vector<Node*>& targets);   // every group the pending graph below `targets` touches
     void replica_roots_done(ReplicaGroup* g, const std::vector<int>& roots);   // those roots have been executed with all their copies
     void destroy_replica_group(ReplicaGroup* g);
+    void replicas_after_failure(const std::vector<std::pair<ReplicaGroup*, std::vector<int>>>& done);   // a launch sequence over these roots threw midway
     struct ReplicaView;
     std::unordered_map<uint64_t, BigPlan> plan_cache_;                        // component shape -> segments, programs and row-block sources
     bool build_dag(const std::vector<Node*>& roots, Dag& dag);

@@ -333,7 +333,11 @@ public class RandomVariableHip implements RandomVariable {
 		final double[] sample = sortedSample();
 		final int from = quantilePosition(Math.min(quantileStart, quantileEnd), sample.length);
 		final int to = quantilePosition(Math.max(quantileStart, quantileEnd), sample.length);
-		return Arrays.stream(sample, from, to + 1).sum() / (to - from + 1);
+		double sum = 0.0;			// plain left-to-right sum, as the reference and the C++ / Python mirrors (Arrays.stream(...).sum() is compensated: other bits)
+		for(int i = from; i <= to; i++) {
+			sum += sample[i];
+		}
+		return sum / (to - from + 1);
 	}
 
 	@Override

@@ -126,3 +126,39 @@ def test_black_scholes_with_mersenne_brownian_motion(gpu):
     host = gpu.mersenne_increments(31415, [1.0, 1.0], 1, 1000)
     assert (bm.getBrownianIncrement(1, 0).realizations.to_float32()[:1000] == host[1, 0].astype(np.float32)).all()
     assert bm.getBrownianIncrement(1, 0).getFiltrationTime() == 2.0
+
+
+def test_two_brownian_motions_in_one_time_loop_are_grouped_like_one(gpu):
+    """A hybrid model drives two processes with two BrownianMotion objects inside ONE time loop.  The engine's time-step grouping keys
+    its state by generation (runtime.cpp: step_boundary): the second generation at the time index just seen is not a boundary, and
+    neither resets the other's count — so the engine runs what is pending every few time steps WHILE the caller records, exactly as
+    with one generation (until round 4 every change of generation restarted the count and nothing ran before the first read).
+    Same numbers either way."""
+    n, steps, dt = 20_000, 40, 0.05
+    td = gpu.TimeDiscretization(0.0, steps, dt)
+    prev = gpu.set_fusion(True)
+    try:
+        def simulate(two):
+            bm_a = gpu.BrownianMotionHip(td, 1, n, 4711)
+            bm_b = gpu.BrownianMotionHip(td, 1, n, 4712) if two else bm_a
+            bm_a.getBrownianIncrement(0, 0); bm_b.getBrownianIncrement(0, 0)          # generated up front: the launches counted below are the model's
+            gpu.flush()
+            x = bm_a.getRandomVariableForConstant(0.0)
+            y = bm_a.getRandomVariableForConstant(1.0)
+            before = gpu.pool_stats().n_kernel_launches
+            for i in range(steps):
+                da, db = bm_a.getBrownianIncrement(i, 0), bm_b.getBrownianIncrement(i, 0)
+                x = x.addProduct(y, da).add(0.01 * dt)
+                y = y.addProduct(x.mult(0.1), db).floor(0.05)
+                x = x.addProduct(da, 0.2)                                              # (the first generation again within the step)
+            while_recording = gpu.pool_stats().n_kernel_launches - before
+            return x.getAverage(), y.getAverage(), while_recording
+        one = simulate(False)
+        two = simulate(True)
+        assert one[2] >= steps // 4 - 2, "one generation: a flush every four time steps while the caller records"
+        assert two[2] >= steps // 4 - 2, "two generations: the same"
+        assert two[2] <= 4 * one[2] + 8
+        again = simulate(True)
+        assert again[:2] == two[:2]
+    finally:
+        gpu.set_fusion(prev)

@@ -215,3 +215,76 @@ def test_nothing_leaks(data):
         del roots
         copies = None
         assert gpu.pool_stats().n_live_vectors == live0
+
+
+_FAILURE_SCRIPT = r'''
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+fm.init(0)
+fm.set_fusion(True)
+n, copies = 257, 1100                                   # more members than one launch part takes (1024): two parts
+rng = np.random.default_rng(5)
+x0, y0 = rng.uniform(0.5, 1.5, n).astype(np.float32), rng.uniform(0.5, 1.5, n).astype(np.float32)
+xs = [fm.DeviceVector.from_host(x0 * np.float32(1.0 + 0.001 * j)) for j in range(copies + 1)]
+y = fm.DeviceVector.from_host(y0)
+def chain(x):
+    t = x.v2s1("ACCRUE", y, 0.5)
+    return [t, t.v1s1("ADD_S", 1.0).v2s0("MULT", y)]            # two roots: the second depends on the first
+want = []
+for j in range(copies + 1):                              # eager reference (counted by the failure hook as well: it is armed far behind these)
+    prev = fm.set_fusion(False)
+    want.append([r.to_float32() for r in chain(xs[j])])
+    fm.set_fusion(True)
+with fm.holding():
+    roots = chain(xs[0])
+    clones = fm.graph_clone(roots, copies, [xs[0]], [[xs[j]] for j in range(1, copies + 1)])
+st = fm.pool_stats(); allocs_before = st.n_alloc_hits + st.n_alloc_misses
+failed = None
+try:
+    fm.flush()
+except fm.FmhipError as e:
+    failed = e.code
+wrong = lost = right = 0
+for j in range(copies + 1):
+    for r, v in enumerate(roots if j == 0 else clones[j - 1]):
+        try:
+            got = v.to_float32()
+        except fm.FmhipError as e:
+            lost += 1
+            continue
+        if got.tobytes() == want[j][r].tobytes(): right += 1
+        else: wrong += 1
+print(json.dumps({"failed": failed, "wrong": wrong, "lost": lost, "right": right, "allocs_before": allocs_before}))
+'''
+
+
+def test_a_failure_between_the_parts_of_a_replicated_launch_never_yields_a_wrong_copy(gpu, tmp_path):
+    """An allocation that fails while a replicated graph runs in several parts (more than 1024 members): the parts that ran have
+    committed their buffers, the others have not.  Afterwards every value of the original and of every copy is either RIGHT (it was
+    computed, or it can still be computed from the description) or reading it is an error — never a wrong number; and the group's
+    holds are gone (the process ends without leaking into the next allocation).  The hook FMHIP_TEST_FAIL_ALLOC_AT makes the N-th
+    allocation of the child process fail; several N cover failures in the first part, between the parts and in the second."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "fail.py"
+    script.write_text(_FAILURE_SCRIPT % {"root": root})
+    def child(fail_at):
+        env = dict(os.environ, FMHIP_TEST_FAIL_ALLOC_AT=str(fail_at), FMHIP_JIT="off")
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    probe = child(10**12)                                 # never fails: how many allocations precede the flush
+    assert probe["failed"] is None and probe["wrong"] == 0 and probe["lost"] == 0
+    base = probe["allocs_before"]
+    seen_failure = 0
+    for extra in (1, 200, 1000, 1030, 1500, 2040, 2100, 2199):      # 2 x 1101 buffers in two parts of 1024 and 77 members
+        out = child(base + extra)
+        assert out["wrong"] == 0, (extra, out)
+        assert out["right"] + out["lost"] == 2 * 1101
+        if out["failed"] is not None:
+            seen_failure += 1
+        else:
+            assert out["lost"] == 0
+    assert seen_failure >= 2, "the sweep must hit the flush at least twice"
