@@ -468,6 +468,65 @@ __device__ __forceinline__ void ueval_div_all(float (&out)[E], const float (&acc
     }
 }
 
+// pow with a WAVE-UNIFORM exponent (a scalar operand of the row block), all E elements of a lane: the exponents Monte-Carlo code
+// actually writes take code of their own, chosen ONCE per micro-op by a scalar comparison — the out-of-line fp64 library path (pow_f:
+// ≈ 75 fp64 instructions and a call per element, 2.2-2.35 TB/s for the opcode alone) is left for everything else.  Each special form
+// returns (float)Math.pow((double)a, (double)s) bit for bit (all 2^32 arguments per exponent against the oracle:
+// profiles/round04_exhaustive_pow.json):
+//   s = 2      a·a in fp32: the exact square of a 24-bit number has 48 bits, so the fp64 product is exact and its narrowing IS the fp32 product
+//   s = 0.5    the correctly rounded fp32 square root (sqrt_all), except that pow(-0, 0.5) = +0 and pow(-inf, 0.5) = +inf (C99 / Java)
+//   s = -1     the correctly rounded fp32 quotient 1 / a (double rounding is innocuous for a quotient: 53 >= 2·24 + 2)
+//   s = 3, 4, -2, 1.5, 2.5   the fp64 forms of pow_f, inline (1.5 and 2.5: positive bases; a wave that holds any other base calls the library for those lanes)
+template <int E>
+__device__ __forceinline__ void pow_all(float (&a)[E], const float s) {
+    if (s == 2.0f) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = a[j] * a[j];
+    } else if (s == 0.5f) {
+        float y[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) y[j] = a[j];
+        sqrt_all<E>(y);
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = (a[j] == -__builtin_huge_valf()) ? __builtin_huge_valf() : __builtin_fabsf(y[j]);
+    } else if (s == -1.0f) {
+        if constexpr (E % 2 == 0) { float q[E]; ueval_div_all<U_INVERT, E>(q, a, nullptr, nullptr, 0.f);
+#pragma unroll
+            for (int j = 0; j < E; ++j) a[j] = q[j]; }
+        else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) a[j] = 1.0f / a[j]; }
+    } else if (s == 3.0f) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { const double x = (double)a[j]; a[j] = (float)((x * x) * x); }
+    } else if (s == 4.0f) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { const double x = (double)a[j], t = x * x; a[j] = (float)(t * t); }
+    } else if (s == -2.0f) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { const double x = (double)a[j]; a[j] = (float)(1.0 / (x * x)); }
+    } else if (s == 1.5f || s == 2.5f) {     // x^k·sqrt(x) for positive bases (pow_f's own form); any other base in the wave: the library's business, lane by lane
+        float y[E];
+        bool positive = true;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double x = (double)a[j], r = __builtin_sqrt(x);
+            y[j] = (float)(s == 1.5f ? x * r : (x * x) * r);
+            positive = positive && a[j] > 0.0f;
+        }
+        if (__builtin_amdgcn_ballot_w64(!positive) != 0ull) {
+            asm volatile("; pow: a base that is not positive: library path for that lane");
+#pragma unroll
+            for (int j = 0; j < E; ++j) y[j] = a[j] > 0.0f ? y[j] : pow_f(a[j], s);
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = y[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = pow_f(a[j], s);
+    }
+}
+
 // One element of one micro-op (fm_program.h: UOp), micro-op known at compile time: the interpreter switches
 // once per instruction on the wave-uniform code and evaluates all of a thread's elements with ueval<CODE>.
 //   acc = accumulator, r1/r2 = fetched register operands, s = narrowed scalar.

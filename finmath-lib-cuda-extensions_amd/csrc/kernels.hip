@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(FM_BLOCK) __attribute__((amdgpu_waves_per_eu(4
                     // them are compiled for the 4-element / 16-register variant (runtime.cpp: compile()).
                     if constexpr (E == 4) {
                         switch (code) {
-                            FM_U0(U_SIN) FM_U0(U_COS) FM_U0(U_POW_S)
+                            FM_U0(U_SIN) FM_U0(U_COS)
+                            case U_POW_S: pow_all<E>(a, s); break;       // wave-uniform exponent: the common ones take code of their own (fm_device_math.hpp)
                             default: break;
                         }
                     }
