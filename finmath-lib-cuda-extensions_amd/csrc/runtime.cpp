@@ -161,6 +161,8 @@ void Engine::init(int device_index) {
     hip_check(hipMalloc(&ring_dev_, ring_cap_ + 256), "hipMalloc(ring)");
     hip_check(hipMalloc(&dump_dev_, FM_DUMP_BYTES), "hipMalloc(dump)");
     hip_check(hipHostMalloc((void**)&result_slots_, (size_t)RESULT_SLOTS * 128, hipHostMallocDefault), "hipHostMalloc(result slots)");
+    ARENA_BYTES = size_t(16) << 20;
+    if (const char* e = std::getenv("FMHIP_ARENA_BYTES")) { const long long v = std::atoll(e); if (v >= 1024) ARENA_BYTES = ((size_t)v + 31) & ~size_t(31); }      // tests: a wrap after a few dozen expectations
     hip_check(hipHostMalloc((void**)&moments_arena_, ARENA_BYTES, hipHostMallocDefault), "hipHostMalloc(moments arena)");
     arena_off_ = 0; arena_outstanding_.clear();
     free_slots_.clear();

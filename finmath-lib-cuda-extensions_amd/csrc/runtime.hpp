@@ -421,7 +421,7 @@ private:
     bool async_moments_ = false;
     size_t ops_since_boundary_ = 0;                              // methods recorded since the last time-step boundary (step_boundary)
     char* moments_arena_ = nullptr; size_t arena_off_ = 0;
-    static constexpr size_t ARENA_BYTES = size_t(16) << 20;       // 512 k slots: a wrap waits for the stream, so it should be rare (a 1 M-path calibration uses 89 k)
+    size_t ARENA_BYTES = size_t(16) << 20;                        // 512 k slots: a wrap waits for the stream, so it should be rare (a 1 M-path calibration uses 89 k); FMHIP_ARENA_BYTES: tests shrink it
     static constexpr uint64_t MOMENTS_SENTINEL = 0x7ff8dead0000beefull;
     std::vector<std::pair<int64_t, volatile uint64_t*>> arena_outstanding_;
     double* arena_alloc(size_t count);                           // count slots, preset; may synchronise the stream (arena full)

@@ -1,0 +1,296 @@
+// drive.cpp — drives the engine's host runtime through its C-ABI on the TEST-ONLY null device (null_hip.cpp) under the sanitizers:
+// the graph shapes of the GPU tests — record / flush / clone / expand / release in the orders of tests/test_gpu_replicas.py, long
+// chains through segments, rolled and peeled plans, expectations taken along, values given up, tickets begun and ended out of order,
+// the row-table ring and the moments arena wrapping at tiny sizes, a failing allocation in the middle of a replicated launch, eight
+// threads as tests/test_gpu_threads.py, shutdown and re-initialisation.  Nothing is computed: statuses are checked, the sanitizers do
+// the rest.   usage: drive [scenario …]   (none = all)
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fmhip.h"
+
+#define OK(x) do { const int st_ = (x); if (st_ != FMHIP_OK) { std::fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, st_, fmhip_last_error()); std::abort(); } } while (0)
+#define EXPECT(x, code) do { const int st_ = (x); if (st_ != (code)) { std::fprintf(stderr, "%s:%d: %s -> %d, expected %d (%s)\n", __FILE__, __LINE__, #x, st_, (int)(code), fmhip_last_error()); std::abort(); } } while (0)
+
+typedef fmhip_vec V;
+static V filled(int64_t n, double v) { V h = 0; OK(fmhip_vec_create_filled(n, v, &h)); return h; }
+static V u1(int op, V a) { V o = 0; OK(fmhip_call_v1s0(op, a, &o)); return o; }
+static V s1(int op, V a, double s) { V o = 0; OK(fmhip_call_v1s1(op, a, s, &o)); return o; }
+static V b2(int op, V a, V b) { V o = 0; OK(fmhip_call_v2s0(op, a, b, &o)); return o; }
+static V s2(int op, V a, V b, double s) { V o = 0; OK(fmhip_call_v2s1(op, a, b, s, &o)); return o; }
+static void rel(V h) { OK(fmhip_vec_release(h)); }
+static void rel(std::vector<V>& v) { for (V h : v) rel(h); v.clear(); }
+
+// tests/test_gpu_replicas.py: record() — two roots sharing an inner value; long_chain() — a backward induction of `periods` periods
+static std::vector<V> record(const V* vecs, V shared, const double* s, std::vector<V>* inner = nullptr) {
+    const V d = s2(FMHIP_OP_DISCOUNT, vecs[0], vecs[1], s[0]), t = s1(FMHIP_OP_MULT_S, d, s[1]);
+    rel(d);
+    const V ap = s2(FMHIP_OP_ADDPRODUCT_VS, t, shared, s[2]), u = b2(FMHIP_OP_ADD, ap, vecs[2]);
+    rel(ap);
+    if (inner) inner->push_back(t); else rel(t);
+    const V f = s1(FMHIP_OP_FLOOR_S, u, s[3]), w = u1(FMHIP_OP_SQUARED, f);
+    rel(f);
+    return { u, w };
+}
+static std::vector<V> long_chain(const V* vecs, V shared, const double* s, int periods = 30) {
+    V value = 0;
+    for (int p = 0; p < periods; ++p) {
+        V libor = vecs[p % 3];
+        bool own = false;
+        if (p % 5 == 0) { libor = s1(FMHIP_OP_MULT_S, vecs[p % 3], 1.0 + 0.013 * p); own = true; }
+        const V a = s1(FMHIP_OP_SUB_S, libor, s[0]), payoff = s1(FMHIP_OP_MULT_S, a, s[1]);
+        rel(a);
+        V next = payoff;
+        if (value) { next = b2(FMHIP_OP_ADD, value, payoff); rel(value); rel(payoff); }
+        value = s2(FMHIP_OP_DISCOUNT, next, libor, s[2]);
+        rel(next);
+        if (own) rel(libor);
+    }
+    const V fl = s1(FMHIP_OP_FLOOR_S, value, 0.0), ex = u1(FMHIP_OP_EXP, shared), out = b2(FMHIP_OP_DIV, fl, ex);
+    rel(value); rel(fl); rel(ex);
+    return { out };
+}
+
+struct Inputs { std::vector<std::vector<V>> dev; V shared = 0; std::vector<std::vector<double>> scal; int copies; int64_t n; };
+static Inputs make_inputs(int64_t n, int copies) {
+    Inputs in; in.copies = copies; in.n = n;
+    for (int j = 0; j <= copies; ++j) { in.dev.push_back({ filled(n, 0.5 + j), filled(n, 1.0 + 0.1 * j), filled(n, 0.75) }); in.scal.push_back({ 0.5 + 0.1 * j, 1.25 - 0.05 * j, 0.25, 0.3 + j }); }
+    in.shared = filled(n, 0.1);
+    return in;
+}
+static void free_inputs(Inputs& in) { for (auto& r : in.dev) rel(r); rel(in.shared); in.dev.clear(); }
+static void read_all(const std::vector<V>& vs, int64_t n) { std::vector<float> h((size_t)n); for (V v : vs) OK(fmhip_vec_read_float(v, h.data(), n)); }
+
+typedef std::function<std::vector<V>(const V*, V, const double*)> Chain;
+// the original recorded, `copies` copies as a description; what happens before the flush is the case
+static void replica_case(const Chain& chain, int which, bool jit_sync) {
+    Inputs in = make_inputs(/*n*/ 1031, /*copies*/ 4);
+    int prev = 0;
+    OK(fmhip_set_jit(jit_sync ? FMHIP_JIT_SYNC : FMHIP_JIT_OFF, &prev));
+    OK(fmhip_fusion_hold(1, nullptr));
+    std::vector<V> roots = chain(in.dev[0].data(), in.shared, in.scal[0].data());
+    const int n_roots = (int)roots.size(), n_map = 3;
+    std::vector<V> from(in.dev[0]), to, out((size_t)n_roots * in.copies);
+    std::vector<double> sc;
+    int n_scal = 0;
+    OK(fmhip_graph_scalars(roots.data(), n_roots, nullptr, 0, &n_scal));
+    std::vector<double> recorded((size_t)n_scal);
+    OK(fmhip_graph_scalars(roots.data(), n_roots, recorded.data(), n_scal, &n_scal));
+    for (int j = 1; j <= in.copies; ++j) { for (V v : in.dev[(size_t)j]) to.push_back(v); for (int k = 0; k < n_scal; ++k) sc.push_back(recorded[(size_t)k] * (1.0 + 0.01 * j)); }
+    OK(fmhip_graph_clone(roots.data(), n_roots, in.copies, from.data(), to.data(), n_map, sc.data(), n_scal, out.data()));
+    std::vector<V> extra;
+    switch (which) {
+    case 0: break;                                                                  // flushed as recorded: the copies run as rows of the original's launches
+    case 1: extra.push_back(s1(FMHIP_OP_ADD_S, roots[0], 1.0)); break;                // an operation on top of the original
+    case 2: extra.push_back(s1(FMHIP_OP_MULT_S, out[0], 2.0)); break;                 // a copy used before the flush
+    case 3: { std::vector<V> again((size_t)n_roots * 2); std::vector<V> to2;         // a copy of a copy
+              for (int j = 0; j < 2; ++j) for (V v : in.dev[(size_t)j + 1]) to2.push_back(v);
+              OK(fmhip_graph_clone(out.data(), n_roots, 2, in.dev[1].data(), to2.data(), n_map, nullptr, 0, again.data()));
+              for (V v : again) extra.push_back(v); break; }
+    case 4: rel(roots); break;                                                        // the original's handles released before the flush
+    case 5: for (V& v : out) { rel(v); v = 0; } break;                                // all copies released before the flush
+    case 6: { std::vector<float> h(1031); OK(fmhip_vec_read_float(out.back(), h.data(), 1031)); break; }   // one copy read (materialised on its own)
+    case 7: rel(out[1]); out[1] = 0; break;                                           // one copy released
+    case 8: { fmhip_moments m; OK(fmhip_reduce_moments(out[0], 0.0, &m)); break; }   // the expectation of a copy asked for under the hold
+    case 9: OK(fmhip_vec_retain(roots[0])); extra.push_back(roots[0]); break;         // a second handle on an original root
+    }
+    OK(fmhip_fusion_hold(0, nullptr));
+    OK(fmhip_flush());
+    read_all(roots, in.n);
+    for (V v : out) if (v) { std::vector<float> h((size_t)in.n); OK(fmhip_vec_read_float(v, h.data(), in.n)); }
+    read_all(extra, in.n);
+    rel(roots); for (V v : out) if (v) rel(v);
+    rel(extra);
+    free_inputs(in);
+    OK(fmhip_set_jit(prev, nullptr));
+}
+
+static void scenario_basic() {
+    const int64_t n = 777;
+    V a = filled(n, 1.5), b = filled(n, 0.5);
+    std::vector<double> host((size_t)n, 0.25);
+    V c = 0; OK(fmhip_vec_create_from_double(host.data(), n, &c));
+    for (int fusion = 0; fusion < 2; ++fusion) {
+        OK(fmhip_set_fusion(fusion, nullptr));
+        V t = b2(FMHIP_OP_ADD, a, b), u = s1(FMHIP_OP_DIV_S, t, 2.0), w = u1(FMHIP_OP_EXP, u), x = s2(FMHIP_OP_ACCRUE, w, c, 0.5);
+        fmhip_moments m; OK(fmhip_reduce_moments(x, 0.0, &m)); OK(fmhip_reduce_moments(x, 0.5, &m));
+        std::vector<double> out((size_t)n); OK(fmhip_vec_read_double(x, out.data(), n));
+        V both[2] = { x, w }; fmhip_moments mm[2]; OK(fmhip_reduce_moments_batch(both, 2, nullptr, mm));
+        rel(t); rel(u); rel(w); rel(x);
+    }
+    EXPECT(fmhip_vec_release(123456789), FMHIP_ERR_INVALID_HANDLE);
+    V bad = 0; EXPECT(fmhip_call_v2s0(FMHIP_OP_ADD, a, filled(3, 1.0), &bad), FMHIP_ERR_SIZE_MISMATCH);
+    rel(a); rel(b); rel(c);
+    OK(fmhip_flush()); OK(fmhip_pool_clean()); OK(fmhip_pool_purge());
+}
+
+static void scenario_replicas() {
+    OK(fmhip_set_fusion(1, nullptr));
+    for (int jit = 0; jit < 2; ++jit)
+        for (int which = 0; which < 10; ++which) {
+            replica_case([](const V* v, V sh, const double* s) { return record(v, sh, s); }, which, jit != 0);
+            replica_case([](const V* v, V sh, const double* s) { return long_chain(v, sh, s); }, which, jit != 0);
+            replica_case([](const V* v, V sh, const double* s) { return long_chain(v, sh, s); }, which, jit != 0);     // the shape's plan exists now
+        }
+    OK(fmhip_pool_purge());
+}
+
+// expectations: taken along by the flush, values given up, tickets out of order, the arena wrapping (FMHIP_ARENA_BYTES is tiny here)
+static void scenario_expectations() {
+    OK(fmhip_set_fusion(1, nullptr));
+    int prev = 0; OK(fmhip_set_jit(FMHIP_JIT_SYNC, &prev));
+    Inputs in = make_inputs(2049, 2);
+    std::vector<fmhip_ticket> tickets;
+    std::vector<int> counts;
+    for (int round = 0; round < 12; ++round) {
+        OK(fmhip_fusion_hold(2, nullptr));
+        std::vector<V> payoffs;
+        for (int k = 0; k < 9; ++k) {
+            std::vector<double> s = { 0.02 + 0.001 * k, 0.5, 0.5, 0.0 };
+            std::vector<V> r = (k % 3 == 2) ? record(in.dev[(size_t)k % 3].data(), in.shared, s.data()) : long_chain(in.dev[(size_t)k % 3].data(), in.shared, s.data(), k % 3 == 0 ? 24 : 3);
+            for (V v : r) payoffs.push_back(v);
+        }
+        OK(fmhip_fusion_hold(0, nullptr));
+        if (round % 2 == 1) OK(fmhip_vec_give_up_values(payoffs.data(), (int)payoffs.size()));
+        if (round % 4 == 3) { V keep = s1(FMHIP_OP_ADD_S, payoffs[1], 1.0); rel(keep); }       // a consumer of a given-up value that goes away again
+        fmhip_ticket t = 0;
+        OK(fmhip_reduce_moments_batch_begin(payoffs.data(), (int)payoffs.size(), nullptr, &t));
+        tickets.push_back(t); counts.push_back((int)payoffs.size());
+        if (round % 2 == 1) {                       // given up: reading is an error where nothing was kept, the moments stay
+            std::vector<float> h(2049);
+            const int st = fmhip_vec_read_float(payoffs[0], h.data(), 2049);
+            if (st != FMHIP_OK && st != FMHIP_ERR_INVALID_ARGUMENT) std::abort();
+            fmhip_moments m; OK(fmhip_reduce_moments(payoffs[0], 0.0, &m));
+        }
+        rel(payoffs);
+        if (tickets.size() == 3) {                  // ended out of order
+            for (int i : { 1, 0, 2 }) { std::vector<fmhip_moments> m((size_t)counts[(size_t)i]); OK(fmhip_reduce_moments_batch_end(tickets[(size_t)i], m.data(), counts[(size_t)i])); }
+            fmhip_moments one; EXPECT(fmhip_reduce_moments_batch_end(tickets[0], &one, 1), FMHIP_ERR_INVALID_HANDLE);
+            tickets.clear(); counts.clear();
+        }
+    }
+    std::vector<double> shifts = { 0.5, 0.25 };
+    V pair[2] = { in.dev[0][0], in.dev[0][1] };
+    fmhip_ticket t = 0; OK(fmhip_reduce_moments_batch_begin(pair, 2, shifts.data(), &t));
+    fmhip_moments m2[2]; EXPECT(fmhip_reduce_moments_batch_end(t, m2, 3), FMHIP_ERR_SIZE_MISMATCH);
+    free_inputs(in);
+    OK(fmhip_set_jit(prev, nullptr));
+}
+
+// explicit programs, the row-table ring wrapping (FMHIP_RING_BYTES is tiny here), Brownian increments and the engine's own time-step grouping
+static void scenario_programs_and_steps() {
+    const int64_t n = 1500;
+    fmhip_prog_op ops[3] = { { FMHIP_OP_ADD_S, 0, -1, -1, 4.0 }, { FMHIP_OP_MULT, 3, 1, -1, 0.0 }, { FMHIP_OP_CHOOSE, 4, 2, 0, 0.0 } };
+    const int32_t outs[1] = { 5 }, reds[1] = { 5 };
+    fmhip_program p = 0; OK(fmhip_program_create(ops, 3, 3, outs, 1, reds, 1, &p));
+    const int batch = 40;
+    std::vector<V> in, out((size_t)batch);
+    for (int b = 0; b < batch; ++b) for (int k = 0; k < 3; ++k) in.push_back(filled(n, 0.5 + k));
+    std::vector<fmhip_moments> m((size_t)batch);
+    for (int rep = 0; rep < 30; ++rep) { OK(fmhip_program_run(p, batch, in.data(), out.data(), nullptr, m.data(), nullptr)); rel(out); out.assign((size_t)batch, 0); }
+    for (int b = 0; b < batch; ++b) out[(size_t)b] = filled(n, 0.0);
+    for (int rep = 0; rep < 30; ++rep) OK(fmhip_program_run_into(p, batch, in.data(), out.data(), nullptr, nullptr, nullptr));
+    OK(fmhip_program_release(p));
+    rel(in); rel(out);
+    // an Euler scheme through methods only: the first use of an increment with a new time index marks a step, four steps run together
+    OK(fmhip_set_fusion(1, nullptr));
+    const int steps = 24;
+    std::vector<double> dt((size_t)steps, 0.1);
+    for (int sim = 0; sim < 3; ++sim) {
+        std::vector<V> inc((size_t)steps * 2), inc2((size_t)steps);
+        OK(fmhip_bm_generate(31415 + sim, steps, 2, n, 0, dt.data(), inc.data()));
+        OK(fmhip_bm_generate(27182 + sim, steps, 1, n, 0, dt.data(), inc2.data()));
+        V x = filled(n, 0.0), v = filled(n, 0.09);
+        for (int i = 0; i < steps; ++i) {
+            const V vp = s1(FMHIP_OP_FLOOR_S, v, 0.0), sq = u1(FMHIP_OP_SQRT, vp), d = b2(FMHIP_OP_MULT, sq, inc[(size_t)i * 2]), x2 = b2(FMHIP_OP_ADD, x, d);
+            const V e = s2(FMHIP_OP_ADDPRODUCT_VS, v, inc[(size_t)i * 2 + 1], 0.3), v2 = s2(FMHIP_OP_ADDPRODUCT_VS, e, inc2[(size_t)i], 0.1);      // (a second generation inside the step)
+            rel(vp); rel(sq); rel(d); rel(e); rel(x); rel(v);
+            x = x2; v = v2;
+            if (sim == 2 && i == 13) { fmhip_moments mm; OK(fmhip_reduce_moments(x, 0.0, &mm)); }    // a value read in the middle of a group
+        }
+        fmhip_moments mm; OK(fmhip_reduce_moments(x, 0.0, &mm));
+        rel(x); rel(v); rel(inc); rel(inc2);
+    }
+}
+
+static void scenario_threads() {
+    OK(fmhip_set_fusion(1, nullptr));
+    std::atomic<int> failures{ 0 };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < 8; ++t)
+        ts.emplace_back([t, &failures] {
+            const int64_t n = 600 + t;
+            for (int rep = 0; rep < 25; ++rep) {
+                V a = 0, b = 0;
+                if (fmhip_vec_create_filled(n, 1.0 + t, &a) != FMHIP_OK || fmhip_vec_create_filled(n, 0.5, &b) != FMHIP_OK) { ++failures; return; }
+                V cur = a;
+                for (int k = 0; k < 12 + (rep % 5) * 10; ++k) {
+                    V nx = 0;
+                    if (fmhip_call_v2s1(FMHIP_OP_DISCOUNT, cur, b, 0.5, &nx) != FMHIP_OK) { ++failures; return; }
+                    if (cur != a) fmhip_vec_release(cur);
+                    cur = nx;
+                }
+                fmhip_moments m;
+                if (fmhip_reduce_moments(cur, 0.0, &m) != FMHIP_OK) ++failures;
+                if (rep % 3 == 0) { fmhip_ticket tk = 0; V one[1] = { cur }; fmhip_moments mm[1];
+                                    if (fmhip_reduce_moments_batch_begin(one, 1, nullptr, &tk) != FMHIP_OK || fmhip_reduce_moments_batch_end(tk, mm, 1) != FMHIP_OK) ++failures; }
+                if (cur != a) fmhip_vec_release(cur);
+                fmhip_vec_release(a); fmhip_vec_release(b);
+            }
+        });
+    for (auto& th : ts) th.join();
+    if (failures.load() != 0) { std::fprintf(stderr, "threads: %d failed calls (%s)\n", failures.load(), fmhip_last_error()); std::abort(); }
+}
+
+// FMHIP_TEST_FAIL_ALLOC_AT is set by the caller for this scenario: an allocation fails somewhere inside a replicated launch of 1100 members
+static void scenario_failure() {
+    OK(fmhip_set_fusion(1, nullptr));
+    OK(fmhip_set_jit(FMHIP_JIT_OFF, nullptr));
+    const int64_t n = 64; const int copies = 1100;
+    std::vector<V> xs; for (int j = 0; j <= copies; ++j) xs.push_back(filled(n, 1.0 + 0.001 * j));
+    V y = filled(n, 0.5);
+    OK(fmhip_fusion_hold(1, nullptr));
+    V t = s2(FMHIP_OP_ACCRUE, xs[0], y, 0.5), u = s1(FMHIP_OP_ADD_S, t, 1.0), w = b2(FMHIP_OP_MULT, u, y);
+    rel(u);
+    V roots[2] = { t, w };
+    std::vector<V> out((size_t)copies * 2);
+    OK(fmhip_graph_clone(roots, 2, copies, &xs[0], &xs[1], 1, nullptr, 0, out.data()));
+    OK(fmhip_fusion_hold(0, nullptr));
+    const int st = fmhip_flush();
+    if (st != FMHIP_OK && st != FMHIP_ERR_OUT_OF_MEMORY) std::abort();
+    int lost = 0;
+    std::vector<float> h((size_t)n);
+    for (V v : out) { const int r = fmhip_vec_read_float(v, h.data(), n); if (r != FMHIP_OK && r != FMHIP_ERR_INVALID_ARGUMENT && r != FMHIP_ERR_OUT_OF_MEMORY) std::abort(); lost += r == FMHIP_ERR_INVALID_ARGUMENT; }
+    std::printf("failure: flush status %d, %d copies lost\n", st, lost);
+    for (V v : roots) { const int r = fmhip_vec_read_float(v, h.data(), n); if (r != FMHIP_OK && r != FMHIP_ERR_OUT_OF_MEMORY) std::abort(); }
+    rel(out); rel(t); rel(w); rel(xs); rel(y);
+    OK(fmhip_flush());
+}
+
+int main(int argc, char** argv) {
+    struct Scenario { const char* name; void (*run)(); };
+    const Scenario all[] = { { "basic", scenario_basic }, { "replicas", scenario_replicas }, { "expectations", scenario_expectations },
+                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "failure", scenario_failure } };
+    std::vector<std::string> wanted;
+    for (int i = 1; i < argc; ++i) wanted.push_back(argv[i]);
+    const bool only_failure = wanted.size() == 1 && wanted[0] == "failure";      // (the hook counts the allocations of the whole process: one cycle)
+    for (int cycle = 0; cycle < (only_failure ? 1 : 2); ++cycle) {                  // twice: shutdown and re-initialisation in between
+        OK(fmhip_init(0));
+        for (const Scenario& s : all) {
+            bool run = wanted.empty() ? std::strcmp(s.name, "failure") != 0 : false;
+            for (const std::string& w : wanted) run |= w == s.name;
+            if (!run) continue;
+            s.run();
+            std::printf("cycle %d: %s done\n", cycle, s.name);
+            std::fflush(stdout);
+        }
+        OK(fmhip_shutdown());
+    }
+    return 0;
+}

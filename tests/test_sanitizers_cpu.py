@@ -1,0 +1,51 @@
+"""The engine's host runtime (csrc/runtime.cpp, abi.cpp, jit.cpp: node pools, intrusive reference counts, replica descriptions, tickets, the
+pinned arena, plan caches) under AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer, on a TEST-ONLY null device
+(tests/nulldev/null_hip.cpp: device memory = host memory, launches compute nothing) — no GPU needed; GPU sanitizers do not exist on this
+pool.  tests/nulldev/drive.cpp replays the graph shapes of the GPU tests (replicas in the ten orders of test_gpu_replicas.py, long
+chains through segments / rolled / peeled plans, expectations taken along, values given up, tickets out of order, the row-table ring
+and the moments arena wrapping at tiny sizes, eight threads, shutdown and re-initialisation) and, in a sweep of its own, a failing
+allocation in the middle of a replicated launch of 1100 members.  The null device is not a back end and never ships."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NULLDEV = os.path.join(HERE, "nulldev")
+
+
+@pytest.fixture(scope="module")
+def built():
+    r = subprocess.run(["make", "-C", NULLDEV, "-j8", "asan", "tsan"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return os.path.join(NULLDEV, "build")
+
+
+def run(binary, tmp_path, *scenarios, **extra_env):
+    env = dict(os.environ, FMHIP_JIT_CACHE_DIR=str(tmp_path / "code_objects"), FMHIP_JIT_PACK_DIR="off", FMHIP_RING_BYTES="16384", FMHIP_ARENA_BYTES="4096",
+               ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", TSAN_OPTIONS="halt_on_error=1")
+    env.update(extra_env)
+    return subprocess.run([binary, *scenarios], capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(built, tmp_path):
+    r = run(os.path.join(built, "drive_asan"), tmp_path)
+    assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
+    assert r.stdout.count("done") == 10          # five scenarios, twice (shutdown and re-initialisation in between)
+    again = run(os.path.join(built, "drive_asan"), tmp_path)      # once more: the code objects of the first run come from the cache directory
+    assert again.returncode == 0 and "Sanitizer" not in again.stderr, again.stderr[-6000:]
+
+
+def test_host_runtime_is_clean_under_thread_sanitizer(built, tmp_path):
+    r = run(os.path.join(built, "drive_tsan"), tmp_path)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
+    assert r.stdout.count("done") == 10
+
+
+def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(built, tmp_path):
+    """1101 vectors + 1 are allocated before the flush; the 2 x 1101 buffers of the launch follow in two parts of 1024 and 77 members: the
+    hook is swept over that stretch.  Every position must leave a process that ends cleanly — no leak, no use after free, no bad status."""
+    for at in (1103, 1500, 2125, 2127, 2400, 3150, 3151, 3300, 10**9):
+        r = run(os.path.join(built, "drive_asan"), tmp_path, "failure", FMHIP_TEST_FAIL_ALLOC_AT=str(at))
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (at, r.stdout[-500:] + r.stderr[-6000:])
+        assert "failure done" in r.stdout
