@@ -46,6 +46,24 @@ def init(device_index: int = -1) -> None:
         _atexit_registered = True
 
 
+def init_devices(devices) -> None:
+    """ONE process, several devices (include/fmhip.h: fmhip_init_devices): every vector is cut into blocks of paths, block d on devices[d];
+    everything else of this package works unchanged.  An index may repeat (shards on separate streams of one device)."""
+    global _atexit_registered
+    arr = (_C.c_int * len(devices))(*[int(d) for d in devices])
+    _native.check(lib().fmhip_init_devices(arr, len(devices)))
+    if not _atexit_registered:
+        import atexit
+        atexit.register(_shutdown_at_exit)
+        _atexit_registered = True
+
+
+def device_count() -> int:
+    c = _C.c_int(0)
+    _native.check(lib().fmhip_device_count(_C.byref(c)))
+    return c.value
+
+
 def shutdown() -> None:
     _native.check(lib().fmhip_shutdown())
 

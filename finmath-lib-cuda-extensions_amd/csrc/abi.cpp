@@ -1,6 +1,7 @@
 // abi.cpp — the extern "C" surface declared in include/fmhip.h.  No logic: argument checks, the engine
 // lock, exception → status translation.  A JNI layer maps 1:1 onto these.
 #include "runtime.hpp"
+#include "sharded.hpp"
 #include <cmath>
 
 #include <cstring>
@@ -14,6 +15,9 @@ using fm::Engine;
 using fm::Error;
 
 static thread_local std::string g_last_error;
+namespace fm { void set_last_error(const std::string& message) { g_last_error = message; } }
+namespace front = fm::front;
+#define FRONT(call) do { if (fm::front_active()) return front::call; } while (0)
 
 template <typename F>
 static int guarded(F&& f) {
@@ -39,8 +43,23 @@ static void need(const void* p, const char* what) {
 
 extern "C" {
 
-int fmhip_init(int device_index) { return guarded([&] { Engine::get().init(device_index); }); }
+int fmhip_init(int device_index) {
+    if (fm::front_active()) { g_last_error = "a device list is active (fmhip_init_devices): fmhip_shutdown first"; return FMHIP_ERR_INVALID_ARGUMENT; }
+    return guarded([&] { Engine::get().init(device_index); });
+}
+// One process, several devices (sharded.hpp): `count` device indices (an index may repeat: shards on separate streams of one device).
+// One entry = fmhip_init(devices[0]).
+int fmhip_init_devices(const int* devices, int count) {
+    if (count == 1 && devices) return fmhip_init(devices[0]);
+    if (fm::front_active()) { g_last_error = "a device list is active already"; return FMHIP_ERR_INVALID_ARGUMENT; }
+    return front::init_devices(devices, count);
+}
+int fmhip_device_count(int* count) {
+    FRONT(device_count(count));
+    return guarded([&] { need(count, "count"); Engine::get().require_init(); *count = 1; });
+}
 int fmhip_shutdown(void) {
+    FRONT(shutdown());
     // a thread that waits for its moments outside the lock still holds a result slot, a pinned block or an event of this engine: the
     // teardown starts when the last such wait is over (they end by themselves: the device finishes what was launched)
     for (;;) {
@@ -51,62 +70,78 @@ int fmhip_shutdown(void) {
         std::this_thread::yield();
     }
 }
-int fmhip_is_initialized(void) { return Engine::get().initialized() ? 1 : 0; }
+int fmhip_is_initialized(void) { return (fm::front_active() || Engine::get().initialized()) ? 1 : 0; }
 int fmhip_abi_version(void) { return FMHIP_ABI_VERSION; }
 const char* fmhip_last_error(void) { return g_last_error.c_str(); }
 
 int fmhip_device_info(char* name_buf, int name_buf_len, int* n_compute_units, int64_t* hbm_bytes) {
+    FRONT(device_info(name_buf, name_buf_len, n_compute_units, hbm_bytes));
     return guarded([&] { Engine::get().device_info(name_buf, name_buf_len, n_compute_units, hbm_bytes); });
 }
-int fmhip_synchronize(void) { return guarded([&] { Engine::get().synchronize(); }); }
+int fmhip_synchronize(void) { FRONT(synchronize()); return guarded([&] { Engine::get().synchronize(); }); }
 int fmhip_get_stream(void** stream_out) {
+    FRONT(unsupported("fmhip_get_stream"));
     return guarded([&] { need(stream_out, "stream_out"); Engine::get().require_init(); *stream_out = (void*)Engine::get().stream(); });
 }
 
 int fmhip_vec_create_from_double(const double* host_values, int64_t n, fmhip_vec* out) {
+    FRONT(vec_create_from_host(host_values, true, n, out));
     return guarded([&] { need(out, "out"); *out = Engine::get().create_from_host(host_values, true, n); });
 }
 int fmhip_vec_create_from_float(const float* host_values, int64_t n, fmhip_vec* out) {
+    FRONT(vec_create_from_host(host_values, false, n, out));
     return guarded([&] { need(out, "out"); *out = Engine::get().create_from_host(host_values, false, n); });
 }
 int fmhip_vec_create_filled(int64_t n, double value, fmhip_vec* out) {
+    FRONT(vec_create_filled(n, value, true, out));
     return guarded([&] { need(out, "out"); *out = Engine::get().create_filled(n, (float)value); });
 }
 int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
+    FRONT(vec_create_filled(n, 0.0, false, out));
     return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
 }
-int fmhip_vec_retain(fmhip_vec v) { return guarded([&] { Engine::get().retain(v); }); }
-int fmhip_vec_release(fmhip_vec v) { return guarded([&] { Engine::get().release(v); }); }
+int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
+int fmhip_vec_release(fmhip_vec v) { FRONT(vec_release(v)); return guarded([&] { Engine::get().release(v); }); }
 int fmhip_vec_size(fmhip_vec v, int64_t* n_out) {
+    FRONT(vec_size(v, n_out));
     return guarded([&] { need(n_out, "n_out"); Engine::get().require_init(); *n_out = Engine::get().node(v)->n; });
 }
 int fmhip_vec_read_double(fmhip_vec v, double* host_out, int64_t n) {
+    FRONT(vec_read(v, host_out, true, n));
     return guarded([&] { Engine::get().read(v, host_out, true, n); });
 }
 int fmhip_vec_read_float(fmhip_vec v, float* host_out, int64_t n) {
+    FRONT(vec_read(v, host_out, false, n));
     return guarded([&] { Engine::get().read(v, host_out, false, n); });
 }
 int fmhip_vec_device_ptr(fmhip_vec v, void** device_ptr_out) {
+    FRONT(unsupported("fmhip_vec_device_ptr"));
     return guarded([&] { need(device_ptr_out, "device_ptr_out"); *device_ptr_out = Engine::get().device_ptr(v); });
 }
 
 int fmhip_call_v1s0(int opcode, fmhip_vec a, fmhip_vec* out) {
+    if (fm::front_active()) { const fmhip_vec in[1] = { a }; return front::call(opcode, 1, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, 0.0, false); });
 }
 int fmhip_call_v1s1(int opcode, fmhip_vec a, double s, fmhip_vec* out) {
+    if (fm::front_active()) { const fmhip_vec in[1] = { a }; return front::call(opcode, 1, in, s, true, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, s, true); });
 }
 int fmhip_call_v2s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec* out) {
+    if (fm::front_active()) { const fmhip_vec in[2] = { a, b }; return front::call(opcode, 2, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, 0.0, false); });
 }
 int fmhip_call_v2s1(int opcode, fmhip_vec a, fmhip_vec b, double s, fmhip_vec* out) {
+    if (fm::front_active()) { const fmhip_vec in[2] = { a, b }; return front::call(opcode, 2, in, s, true, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, s, true); });
 }
 int fmhip_call_v3s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec c, fmhip_vec* out) {
+    if (fm::front_active()) { const fmhip_vec in[3] = { a, b, c }; return front::call(opcode, 3, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[3] = { a, b, c }; *out = Engine::get().call(opcode, 3, in, 0.0, false); });
 }
 
 int fmhip_set_fusion(int enabled, int* previous) {
+    FRONT(set_int(0, enabled, previous));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -116,6 +151,7 @@ int fmhip_set_fusion(int enabled, int* previous) {
     });
 }
 int fmhip_fusion_hold(int hold, int* previous) {
+    FRONT(set_int(1, hold, previous));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -124,6 +160,7 @@ int fmhip_fusion_hold(int hold, int* previous) {
     });
 }
 int fmhip_set_step_grouping(int steps, int* previous) {
+    FRONT(set_int(2, steps, previous));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -134,15 +171,18 @@ int fmhip_set_step_grouping(int steps, int* previous) {
 }
 int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
                       const double* scalars, int n_scalars, fmhip_vec* out) {
+    FRONT(graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out));
     return guarded([&] { Engine::get().graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out); });
 }
 int fmhip_graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int capacity, int* n_scalars) {
+    FRONT(graph_scalars(roots, n_roots, scalars_out, capacity, n_scalars));
     return guarded([&] {
         if (!n_scalars) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null count pointer");
         *n_scalars = Engine::get().graph_scalars(roots, n_roots, scalars_out, capacity);
     });
 }
 int fmhip_set_math_mode(int mode, int* previous) {
+    FRONT(set_int(3, mode, previous));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -152,7 +192,7 @@ int fmhip_set_math_mode(int mode, int* previous) {
         e.math_mode = mode;
     });
 }
-int fmhip_flush(void) { return guarded([&] { Engine::get().flush_all(); Engine::get().end_step_group(); }); }
+int fmhip_flush(void) { FRONT(flush()); return guarded([&] { Engine::get().flush_all(); Engine::get().end_step_group(); }); }
 
 // ---- expectation communicator (include/fmhip.h): the global moments of path-sharded vectors
 static void combine_moments(const fmhip_moments* gathered, int world, int count, fmhip_moments* out) {
@@ -176,6 +216,7 @@ static void exchange_moments(Engine& e, fmhip_moments* inout, int count) {
     combine_moments(all.data(), e.comm_world, count, inout);
 }
 int fmhip_set_expectation_comm(int world, int rank, fmhip_gather_fn gather, void* context) {
+    if (fm::front_active() && world > 1) return front::unsupported("fmhip_set_expectation_comm");
     return guarded([&] {
         Engine& e = Engine::get();
         if (world < 1 || rank < 0 || rank >= world) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad communicator: world " + std::to_string(world) + ", rank " + std::to_string(rank));
@@ -198,6 +239,7 @@ int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int coun
 // NOT while the device computes — other threads record and launch meanwhile.  The moments arrive in a slot of pinned memory of their
 // own; this thread polls its flag, then takes the lock again to copy them out and give the launch's buffers back.
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
+    if (fm::front_active()) { const fmhip_vec one[1] = { v }; const double sh[1] = { shift }; return front::reduce_moments_batch(one, 1, sh, out); }
     Engine::RedLaunch pending;
     int rc = guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr, &pending); if (pending.pending) Engine::get().waits_in_flight.fetch_add(1, std::memory_order_acq_rel); });
     if (rc == FMHIP_OK && pending.pending) {
@@ -208,18 +250,23 @@ int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     return rc;
 }
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
+    FRONT(reduce_moments_batch(vectors, count, shifts, out));
     return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine& e = Engine::get(); e.reduce_batch(vectors, count, shifts, out, nullptr); exchange_moments(e, out, count); });
 }
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
+    FRONT(unsupported("fmhip_reduce_moments_batch_device"));
     return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch(vectors, count, shifts, nullptr, device_out); });
 }
 int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out) {
+    FRONT(reduce_moments_batch_begin(vectors, count, shifts, ticket_out));
     return guarded([&] { need(vectors, "vectors"); need(ticket_out, "ticket_out"); *ticket_out = Engine::get().reduce_batch_begin(vectors, count, shifts); });
 }
 int fmhip_vec_give_up_values(const fmhip_vec* vectors, int count) {
+    FRONT(vec_give_up_values(vectors, count));
     return guarded([&] { need(vectors, "vectors"); Engine::get().give_up_values(vectors, count); });
 }
 int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count) {
+    FRONT(reduce_moments_batch_end(ticket, out, count));
     Engine::MomentsTicket t;
     int rc = guarded([&] {
         need(out, "out");
@@ -243,17 +290,20 @@ int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int 
     return rc;
 }
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
+    FRONT(unsupported("fmhip_reduce_moments_device"));
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
 }
 
 int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, const int32_t* out_values, int n_outputs,
                          const int32_t* reduce_values, int n_reduce, fmhip_program* out) {
+    FRONT(program_create(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce, out));
     return guarded([&] {
         need(out, "out");
         *out = Engine::get().program_create(ops, n_ops, n_inputs, out_values, n_outputs, reduce_values, n_reduce);
     });
 }
 int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_reduce) {
+    FRONT(program_shape(p, n_inputs, n_outputs, n_reduce));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -264,6 +314,7 @@ int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_r
     });
 }
 int fmhip_set_jit(int mode, int* previous) {
+    FRONT(set_int(4, mode, previous));
     return guarded([&] {
         if (mode != FMHIP_JIT_OFF && mode != FMHIP_JIT_AUTO && mode != FMHIP_JIT_SYNC) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown JIT mode");
         if (previous) *previous = Engine::get().jit_mode;
@@ -271,10 +322,12 @@ int fmhip_set_jit(int mode, int* previous) {
     });
 }
 int fmhip_jit_wait(void) {
+    FRONT(jit_wait());
     // not under the engine mutex: other threads keep launching while this one waits for the compiler thread
     try { Engine::get().jit_wait(); return FMHIP_OK; } catch (...) { return FMHIP_ERR_HIP; }
 }
 int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds, int64_t* disk_cache_hits) {
+    FRONT(jit_stats(compiled, failed, pending, compile_seconds, disk_cache_hits));
     return guarded([&] {
         const fm::JitStats s = Engine::get().jit_stats();
         if (compiled) *compiled = s.compiled;
@@ -285,6 +338,7 @@ int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double
     });
 }
 int fmhip_program_tier(fmhip_program p, int* tier, int* vgprs) {
+    FRONT(program_tier(p, tier, vgprs));
     return guarded([&] {
         Engine::get().require_init();
         fm::Program* pr = Engine::get().program(p);
@@ -305,8 +359,9 @@ int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
         }
     });
 }
-int fmhip_program_release(fmhip_program p) { return guarded([&] { Engine::get().program_release(p); }); }
+int fmhip_program_release(fmhip_program p) { FRONT(program_release(p)); return guarded([&] { Engine::get().program_release(p); }); }
 int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
+    if (fm::front_active()) { int a = 0; const int st = front::program_shape(p, &a, nullptr, nullptr); if (st == FMHIP_OK && n_launches) *n_launches = 1; return st; }
     return guarded([&] {
         need(n_launches, "n_launches");
         Engine::get().require_init();
@@ -316,10 +371,12 @@ int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
 }
 int fmhip_program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs,
                       const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
+    if (fm::front_active()) return device_moments ? front::unsupported("fmhip_program_run with device_moments") : front::program_run(p, batch, inputs, outputs, false, reduce_shift, moments);
     return guarded([&] { Engine::get().program_run(p, batch, inputs, outputs, false, reduce_shift, moments, device_moments); });
 }
 int fmhip_program_run_into(fmhip_program p, int batch, const fmhip_vec* inputs, const fmhip_vec* outputs,
                            const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
+    if (fm::front_active()) return device_moments ? front::unsupported("fmhip_program_run_into with device_moments") : front::program_run(p, batch, inputs, const_cast<fmhip_vec*>(outputs), true, reduce_shift, moments);
     return guarded([&] {
         Engine::get().program_run(p, batch, inputs, const_cast<fmhip_vec*>(outputs), true, reduce_shift, moments, device_moments);
     });
@@ -327,6 +384,7 @@ int fmhip_program_run_into(fmhip_program p, int batch, const fmhip_vec* inputs, 
 
 int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
                       const double* dt, fmhip_vec* out) {
+    FRONT(bm_generate(seed, n_steps, n_factors, n_paths, path_offset, dt, out));
     return guarded([&] { Engine::get().bm_generate(seed, n_steps, n_factors, n_paths, path_offset, dt, out); });
 }
 
@@ -338,6 +396,18 @@ int fmhip_mersenne_increments(int32_t seed, int n_steps, int n_factors, int64_t 
     } catch (const Error& e) { g_last_error = e.what(); return e.code; }
 }
 int fmhip_bm_generate_mersenne(int32_t seed, int n_steps, int n_factors, int64_t n_paths, const double* dt, fmhip_vec* out) {
+    if (fm::front_active()) {           // generated on the host, every increment uploaded block by block through the front
+        if (!out || !dt || n_steps <= 0 || n_factors <= 0 || n_paths < 0) { g_last_error = "bad Brownian motion description"; return FMHIP_ERR_INVALID_ARGUMENT; }
+        std::vector<double> host((size_t)n_steps * n_factors * (size_t)n_paths);
+        fm::mersenne_increments(seed, n_steps, n_factors, n_paths, dt, host.data());
+        const size_t count = (size_t)n_steps * n_factors;
+        for (size_t k = 0; k < count; ++k) out[k] = 0;
+        for (size_t k = 0; k < count; ++k) {
+            const int st = front::vec_create_from_host(host.data() + k * (size_t)n_paths, true, n_paths, &out[k]);
+            if (st != FMHIP_OK) { for (size_t j = 0; j < k; ++j) { (void)front::vec_release(out[j]); out[j] = 0; } return st; }
+        }
+        return FMHIP_OK;
+    }
     return guarded([&] {
         need(out, "out"); need(dt, "dt");
         if (n_steps <= 0 || n_factors <= 0 || n_paths < 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad Brownian motion description");
@@ -351,18 +421,20 @@ int fmhip_bm_generate_mersenne(int32_t seed, int n_steps, int n_factors, int64_t
 }
 double fmhip_inverse_normal_cdf(double p) { return fm::inverse_normal_cdf(p); }
 
-int fmhip_pool_clean(void) { return guarded([&] { Engine::get().pool_clean(); }); }
-int fmhip_pool_purge(void) { return guarded([&] { Engine::get().pool_purge(); }); }
-int fmhip_pool_stats(fmhip_pool_stats_t* out) { return guarded([&] { Engine::get().pool_stats(out); }); }
+int fmhip_pool_clean(void) { FRONT(pool(0)); return guarded([&] { Engine::get().pool_clean(); }); }
+int fmhip_pool_purge(void) { FRONT(pool(1)); return guarded([&] { Engine::get().pool_purge(); }); }
+int fmhip_pool_stats(fmhip_pool_stats_t* out) { FRONT(pool_stats(out)); return guarded([&] { Engine::get().pool_stats(out); }); }
 
 int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches) {
+    FRONT(traffic_stats(algorithmic_bytes, specialised_launches));
     return guarded([&] {
         if (algorithmic_bytes) *algorithmic_bytes = Engine::get().algorithmic_bytes();
         if (specialised_launches) *specialised_launches = Engine::get().jit_launches();
     });
 }
-int fmhip_profile_enable(int enabled) { return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
+int fmhip_profile_enable(int enabled) { FRONT(profile_enable(enabled)); return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches) {
+    FRONT(profile_read(kernel_ms_total, n_launches));
     return guarded([&] { Engine::get().profile_read(kernel_ms_total, n_launches); });
 }
 

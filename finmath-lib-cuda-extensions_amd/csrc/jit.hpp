@@ -94,7 +94,7 @@ bool jit_precompile(const std::string& source, const std::string& dir, std::stri
 
 class Jit {
 public:
-    ~Jit() { quiesce(); }                                       // static destruction: join only, no HIP calls (fmhip_shutdown unloads)
+    ~Jit();                                                     // static destruction: join only, no HIP calls (fmhip_shutdown unloads)
     void start(int device);
     void stop();                                               // joins the worker, unloads every module
     void quiesce();                                            // joins the worker only (process exit: no HIP calls)

@@ -116,7 +116,13 @@ void Pool::purge() {
 
 // ---------------------------------------------------------------- engine lifecycle
 
-Engine& Engine::get() { static Engine* e = new Engine(); return *e; }
+// The engine of the calling thread: the process-wide one — or, on a worker thread of a device list (sharded.cpp: one engine per
+// device shard, each driven by a thread of its own), that worker's.
+static thread_local Engine* tls_engine = nullptr;
+Engine& Engine::get() { if (tls_engine) return *tls_engine; static Engine* e = new Engine(); return *e; }
+Engine* Engine::create() { return new Engine(); }
+void Engine::bind_thread(Engine* e) { tls_engine = e; }
+bool Engine::thread_is_bound() { return tls_engine != nullptr; }
 
 void Engine::require_init() const {
     if (!initialized_) throw Error(FMHIP_ERR_NOT_INITIALIZED, "fmhip_init has not been called");
@@ -180,11 +186,11 @@ void Engine::init(int device_index) {
         else if (v == "auto" || v == "1") jit_mode = FMHIP_JIT_AUTO;
     }
     jit_.start(device_index);
-    g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr;
+    { static std::once_flag once; std::call_once(once, [] { g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr; }); }      // (process-wide: several engines initialise side by side behind a device list)
     for (const char* name : { "FMHIP_BM_GROUP_STEPS", "FMHIP_GROUP_STEPS" })       // (the first: where round 2 had this, in BrownianMotionHip)
         if (const char* e = std::getenv(name)) { const int v = std::atoi(e); if (v >= 0) group_steps = v; }
     group_bm_id_ = 0; group_last_step_ = -1; group_steps_pending_ = 0; group_hold_ = false; group_last_by_bm_.clear();
-    if (const char* e = std::getenv("FMHIP_FUSION_MAX_WEIGHT")) { const int v = std::atoi(e); if (v > 0) fusion_max_weight_override(v); }
+    { static std::once_flag once; std::call_once(once, [] { if (const char* e = std::getenv("FMHIP_FUSION_MAX_WEIGHT")) { const int v = std::atoi(e); if (v > 0) fusion_max_weight_override(v); } }); }
     initialized_ = true;
 }
 

@@ -194,6 +194,9 @@ private:
 class Engine {
 public:
     static Engine& get();
+    static Engine* create();                 // a further engine (sharded.cpp: one per device of a device list); the caller owns it
+    static void bind_thread(Engine* e);      // Engine::get() of THIS thread returns e from now on (nullptr: the process-wide engine again)
+    static bool thread_is_bound();
     std::recursive_mutex mu;
     // Callers that wait for moments WITHOUT the engine lock (abi.cpp: fmhip_reduce_moments, fmhip_reduce_moments_batch_end) hold slots,
     // pinned blocks and events of this engine meanwhile: counted here (under the lock, before it is dropped); fmhip_shutdown waits for zero.

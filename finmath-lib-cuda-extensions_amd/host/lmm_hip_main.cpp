@@ -17,7 +17,8 @@ static void ncclCheck(ncclResult_t r, const char* what) {
 int main(int argc, char** argv) {
     const lmm::Options o = lmm::parseOptions(argc, argv);
     try {
-        check(fmhip_init(-1));                           // device = LOCAL_RANK (torchrun) / FMHIP_DEVICE_INDEX / 0
+        if (!o.devices.empty()) check(fmhip_init_devices(o.devices.data(), (int)o.devices.size()));      // one process, several devices: nothing else in this driver changes
+        else check(fmhip_init(-1));                      // device = LOCAL_RANK (torchrun) / FMHIP_DEVICE_INDEX / 0
         check(fmhip_set_fusion(1, nullptr));            // chains of RandomVariable calls run as fused launches
         RandomVariableHipFactory factory;
         lmm::Market m;

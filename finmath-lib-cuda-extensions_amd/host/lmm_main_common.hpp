@@ -1,6 +1,7 @@
 // lmm_main_common.hpp — command line + JSON report shared by the two LMM driver executables
 // (lmm_hip: product, links libfmhip.so only;  oracle/host/lmm_cpu: CPU twin, test infrastructure / cpu_baseline).
 #pragma once
+#include <vector>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -14,6 +15,7 @@ struct Options {
     int warmupEvaluations = 0;                             // mode evaluate: parameter sets evaluated once (in one lock-step batch) BEFORE statistics and profiling start —
                                                            // the first batch meets every graph shape for the first time (plans are written down, kernels compiled)
     int world = 1, rank = 0; std::string ncclIdFile; long long ncclNonce = 0;
+    std::vector<int> devices;                              // --devices 0,1,2,…: ONE process drives these devices (fmhip_init_devices), `paths` in all, sharded by path blocks
     int chunk = 0;                                         // LIBOR components per fused launch; 0 = back end default
     int stepsPerLaunch = 0;                                // Euler steps recorded per engine flush; 0 = back end default (4)
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
@@ -34,6 +36,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--warmup-evaluations") o.warmupEvaluations = std::atoi(next());
         else if (a == "--path-offset") o.pathOffset = std::atoll(next());
         else if (a == "--world") o.world = std::atoi(next());
+        else if (a == "--devices") { std::string list = next(); size_t p0 = 0; while (p0 <= list.size()) { const size_t q = list.find(',', p0); o.devices.push_back(std::atoi(list.substr(p0, q == std::string::npos ? std::string::npos : q - p0).c_str())); if (q == std::string::npos) break; p0 = q + 1; } }
         else if (a == "--rank") o.rank = std::atoi(next());
         else if (a == "--nccl-id-file") o.ncclIdFile = next();
         else if (a == "--nccl-nonce") o.ncclNonce = std::atoll(next());

@@ -133,6 +133,18 @@ typedef struct fmhip_pool_stats_t {
  * device_index < 0: use env FMHIP_DEVICE_INDEX, else LOCAL_RANK, else 0.
  * Idempotent for the same device.  (RandomVariableCuda.java:159-248) */
 int fmhip_init(int device_index);
+/* ONE process, SEVERAL devices (replaces the single device index of RandomVariableCuda.java:161,177): every
+ * vector is cut into contiguous blocks of paths (boundaries at multiples of four), block d lives on devices[d], every method runs on
+ * every block, a read gathers the blocks by one device-to-host copy per device, and host-side moments are the per-device moments
+ * added in device order (the rule of fmhip_expectation_combine) — no collective, nothing travels between devices.  Everything else of
+ * this header works unchanged on the caller's side; handles are the library's own numbers.  An index may repeat (shards on separate
+ * streams of one device: how this is tested on a one-GPU box).  Calls that only return handles are queued to one worker thread per
+ * device and return at once: an error a device meets later (an allocation that fails) is returned by the next call that waits (a read,
+ * a reduction, fmhip_synchronize).  Not available with a device list: fmhip_get_stream, fmhip_vec_device_ptr, the *_device variants
+ * of the reductions, device_moments of fmhip_program_run, fmhip_set_expectation_comm.  count == 1 is fmhip_init(devices[0]).
+ * UNMEASURED on more than one physical GPU. */
+int fmhip_init_devices(const int* devices, int count);
+int fmhip_device_count(int* count);           /* devices (shards) behind the handles: 1 after fmhip_init */
 int fmhip_shutdown(void);
 int fmhip_is_initialized(void);
 int fmhip_abi_version(void);

@@ -25,6 +25,8 @@ final class Native {
 
 	// ---- lifecycle (fmhip.h: fmhip_init … fmhip_get_stream)
 	static native int init(int deviceIndex);
+	static native int initDevices(int[] devices);
+	static native int deviceCount(int[] count);
 	static native int shutdown();
 	static native int isInitialized();
 	static native int abiVersion();

@@ -58,6 +58,18 @@ inline void set1(JNIEnv* env, jlongArray arr, jlong v) { if (arr && env->GetArra
 
 // ---------------------------------------------------------------- lifecycle
 FMJ(jint, init)(JNIEnv*, jclass, jint deviceIndex) { return fmhip_init(deviceIndex); }
+FMJ(jint, initDevices)(JNIEnv* env, jclass, jintArray devices) {
+    Pin<jint> pd(env, devices, JNI_ABORT);
+    if (!pd.p) return FMHIP_ERR_INVALID_ARGUMENT;
+    return fmhip_init_devices((const int*)pd.p, pd.length());
+}
+FMJ(jint, deviceCount)(JNIEnv* env, jclass, jintArray count) {
+    if (!count || env->GetArrayLength(count) < 1) return FMHIP_ERR_INVALID_ARGUMENT;
+    int c = 0;
+    const int st = fmhip_device_count(&c);
+    if (st == FMHIP_OK) { const jint v = c; env->SetIntArrayRegion(count, 0, 1, &v); }
+    return st;
+}
 FMJ(jint, shutdown)(JNIEnv*, jclass) { return fmhip_shutdown(); }
 FMJ(jint, isInitialized)(JNIEnv*, jclass) { return fmhip_is_initialized(); }
 FMJ(jint, abiVersion)(JNIEnv*, jclass) { return fmhip_abi_version(); }

@@ -5,6 +5,7 @@
 // threads as tests/test_gpu_threads.py, shutdown and re-initialisation.  Nothing is computed: statuses are checked, the sanitizers do
 // the rest.   usage: drive [scenario …]   (none = all)
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -273,17 +274,46 @@ static void scenario_failure() {
     OK(fmhip_flush());
 }
 
+// cost of a recorded method on the caller's side (and of its replay on the shards): not a sanitizer scenario — build with -O2, no sanitizer
+static void scenario_speed() {
+    OK(fmhip_set_fusion(1, nullptr));
+    OK(fmhip_fusion_hold(1, nullptr));
+    const int64_t n = 1024;
+    V a = filled(n, 1.0), b = filled(n, 0.5);
+    const int reps = 2000000;
+    const auto t0 = std::chrono::steady_clock::now();
+    V cur = a;
+    for (int k = 0; k < reps; ++k) {
+        V nx = 0;
+        OK(fmhip_call_v2s1(FMHIP_OP_DISCOUNT, cur, b, 0.5, &nx));
+        if (cur != a) OK(fmhip_vec_release(cur));
+        cur = nx;
+        if (k % 200 == 199) { rel(cur); cur = a; }         // chains of 200: released unexecuted (under the hold nothing runs)
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    OK(fmhip_synchronize());
+    const auto t2 = std::chrono::steady_clock::now();
+    std::printf("speed: %.0f ns per recorded method + release on the caller's thread, %.0f ns including the shards' replay\n",
+                std::chrono::duration<double>(t1 - t0).count() / reps * 1e9, std::chrono::duration<double>(t2 - t0).count() / reps * 1e9);
+    if (cur != a) rel(cur);
+    OK(fmhip_fusion_hold(0, nullptr));
+    rel(a); rel(b);
+}
+
 int main(int argc, char** argv) {
     struct Scenario { const char* name; void (*run)(); };
     const Scenario all[] = { { "basic", scenario_basic }, { "replicas", scenario_replicas }, { "expectations", scenario_expectations },
-                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "failure", scenario_failure } };
+                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "failure", scenario_failure }, { "speed", scenario_speed } };
     std::vector<std::string> wanted;
     for (int i = 1; i < argc; ++i) wanted.push_back(argv[i]);
     const bool only_failure = wanted.size() == 1 && wanted[0] == "failure";      // (the hook counts the allocations of the whole process: one cycle)
     for (int cycle = 0; cycle < (only_failure ? 1 : 2); ++cycle) {                  // twice: shutdown and re-initialisation in between
-        OK(fmhip_init(0));
+        // FMNULL_DEVICES=N: the same scenarios behind a device list of N shards (sharded.cpp: one engine and one worker thread per shard)
+        const int n_devices = std::getenv("FMNULL_DEVICES") ? std::atoi(std::getenv("FMNULL_DEVICES")) : 1;
+        if (n_devices > 1) { std::vector<int> devices((size_t)n_devices, 0); OK(fmhip_init_devices(devices.data(), n_devices)); int c = 0; OK(fmhip_device_count(&c)); if (c != n_devices) std::abort(); }
+        else OK(fmhip_init(0));
         for (const Scenario& s : all) {
-            bool run = wanted.empty() ? std::strcmp(s.name, "failure") != 0 : false;
+            bool run = wanted.empty() ? (std::strcmp(s.name, "failure") != 0 && std::strcmp(s.name, "speed") != 0) : false;
             for (const std::string& w : wanted) run |= w == s.name;
             if (!run) continue;
             s.run();

@@ -49,3 +49,15 @@ def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(b
         r = run(os.path.join(built, "drive_asan"), tmp_path, "failure", FMHIP_TEST_FAIL_ALLOC_AT=str(at))
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (at, r.stdout[-500:] + r.stderr[-6000:])
         assert "failure done" in r.stdout
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+def test_a_device_list_is_clean_under_both_sanitizer_builds(built, tmp_path, shards):
+    """The same scenarios behind fmhip_init_devices (csrc/sharded.cpp: one engine and one worker thread per shard, the caller's calls replayed
+    through a single-producer ring per worker, reads and reductions gathered): ASan + UBSan, then ThreadSanitizer."""
+    r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_DEVICES=str(shards))
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
+    assert r.stdout.count("done") == 10
+    t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_DEVICES=str(shards))
+    assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
+    assert t.stdout.count("done") == 10
