@@ -50,7 +50,11 @@ int fmhip_init(int device_index) {
 // One process, several devices (sharded.hpp): `count` device indices (an index may repeat: shards on separate streams of one device).
 // One entry = fmhip_init(devices[0]).
 int fmhip_init_devices(const int* devices, int count) {
-    if (count == 1 && devices) return fmhip_init(devices[0]);
+    // one entry: fmhip_init(devices[0]) — unless FMHIP_WORKER_THREAD=1 asks for the front with ONE shard: the engine's bookkeeping (recording,
+    // planning, launching) then runs on a worker thread beside the caller's own (a caller that spends as long in its model classes as the
+    // engine spends recording: the two overlap); values and statuses are the same
+    static const bool worker_thread = [] { const char* e = std::getenv("FMHIP_WORKER_THREAD"); return e && e[0] == '1'; }();
+    if (count == 1 && devices && !worker_thread) return fmhip_init(devices[0]);
     if (fm::front_active()) { g_last_error = "a device list is active already"; return FMHIP_ERR_INVALID_ARGUMENT; }
     return front::init_devices(devices, count);
 }

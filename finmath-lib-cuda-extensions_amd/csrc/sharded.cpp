@@ -263,7 +263,7 @@ namespace front {
 
 int init_devices(const int* devices, int count) {
     try {
-        if (!devices || count < 2) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a device list needs at least two entries");
+        if (!devices || count < 1) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a device list needs at least one entry");
         if (count > 64) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "more than 64 device shards");
         std::lock_guard<std::mutex> lk(g_shards_mu);
         if (g_shards) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a device list is active already");
