@@ -21,6 +21,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <string>
 #include <vector>
@@ -225,7 +226,11 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
     static int cloneChecks = 0;                                                          // the first groups verify the scalar lists against the recording
     for (int i0 = 0; i0 < lastTimeIndex;) {
         int i1 = std::min(i0 + S, lastTimeIndex);
-        if (keep) for (int s2 = i0 + 1; s2 < i1; ++s2) if ((*keep)[(size_t)s2]) { i1 = s2; break; }   // a state somebody reads ends the group
+        // A state somebody reads (an exercise date) INSIDE a group does not end it (until round 4 it did: the first ten time steps ran as five
+        // groups of two): the group keeps that state's handles, so it is one more value the group's launches store — one read of the state
+        // less, and one launch of the four-step kernel instead of two of the two-step one.  FMHIP_LMM_GROUPS_END_AT_KEPT=1: the old grouping.
+        static const bool endAtKept = std::getenv("FMHIP_LMM_GROUPS_END_AT_KEPT") && std::getenv("FMHIP_LMM_GROUPS_END_AT_KEPT")[0] == '1';
+        if (keep && endAtKept) for (int s2 = i0 + 1; s2 < i1; ++s2) if ((*keep)[(size_t)s2]) { i1 = s2; break; }
         // From time index 2 on every value of the state is a vector (L_0 is fixed at time 0, the bank account is constant until
         // L_1 is): the group's pending graph has the same shape for every parameter set — record set 0, replicate the others.
         const bool cloning = K > 1 && S > 1 && keep && be.clone && i0 >= 2;
@@ -268,6 +273,8 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
             std::vector<RV> roots, leafFrom;
             for (int j = i0 + 1; j < n; ++j) roots.push_back(sims[0].libor[(size_t)i1][(size_t)j]);
             for (int i = i0; i < i1; ++i) roots.push_back(sims[0].numeraire[(size_t)i + 1]);
+            for (int s2 = i0 + 1; s2 < i1; ++s2)                                             // states inside the group that a product reads: the components alive at that time
+                if ((*keep)[(size_t)s2]) for (int j = s2; j < n; ++j) roots.push_back(sims[0].libor[(size_t)s2][(size_t)j]);
             for (int j = i0; j < n; ++j) leafFrom.push_back(sims[0].libor[(size_t)i0][(size_t)j]);
             leafFrom.push_back(sims[0].numeraire[(size_t)i0]);
             auto scalarsOf = [&](const VolatilityModel& vol) {
@@ -302,6 +309,8 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
                 size_t r = 0;
                 for (int j = i0 + 1; j < n; ++j) nxt[(size_t)j] = copies[k - 1][r++];
                 for (int i = i0; i < i1; ++i) sims[k].numeraire[(size_t)i + 1] = copies[k - 1][r++];
+                for (int s2 = i0 + 1; s2 < i1; ++s2)
+                    if ((*keep)[(size_t)s2]) { auto& mid = sims[k].libor[(size_t)s2]; mid.resize((size_t)n); for (int j = s2; j < n; ++j) mid[(size_t)j] = copies[k - 1][r++]; }
             }
         }
         // states no product reads lose their handles BEFORE the flush: a pending value without a handle is an intermediate of the
