@@ -1389,7 +1389,11 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
             else if (!async_moments_) { all.resize(dags.size()); reduce_shift = &no_shift; host_moments = all.data(); }
             // … and where the caller has given the values up (fmhip_vec_give_up_values: every member's root, nobody else holds it) the
             // launch takes the moments and stores NOTHING: a program without outputs
-            if (reduce_shift) { moments_only = true; for (const Dag& d : dags) moments_only &= d.outs[0]->discard && d.outs[0]->refs_int == 0; }
+            // (the root of a copy that exists as a description carries one internal reference, its group's hold, until the launch is done)
+            if (reduce_shift) {
+                moments_only = true;
+                for (const Dag& d : dags) { const Node* r = d.outs[0]; moments_only &= r->discard && r->refs_int == ((r->rep_id && r->rep_copy && replica_of(r)) ? 1 : 0); }
+            }
         }
     }
     const std::string key = reduce_shift ? d0.sig + (moments_only ? "\xfeM" : "\xfeR") : d0.sig;       // the program that also reduces its root is a different program
