@@ -712,7 +712,7 @@ def main():
     # correction applied): NOT measured in this run — counters need a profiler pass of their own — but OFFLINE on this exact
     # workload, committed under profiles/ (newest round first); null for other shapes.
     traffic, traffic_source = None, None
-    for name in ("round03_hbm_traffic.json", "round02_hbm_traffic.json", "round01_hbm_traffic.json"):
+    for name in ("round04_hbm_traffic.json", "round03_hbm_traffic.json", "round02_hbm_traffic.json", "round01_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 prof = json.load(fh)
