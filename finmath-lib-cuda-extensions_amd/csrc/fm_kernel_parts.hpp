@@ -303,10 +303,17 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
     const uint32_t slots = gridDim.x + FM_COMBINE_GROUP_SLOTS;             // per (row, reduction)
     const uint32_t spans = (gridDim.x + Q - 1u) / Q;
     const uint32_t G = combine_groups(spans);
-    const uint32_t g = (blockIdx.x / Q) % G;
-    const uint32_t group_spans = (spans - g + G - 1u) / G;
+    // A row of one group whose workgroups all run at once (ONE row of 10^6 paths, a unit per workgroup: 489) would still queue 489 adds
+    // on one counter — 6 µs behind a kernel of 5 (benchmarks/single_row_stream.cpp: 13.0 µs with the reduction, 4.6 without).  Such a row
+    // COUNTS in seven groups as well; the arithmetic stays that of one group (the row's last workgroup adds every span partial in the
+    // order it always did), so the moments do not change.
+    const uint32_t C = (G == 1u && gridDim.x >= FM_COUNT_IN_GROUPS_FROM) ? 7u : G;
+    const uint32_t cg = (blockIdx.x / Q) % C;
+    const uint32_t counted_spans = (spans - cg + C - 1u) / C;
     // workgroups of the group: Q per span, except that the row's last span may have fewer
-    const uint32_t members = group_spans * Q - (((spans - 1u) % G == g) ? spans * Q - gridDim.x : 0u);
+    const uint32_t members = counted_spans * Q - (((spans - 1u) % C == cg) ? spans * Q - gridDim.x : 0u);
+    const uint32_t g = (G == 1u) ? 0u : cg;
+    const uint32_t group_spans = (G == 1u) ? spans : counted_spans;
     uint32_t group_last = 0u;
     if (lane == 0u) {
 #pragma unroll
@@ -320,7 +327,7 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
         // the partial is in memory before this workgroup is counted (the stores are drained, then the counter moves)
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)g * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(counter + (size_t)cg * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         // Ordering of this hand-off.  Producer: every partial is an sc1 (write-through) store, drained by the s_waitcnt above before the
         // counter moves (MI355X_MICROARCH.md, "Valid forms", sc1 table; FM_HANDOFF_RELEASE = 1 makes the add an agent-scope RELEASE on
         // top: buffer_wbl2 + wait in front of it).  Consumer: the last arriver learns that it is last from the value its own add
@@ -332,8 +339,15 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (arrived == members - 1u) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(counter + (size_t)g * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            __hip_atomic_store(counter + (size_t)cg * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             group_last = 1u;
+            if (C != G) {       // counted in groups, added as one: the last of the seven last arrivers goes on (the partials of every group are in memory:
+                                // each of its members drained its stores before it was counted, and this add follows the group's last count)
+                const uint32_t groups_counted = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                if (groups_counted == C - 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                else group_last = 0u;
+            }
         }
     }
     if (__builtin_amdgcn_readfirstlane(group_last) == 0u) return;           // lane 0 is the first active lane

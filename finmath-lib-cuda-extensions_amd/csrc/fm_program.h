@@ -90,6 +90,7 @@ constexpr int FM_INLINE_WORDS = 368;    // row blocks carried in the kernel argu
 // on one address; packed into one or two cache lines the counters of all rows of a launch serialise there (measured on 64
 // rows x 123 workgroups: stand-alone reduction 95 µs packed, 44 µs apart; the bench launch with 4x the workgroups 363 → 223 µs).
 constexpr uint32_t FM_COUNTER_STRIDE = 64;      // in uint32_t
+constexpr uint32_t FM_COUNT_IN_GROUPS_FROM = 256;  // workgroups of a row from which a row of ONE combine group counts its arrivals in seven (block_combine)
 constexpr uint32_t FM_MAX_ROWS = 65536;
 constexpr uint32_t FM_COUNTER_PLANES = 8;
 constexpr size_t   FM_COUNTER_PLANE = (size_t)FM_MAX_ROWS * FM_COUNTER_STRIDE;      // in uint32_t
