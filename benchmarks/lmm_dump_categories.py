@@ -17,7 +17,7 @@ def load(p):
 def cat(r):
     if r['tier'] == 'interpreter': return 'interpreter'
     if r['o'] <= 1 and r['ops'] >= 9: return 'valuation %s%s%s' % ('>= 40 rows' if r['rows'] >= 40 else '< 40 rows', '' if r['red'] else ' (no expectation)', '' if r['o'] else ', value not stored')
-    if r['o'] > 20:         # a group of time steps: ≈ 25 operations per component read for four steps, ≈ 13 for two; a state kept inside the group is a second output per component
+    if r['o'] > 20 and r['ops'] > 0:         # a group of time steps: ≈ 25 operations per component read for four steps, ≈ 13 for two; a state kept inside the group is a second output per component
         steps = 'simulation 4 steps' if r['ops'] / max(1, r['i']) > 20 else 'simulation 2 steps'
         return steps + (' + a kept state' if r['o'] > 1.4 * r['i'] else '') + (' x 8 rows' if r['rows'] == 8 else ' x 1-2 rows')
     return 'other'
