@@ -338,16 +338,16 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
         // whichever compiler (hipcc today, hiprtc at run time) builds this header.
         __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (arrived == members - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(counter + (size_t)cg * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             group_last = 1u;
             if (C != G) {       // counted in groups, added as one: the last of the seven last arrivers goes on (the partials of every group are in memory:
                                 // each of its members drained its stores before it was counted, and this add follows the group's last count)
                 const uint32_t groups_counted = __hip_atomic_fetch_add(counter + (size_t)7 * FM_COUNTER_PLANE, 1u, FM_HANDOFF_ADD_ORDER, __HIP_MEMORY_SCOPE_AGENT);
                 __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                if (groups_counted == C - 1u) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                else group_last = 0u;
+                group_last = (groups_counted == C - 1u) ? 1u : 0u;
             }
+            if (group_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counter + (size_t)cg * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            if (C != G && group_last) __hip_atomic_store(counter + (size_t)7 * FM_COUNTER_PLANE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (__builtin_amdgcn_readfirstlane(group_last) == 0u) return;           // lane 0 is the first active lane
