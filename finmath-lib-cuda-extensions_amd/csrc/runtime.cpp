@@ -12,6 +12,8 @@
 #include <functional>
 #include <map>
 #include <sstream>
+#include <thread>
+#include <chrono>
 #include <unordered_set>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -2786,7 +2788,19 @@ Engine::MomentsTicket Engine::ticket_take(int64_t id) {
             arrived = complete();
             if (!arrived && (spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
-        if (!arrived) { hip_check(hipStreamSynchronize(stream_), "moments sync"); arrived = complete(); }
+        // Not there after 2 ms of spinning: the launch that writes it is far down the queue.  Keep watching THIS slot, asleep in between —
+        // never hipStreamSynchronize: that waits for everything queued behind as well (a driver that records batch b+1 before it asks
+        // for batch b's expectations lost its overlap at every second batch that way: the device drained, then idled 2 ms per batch
+        // while the host recorded the next one).  A stream that has run dry without the slot being written is an error.
+        for (uint32_t naps = 1; !arrived; ++naps) {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            arrived = complete();
+            if (!arrived && (naps & 63u) == 0) {
+                const hipError_t q = hipStreamQuery(stream_);
+                if (q == hipSuccess) { arrived = complete(); break; }
+                if (q != hipErrorNotReady) hip_check(q, "hipStreamQuery(moments)");
+            }
+        }
         if (!arrived) throw Error(FMHIP_ERR_HIP, "the moments of a vector never arrived");
         std::atomic_thread_fence(std::memory_order_acquire);
         uint64_t v[4] = { slot[0], slot[1], slot[2], slot[3] };

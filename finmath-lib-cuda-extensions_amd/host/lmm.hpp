@@ -501,6 +501,8 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
             current.bumped.assign((size_t)(a1 - a0), vol);
             std::vector<const VolatilityModel*> ptrs;
             for (int a = a0; a < a1; ++a) { current.bumped[(size_t)(a - a0)].parameter[(size_t)active[(size_t)a]] += parameterStep; ptrs.push_back(&current.bumped[(size_t)(a - a0)]); }
+            static const bool timeline = std::getenv("FMHIP_LMM_TIMELINE") != nullptr;        // stderr: when a batch was recorded, when the one before it was collected
+            const auto tb0 = clk::now();
             try { current.pending = evaluateManyBegin(m, ptrs, be); current.valid = true; }
             catch (const std::exception& e) {           // K simultaneous states did not fit the device: one by one instead
                 if (ptrs.size() == 1 || std::string(e.what()).find("allocation") == std::string::npos) throw;
@@ -514,7 +516,11 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
                 }
                 continue;
             }
+            const auto tb1 = clk::now();
             collect(previous);
+            if (timeline) std::fprintf(stderr, "[lmm timeline] iteration %d batch from %d: begin %.3f … %.3f ms, previous collected at %.3f ms\n", it, a0,
+                                       std::chrono::duration<double, std::milli>(tb0 - start).count(), std::chrono::duration<double, std::milli>(tb1 - start).count(),
+                                       std::chrono::duration<double, std::milli>(clk::now() - start).count());
             previous = std::move(current);
         }
         collect(previous);

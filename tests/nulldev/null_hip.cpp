@@ -74,6 +74,7 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret
 hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, 0); }
 hipError_t hipStreamDestroy(hipStream_t s) { delete reinterpret_cast<int*>(s); return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(new int(0)); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<int*>(e); return hipSuccess; }
