@@ -259,7 +259,7 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
 }
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
     FRONT(unsupported("fmhip_reduce_moments_batch_device"));
-    return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch(vectors, count, shifts, nullptr, device_out); });
+    return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch_device(vectors, count, shifts, device_out); });
 }
 int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out) {
     FRONT(reduce_moments_batch_begin(vectors, count, shifts, ticket_out));

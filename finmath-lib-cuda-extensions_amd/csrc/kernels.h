@@ -22,4 +22,10 @@ hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double*
 hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st);
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st);
 
+// {Σ, Σ², min, max} blocks of 32 bytes collected from wherever the launches that took them left them (slots of the pinned moments arena,
+// mapped into the device's address space) into one contiguous device buffer — the send buffer of an RCCL exchange.
+constexpr int FM_GATHER_MAX = 384;                 // sources per launch: they travel in the kernel arguments (3 KB of the 4 KB segment)
+struct DevGatherArgs { uint32_t count; uint32_t pad; uint64_t src[FM_GATHER_MAX]; };
+hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t st);
+
 } // namespace fm

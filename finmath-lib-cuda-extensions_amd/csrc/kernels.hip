@@ -341,6 +341,17 @@ __global__ void __launch_bounds__(FM_BLOCK) fm_fill_kernel(float4* __restrict__ 
         p[i] = make_float4(v, v, v, v);
 }
 
+// one lane per {Σ, Σ², min, max} block: 32 bytes from host-coherent memory (written earlier in this stream by the launches that took the
+// moments) to out[i]
+__global__ void __launch_bounds__(64) fm_gather_moments_kernel(const DevGatherArgs A, double* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    if (i >= A.count) return;
+    const volatile double* s = reinterpret_cast<const volatile double*>(A.src[i]);
+    const double v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+    out[(size_t)i * 4 + 0] = v0; out[(size_t)i * 4 + 1] = v1; out[(size_t)i * 4 + 2] = v2; out[(size_t)i * 4 + 3] = v3;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers (the only functions the runtime calls)
 // ---------------------------------------------------------------------------------------------
@@ -392,6 +403,13 @@ hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st)
     if (bx > 2048) bx = 2048;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(fm_fill_kernel, dim3((uint32_t)bx), dim3(FM_BLOCK), 0, st, reinterpret_cast<float4*>(p), v, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t st)
+{
+    if (a.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(fm_gather_moments_kernel, dim3((a.count + 63u) / 64u), dim3(64), 0, st, a, out);
     return hipGetLastError();
 }
 

@@ -2770,6 +2770,66 @@ int64_t Engine::reduce_batch_begin_from_launches(const fmhip_vec* hs, int count)
     return id;
 }
 
+// fmhip_reduce_moments_batch_device on vectors that may still be pending: as reduce_batch_begin_from_launches — the flush that computes them
+// takes their moments along (values that were given up are not stored at all) — but the caller wants the 32-byte blocks in ONE device
+// buffer, in the order asked (the send buffer of its RCCL exchange), not on the host: a one-wave kernel behind the launches collects them
+// from their slots of the pinned arena, which the device reads through the same mapping it wrote them through.  Until round 4 a caller
+// with a communicator of its own (lmm_hip --world N) had to flush first and pay a reduction launch that read every value again.
+void Engine::reduce_batch_device_from_launches(const fmhip_vec* hs, int count, void* dev_out) {
+    end_step_group();
+    std::vector<Node*> nds((size_t)count);
+    for (int i = 0; i < count; ++i) nds[(size_t)i] = node(hs[i]);
+    for (int i = 1; i < count; ++i)
+        if (nds[(size_t)i]->n != nds[0]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "batched reduction over vectors of different size");
+    bool pending = false;
+    for (Node* nd : nds) pending |= !nd->buf && !nd->discarded;
+    if (pending) {
+        struct Mode { Engine* e; ~Mode() { e->want_root_moments_ = false; e->async_moments_ = false; } } mode{ this };
+        want_root_moments_ = true; async_moments_ = true;
+        flush_all();
+    }
+    // one block of the arena for whatever has no slot yet, taken BEFORE the vectors are sorted: if the arena wraps here, the slots written so
+    // far are collected into their nodes (has_moments) now and not between two looks at them
+    double* block = arena_alloc((size_t)count);
+    if (!block) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "too many expectations for one call");
+    std::vector<fmhip_vec> rest;
+    std::vector<uint64_t> src((size_t)count, 0);
+    size_t used = 0;
+    std::vector<size_t> rest_index;
+    for (int i = 0; i < count; ++i) {
+        Node* nd = nds[(size_t)i];
+        if (nd->moments_slot) src[(size_t)i] = (uint64_t)(uintptr_t)nd->moments_slot;
+        else if (nd->has_moments) { double* at = block + 4 * used++; std::memcpy(at, nd->moments, 32); src[(size_t)i] = (uint64_t)(uintptr_t)at; }
+        else { rest.push_back(hs[i]); rest_index.push_back((size_t)i); }
+    }
+    if (!rest.empty()) {           // computed earlier, or by a launch that could not take the moments along: one reduction launch, into the block
+        double* at = block + 4 * used;
+        reduce_batch(rest.data(), (int)rest.size(), nullptr, nullptr, at);
+        for (size_t k = 0; k < rest.size(); ++k) src[rest_index[k]] = (uint64_t)(uintptr_t)(at + 4 * k);
+        used += rest.size();
+    }
+    { volatile uint64_t* tail = reinterpret_cast<volatile uint64_t*>(block + 4 * used); for (size_t i = 0; i < ((size_t)count - used) * 4; ++i) tail[i] = 0; }    // (unused slots: no sentinels left behind)
+    for (int off = 0; off < count; off += FM_GATHER_MAX) {
+        DevGatherArgs a{};
+        a.count = (uint32_t)std::min(FM_GATHER_MAX, count - off);
+        std::memcpy(a.src, src.data() + off, (size_t)a.count * 8);
+        hip_check(launch_gather_moments(a, (double*)dev_out + (size_t)off * 4, stream_), "launch fm_gather_moments_kernel");
+        n_launches_++;
+    }
+}
+
+void Engine::reduce_batch_device(const fmhip_vec* hs, int count, const double* shifts, void* dev_out) {
+    require_init();
+    if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+    static const bool FROM_LAUNCHES = [] { const char* e = std::getenv("FMHIP_MOMENTS_FROM_LAUNCHES"); return !(e && e[0] == '0'); }();
+    bool unshifted = true;
+    for (int i = 0; shifts && i < count; ++i) unshifted &= shifts[i] == 0.0;
+    bool worth = false;                                          // something is pending, given up, or has its moments already
+    if (FROM_LAUNCHES && fusion && unshifted) for (int i = 0; i < count && !worth; ++i) { const Node* nd = node(hs[i]); worth = !nd->buf || nd->has_moments || nd->moments_slot; }
+    if (worth) reduce_batch_device_from_launches(hs, count, dev_out);
+    else reduce_batch(hs, count, shifts, nullptr, dev_out);
+}
+
 Engine::MomentsTicket Engine::ticket_take(int64_t id) {
     auto it = tickets_.find(id);
     if (it == tickets_.end()) throw Error(FMHIP_ERR_INVALID_HANDLE, "unknown (or already ended) expectation ticket");

@@ -267,6 +267,8 @@ public:
                            std::vector<volatile uint64_t*> slots; std::vector<fmhip_moments> ready; };
     int64_t reduce_batch_begin(const fmhip_vec* hs, int count, const double* shifts);
     int64_t reduce_batch_begin_from_launches(const fmhip_vec* hs, int count);
+    void reduce_batch_device(const fmhip_vec* hs, int count, const double* shifts, void* dev_out);
+    void reduce_batch_device_from_launches(const fmhip_vec* hs, int count, void* dev_out);   // the same moments into a device buffer (an RCCL send buffer): gathered in-stream from their arena slots
     void give_up_values(const fmhip_vec* hs, int count);
     MomentsTicket ticket_take(int64_t id);                   // removes it from the table (under the lock)
     void ticket_retire(MomentsTicket& t);                    // block and event back to their free lists (under the lock)

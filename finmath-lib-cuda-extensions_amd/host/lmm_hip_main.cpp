@@ -81,7 +81,10 @@ int main(int argc, char** argv) {
                 ~Flight() { if (dev) fmhip_vec_release(dev); if (host && ev && spare) spare->push_back({ host, ev }); }
             };
             static std::vector<std::pair<double*, hipEvent_t>> spare;                  // (all of one size: count x world)
-            be.expectationsRunPending = false;           // (the sharded reduction leaves its partials on the device: an ordinary reduction launch)
+            // The sharded reduction wants its partials on the device (the send buffer of the all-gather).  Since round 4 the launches that
+            // compute the payoffs take their moments along here too and a one-wave kernel collects them into that buffer
+            // (fmhip_reduce_moments_batch_device on pending vectors); FMHIP_LMM_SHARDED_FROM_LAUNCHES=0: flush first, then a reduction launch.
+            { const char* e = std::getenv("FMHIP_LMM_SHARDED_FROM_LAUNCHES"); be.expectationsRunPending = !(e && e[0] == '0'); }
             be.averagesAsync = [=, &collectives, &collective_seconds](const std::vector<RV>& v) -> std::function<std::vector<double>()> {
                 std::vector<fmhip_vec> h;
                 for (const RV& x : v) {

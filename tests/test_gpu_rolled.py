@@ -375,3 +375,53 @@ def test_values_given_up_are_not_stored_and_their_moments_are_the_same(gpu, orac
     finally:
         gpu.set_jit(prev_jit)
         gpu.set_fusion(prev_fusion)
+
+
+def test_moments_into_a_device_buffer_come_from_the_launches_too(gpu, oracle):
+    """fmhip_reduce_moments_batch_device on PENDING vectors (the send buffer of a caller's own RCCL exchange: lmm_hip --world N): the flush
+    that computes them takes their moments along, given-up values are not stored, and a one-wave kernel collects the 32-byte blocks from the
+    pinned arena into the caller's buffer in the order asked — the same bits as the host-side ticket, for pending vectors, vectors
+    computed earlier (a reduction launch into the arena) and vectors whose moments are known already, mixed in one call."""
+    import ctypes as C
+    n, periods, products = 30_011, 24, 10
+    rng = np.random.default_rng(78)
+    libors = [oracle.f_from_double(rng.uniform(0.005, 0.04, n)) for _ in range(periods + products)]
+    num = oracle.f_from_double(rng.uniform(1.0, 1.3, n))
+    prev_fusion, prev_jit = gpu.set_fusion(True), gpu.set_jit(gpu.JIT_SYNC)
+    try:
+        dev = [gpu.DeviceVector.from_host(x) for x in libors]
+        dnum = gpu.DeviceVector.from_host(num)
+
+        def all_chains():
+            soft = gpu.fusion_hold(2)
+            chains = [swaption_like_chain(lambda p: dev[p + k], 3 if k % 2 else periods, dnum, 0.02 + 0.001 * k, 0.5) for k in range(products)]
+            gpu.fusion_hold(soft)
+            return chains
+        for attempt in range(3):
+            chains = all_chains()
+            ticket = gpu.reduce_moments_batch_begin(chains)
+            want = np.array([(m.sum, m.sumsq, m.min, m.max) for m in gpu.reduce_moments_batch_end(ticket, len(chains))])
+            del chains
+            chains = all_chains()
+            early = dev[0].v1s1("MULT_S", 3.0); early.to_float32()         # computed earlier, no moments yet
+            known = dev[1].v1s1("ADD_S", 1.0); m_known = known.moments()    # moments known already
+            m_early = None
+            gpu.give_up_values(chains[:6])                                  # some given up, some not
+            asked = chains[:5] + [early, known] + chains[5:]
+            k = len(asked)
+            handles = (C.c_int64 * k)(*[w.handle for w in asked])
+            out = gpu.DeviceVector.filled(8 * k, 0.0)
+            gpu._native.check(gpu.lib().fmhip_reduce_moments_batch_device(handles, k, None, C.c_void_p(out.device_ptr())))
+            raw = out.to_float32().view(np.float64).reshape(k, 4)
+            got = np.concatenate([raw[:5], raw[7:]])
+            assert got.tobytes() == want.tobytes(), attempt
+            m_early = early.moments()
+            assert raw[5].tobytes() == np.array([m_early.sum, m_early.sumsq, m_early.min, m_early.max]).tobytes()
+            assert raw[6].tobytes() == np.array([m_known.sum, m_known.sumsq, m_known.min, m_known.max]).tobytes()
+            m = chains[2].moments()                                         # asked again on the host: from the node's slot
+            assert np.array([m.sum, m.sumsq, m.min, m.max]).tobytes() == want[2].tobytes()
+            del chains, asked, early, known
+        gpu.flush()
+    finally:
+        gpu.set_jit(prev_jit)
+        gpu.set_fusion(prev_fusion)
