@@ -160,6 +160,13 @@ static void scenario_expectations() {
         OK(fmhip_fusion_hold(0, nullptr));
         if (round % 2 == 1) OK(fmhip_vec_give_up_values(payoffs.data(), (int)payoffs.size()));
         if (round % 4 == 3) { V keep = s1(FMHIP_OP_ADD_S, payoffs[1], 1.0); rel(keep); }       // a consumer of a given-up value that goes away again
+        int shards = 1; OK(fmhip_device_count(&shards));
+        if (round % 3 == 0 && shards == 1) {        // the same moments into a device buffer (a caller with its own exchange): collected from the arena by a kernel
+            V send = 0; OK(fmhip_vec_create_uninitialized((int64_t)payoffs.size() * 8, &send));
+            void* dev = nullptr; OK(fmhip_vec_device_ptr(send, &dev));
+            OK(fmhip_reduce_moments_batch_device(payoffs.data(), (int)payoffs.size(), nullptr, dev));
+            rel(send);
+        }
         fmhip_ticket t = 0;
         OK(fmhip_reduce_moments_batch_begin(payoffs.data(), (int)payoffs.size(), nullptr, &t));
         tickets.push_back(t); counts.push_back((int)payoffs.size());

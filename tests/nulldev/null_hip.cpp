@@ -53,6 +53,11 @@ hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t) {
     for (uint32_t s = 0; s < n_streams; ++s) { volatile float* p = a.slab + (size_t)s * a.stride_floats; if (a.n_paths > 0) { p[0] = 0.01f; p[a.n_paths - 1] = -0.01f; } }
     return hipSuccess;
 }
+hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t) {
+    ++g_launches;
+    for (uint32_t i = 0; i < a.count; ++i) std::memcpy(out + (size_t)i * 4, reinterpret_cast<const void*>((uintptr_t)a.src[i]), 32);
+    return hipSuccess;
+}
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t) { ++g_launches; for (int64_t i = 0; i < n_padded; ++i) p[i] = v; return hipSuccess; }
 }
 
