@@ -537,7 +537,11 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
             VolatilityModel v = vol;
             for (int a = 0; a < np; ++a) v.parameter[(size_t)active[(size_t)a]] += step[(size_t)a];
             std::vector<double> mv;
+            const auto tt0 = clk::now();
             residuals(v, rTrial, &mv);
+            static const bool timeline2 = std::getenv("FMHIP_LMM_TIMELINE") != nullptr;
+            if (timeline2) std::fprintf(stderr, "[lmm timeline] iteration %d trial %d: %.3f … %.3f ms\n", it, attempt, std::chrono::duration<double, std::milli>(tt0 - start).count(),
+                                        std::chrono::duration<double, std::milli>(clk::now() - start).count());
             const double e = sumsq(rTrial);
             if (e < err) { improved = true; const double rel = (err - e) / err; vol = v; r = rTrial; err = e; modelVols = mv; lambda = std::max(lambda / 3.0, 1e-9); if (rel < accuracy) it = maxIterations; }
             else lambda *= 4.0;
