@@ -97,6 +97,31 @@ def test_large_vector_closed_form(gpu, n):
         assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == -2.0 and m.max == 6.0
 
 
+@pytest.mark.parametrize("n", [520_000, 524_288, 524_289, 600_000, 1_000_000, 2_097_152, 2_200_000, 3_999_999, 4_194_303])
+def test_one_row_that_counts_its_arrivals_in_groups(gpu, n):
+    """A row of ONE arithmetic group whose launch has 256 or more workgroups (round 4: fm_kernel_parts.hpp block_combine, FM_COUNT_IN_GROUPS_FROM)
+    counts its arrivals in seven groups and a second level; the sums are still those of one group.  The sizes sit on both sides of that
+    threshold for a unit per workgroup (one row of up to 128 spans: 254, 256, 257, 293, 489 workgroups) and for a span per workgroup
+    (256 … 511 spans); each vector alone, twice (the counters of both levels must be back at zero), then as one of three rows of a launch
+    (another launch shape: a span per workgroup, fewer than 256 of them per row for the smaller sizes) — exact sums, the same bits."""
+    x = (np.arange(n, dtype=np.int64) % 5).astype(np.float32)
+    x[n // 7] = -3.0
+    x[n - 1] = 9.0
+    xs = x.astype(np.float64)
+    v = dv(gpu, x)
+    alone = []
+    for _ in range(2):
+        m = v.moments()
+        assert m.sum == xs.sum() and m.sumsq == (xs * xs).sum() and m.min == -3.0 and m.max == 9.0, n
+        alone.append((m.sum, m.sumsq, m.min, m.max))
+    others = [dv(gpu, np.full(n, 0.5, dtype=np.float32)), dv(gpu, (np.arange(n) % 3).astype(np.float32))]
+    p = gpu.Program(1); p.reduce(0); p.compile()
+    for _ in range(2):
+        m = np.asarray(p.run([[others[0]], [v], [others[1]]])[1]).reshape(3, 4)
+        assert tuple(m[1]) == alone[0], n
+        assert m[0][0] == 0.5 * n and m[2][3] == 2.0
+
+
 def test_hand_off_with_warm_caches_and_many_workgroups_per_cu(gpu, oracle):
     """The cross-workgroup hand-off of the partials (fm_kernel_parts.hpp: block_combine) where a stale cache line would show: the SAME
     output buffers, partial slots and arrival counters are reused launch after launch with DIFFERENT data (A, B, A, C, …), many rows
