@@ -274,7 +274,7 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
             for (int j = i0 + 1; j < n; ++j) roots.push_back(sims[0].libor[(size_t)i1][(size_t)j]);
             for (int i = i0; i < i1; ++i) roots.push_back(sims[0].numeraire[(size_t)i + 1]);
             for (int s2 = i0 + 1; s2 < i1; ++s2)                                             // states inside the group that a product reads: the components alive at that time
-                if ((*keep)[(size_t)s2]) for (int j = s2; j < n; ++j) roots.push_back(sims[0].libor[(size_t)s2][(size_t)j]);
+                if (!keep || (*keep)[(size_t)s2]) for (int j = s2; j < n; ++j) roots.push_back(sims[0].libor[(size_t)s2][(size_t)j]);   // (no list: every state is kept)
             for (int j = i0; j < n; ++j) leafFrom.push_back(sims[0].libor[(size_t)i0][(size_t)j]);
             leafFrom.push_back(sims[0].numeraire[(size_t)i0]);
             auto scalarsOf = [&](const VolatilityModel& vol) {
@@ -310,7 +310,7 @@ inline std::vector<Simulation> simulateMany(const Market& m, const std::vector<c
                 for (int j = i0 + 1; j < n; ++j) nxt[(size_t)j] = copies[k - 1][r++];
                 for (int i = i0; i < i1; ++i) sims[k].numeraire[(size_t)i + 1] = copies[k - 1][r++];
                 for (int s2 = i0 + 1; s2 < i1; ++s2)
-                    if ((*keep)[(size_t)s2]) { auto& mid = sims[k].libor[(size_t)s2]; mid.resize((size_t)n); for (int j = s2; j < n; ++j) mid[(size_t)j] = copies[k - 1][r++]; }
+                    if (!keep || (*keep)[(size_t)s2]) { auto& mid = sims[k].libor[(size_t)s2]; mid.resize((size_t)n); for (int j = s2; j < n; ++j) mid[(size_t)j] = copies[k - 1][r++]; }
             }
         }
         // states no product reads lose their handles BEFORE the flush: a pending value without a handle is an intermediate of the
