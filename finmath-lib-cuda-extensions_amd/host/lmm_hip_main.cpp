@@ -39,6 +39,7 @@ int main(int argc, char** argv) {
             be.jacobianBatch = 1; be.stepsPerLaunch = 1; be.chunk = 1 << 30; be.keepAllStates = true;
         }
         ncclComm_t comm = nullptr;
+        std::vector<std::pair<double*, hipEvent_t>> sparePinned;      // pinned blocks and events of finished sharded expectations, used again
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)
         long long collectives = 0;
         double collective_seconds = 0.0;                 // host wall time from enqueueing the collective to having its result (latency of the exchange incl. the read-back)
@@ -80,7 +81,7 @@ int main(int argc, char** argv) {
                 std::vector<std::pair<double*, hipEvent_t>>* spare = nullptr;          // pinned blocks and events are used again (allocating them costs ≈ 0.2 ms)
                 ~Flight() { if (dev) fmhip_vec_release(dev); if (host && ev && spare) spare->push_back({ host, ev }); }
             };
-            static std::vector<std::pair<double*, hipEvent_t>> spare;                  // (all of one size: count x world)
+            std::vector<std::pair<double*, hipEvent_t>>* const spare = &sparePinned;     // (all of one size: count x world; freed at the end of main)
             // The sharded reduction wants its partials on the device (the send buffer of the all-gather).  Since round 4 the launches that
             // compute the payoffs take their moments along here too and a one-wave kernel collects them into that buffer
             // (fmhip_reduce_moments_batch_device on pending vectors); FMHIP_LMM_SHARDED_FROM_LAUNCHES=0: flush first, then a reduction launch.
@@ -96,8 +97,8 @@ int main(int argc, char** argv) {
                 auto f = std::make_shared<Flight>();
                 const size_t doubles = (size_t)count * 4 * (size_t)world;
                 check(fmhip_vec_create_uninitialized((int64_t)doubles * 2, &f->dev));
-                f->spare = &spare;
-                if (!spare.empty()) { f->host = spare.back().first; f->ev = spare.back().second; spare.pop_back(); }
+                f->spare = spare;
+                if (!spare->empty()) { f->host = spare->back().first; f->ev = spare->back().second; spare->pop_back(); }
                 else if (hipHostMalloc((void**)&f->host, doubles * 8, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&f->ev, hipEventDisableTiming) != hipSuccess)
                     throw std::runtime_error("pinned memory / event for a sharded expectation");
                 void* dev = nullptr; check(fmhip_vec_device_ptr(f->dev, &dev));
@@ -184,6 +185,8 @@ int main(int argc, char** argv) {
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);
         else { lmm::Options quiet = o; quiet.verbose = false; lmm::runAndReport(quiet, be, "hip", extra); }        // every rank reports: the launcher compares the parameter vectors
         if (sums) fmhip_vec_release(sums);
+        be = lmm::Backend();                                // (closures that may still hold a flight)
+        for (auto& pe : sparePinned) { (void)hipHostFree(pe.first); (void)hipEventDestroy(pe.second); }
         if (comm) ncclCommDestroy(comm);
         check(fmhip_shutdown());
     } catch (const std::exception& e) { std::fprintf(stderr, "lmm_hip[rank %d]: %s\n", o.rank, e.what()); return 1; }

@@ -16,7 +16,7 @@ NULLDEV = os.path.join(HERE, "nulldev")
 
 @pytest.fixture(scope="module")
 def built():
-    r = subprocess.run(["make", "-C", NULLDEV, "-j8", "asan", "tsan"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run(["make", "-C", NULLDEV, "-j8", "asan", "tsan", "lmm_asan", "lmm_tsan"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return os.path.join(NULLDEV, "build")
 
@@ -61,3 +61,26 @@ def test_a_device_list_is_clean_under_both_sanitizer_builds(built, tmp_path, sha
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
     assert t.stdout.count("done") == 10
+
+
+def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_path):
+    """The real workload instead of hand-made scenarios: host/lmm_hip_main.cpp (the LMM calibration driver over the C-ABI) linked against the
+    null device — Jacobian batches as replica descriptions, payoff values given up, expectation tickets collected one batch late, rolled and
+    peeled plans of the 80-rate simulation, the caller without hints (every method a node, time steps grouped by the engine), a device list
+    of two shards, and the path-sharded form whose expectation partials are gathered into a device buffer (RCCL replaced by stand-ins).
+    The numbers are meaningless (the null device computes nothing): what is checked is that every one of these runs ends with status 0 and
+    nothing for ASan / UBSan / LeakSanitizer, resp. ThreadSanitizer, to report."""
+    asan, tsan = os.path.join(built, "lmm_asan"), os.path.join(built, "lmm_tsan")
+    base = ["--paths", "3000"]
+    cases = [["--mode", "calibrate", "--max-iterations", "1"],
+             ["--mode", "evaluate", "--evaluations", "3", "--finmath-like"],
+             ["--mode", "calibrate", "--max-iterations", "1", "--devices", "0,0"],
+             ["--mode", "calibrate", "--max-iterations", "1", "--world", "1", "--rank", "0", "--nccl-id-file", str(tmp_path / "id"), "--nccl-nonce", "5"]]
+    for args in cases:
+        r = run(asan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stdout[-500:] + r.stderr[-6000:])
+        assert '"evaluations"' in r.stdout
+    for args in (cases[0], cases[2]):
+        t = run(tsan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
+        assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
+
