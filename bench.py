@@ -316,6 +316,18 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                                    "what": "the same calibration through methods + getAverage() only; the engine groups time steps itself (fmhip_set_step_grouping)"}
         except Exception as e:
             lmm["finmath_like"] = {"error": str(e)[-500:]}
+        # ONE process, a device LIST (fmhip_init_devices: an engine and a worker thread per shard behind the same handles).  A gpurun / driver
+        # box lends this rank one GPU, so the list names it twice: two shards of ONE GPU — what the front costs and that it calibrates the
+        # same parameters, NOT a scaling figure.  Unmeasured on more than one physical GPU.
+        try:
+            dl, _ = run(base + ["--devices", "0,0"])
+            lmm["device_list_rehearsal"] = {"devices": [0, 0], "seconds": dl["seconds"], "mean_deviation": dl["mean_deviation"],
+                                            "same_acceptance": abs(dl["mean_deviation"]) < 2e-4,
+                                            "what": "the same calibration in one process behind fmhip_init_devices({0, 0}): two path shards on separate streams of ONE GPU "
+                                                    "(expectations = the shards' moments combined in shard order); the cost of the front, not a scaling figure - "
+                                                    "unmeasured on more than one physical GPU"}
+        except Exception as e:
+            lmm["device_list_rehearsal"] = {"error": str(e)[-500:]}
         if cpu_base:
             cj, _ = run([LMM_CPU, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"])
             per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]
