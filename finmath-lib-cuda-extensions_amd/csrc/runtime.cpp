@@ -1529,27 +1529,29 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
     // The signature of a list of nodes: per node its opcode, its operands (positions in the list; leaves by order of discovery) and
     // whether it is needed outside the component; and its hash, 8 bytes at a time.
     auto sign = [&](const std::vector<Node*>& order, std::string& sig, std::vector<char>* escapes_out) {
-        sig.clear();
-        sig.reserve(order.size() * 8 + 8);
-        sig.push_back((char)('0' + math_mode));
-        auto put16 = [&](int v) { sig.push_back((char)(v & 0xff)); sig.push_back((char)((v >> 8) & 0xff)); };
-        for (size_t i = 0; i < order.size(); ++i) {
-            Node* nd = order[i];
-            sig.push_back((char)nd->opcode);
-            for (int k = 0; k < 3; ++k) put16(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0);
+        // one byte for the math mode, then 8 bytes per node — opcode, three operands of 16 bits, the flag — written as ONE word each and
+        // hashed as they are written (until round 4: eight push_backs per node and a second pass for the hash; ≈ 15 ns per node, a tenth of
+        // the host's time for a caller without hints)
+        const size_t count = order.size();
+        sig.resize(1 + count * 8);
+        sig[0] = (char)('0' + math_mode);
+        char* p = &sig[1];
+        if (escapes_out) escapes_out->resize(count);
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)math_mode;
+        for (size_t i = 0; i < count; ++i, p += 8) {
+            const Node* nd = order[i];
             // needed outside the component — unless it is a root whose VALUE the caller has given up (moments only, Node::discard): not an
             // output of the component then ('m': a shape of its own, its peeled kernels do not store it; launches that cannot take the
             // moments along — segments — go by the nodes' references and store it all the same)
             const bool moments_only = nd->discard && nd->refs_int == 0;
             const bool escapes = !moments_only && (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses);
-            if (escapes_out) escapes_out->push_back(escapes ? 1 : 0);
-            sig.push_back(moments_only ? 'm' : escapes ? 'x' : '.');
+            if (escapes_out) (*escapes_out)[i] = escapes ? 1 : 0;
+            uint64_t w = (uint64_t)(uint8_t)nd->opcode;
+            for (int k = 0; k < 3; ++k) w |= (uint64_t)(uint16_t)(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0) << (8 + 16 * k);
+            w |= (uint64_t)(uint8_t)(moments_only ? 'm' : escapes ? 'x' : '.') << 56;
+            std::memcpy(p, &w, 8);
+            h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32;
         }
-        uint64_t h = 0x9e3779b97f4a7c15ull;
-        const char* p = sig.data();
-        size_t len = sig.size();
-        for (; len >= 8; p += 8, len -= 8) { uint64_t w; std::memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
-        for (; len > 0; ++p, --len) { h = (h ^ (unsigned char)*p) * 0x100000001b3ull; }
         return h;
     };
     const size_t m = big.order.size();
