@@ -64,6 +64,14 @@ def device_count() -> int:
     return c.value
 
 
+def set_thread_engines(enabled: bool = True) -> bool:
+    """An engine per caller thread on the one device (fmhip_set_thread_engines): threads that simulate side by side record without meeting
+    each other.  Returns the previous setting.  Ends with shutdown()."""
+    prev = _C.c_int(0)
+    _native.check(lib().fmhip_set_thread_engines(1 if enabled else 0, _C.byref(prev)))
+    return prev.value != 0
+
+
 def shutdown() -> None:
     _native.check(lib().fmhip_shutdown())
 

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/fmhip.h declares (tests/test_abi_symbols.py checks the header against this list)
 SYMBOLS = [
-    "fmhip_init", "fmhip_init_devices", "fmhip_device_count", "fmhip_shutdown", "fmhip_is_initialized", "fmhip_abi_version", "fmhip_last_error",
+    "fmhip_init", "fmhip_init_devices", "fmhip_device_count", "fmhip_set_thread_engines", "fmhip_shutdown", "fmhip_is_initialized", "fmhip_abi_version", "fmhip_last_error",
     "fmhip_device_info", "fmhip_synchronize", "fmhip_get_stream",
     "fmhip_vec_create_from_double", "fmhip_vec_create_from_float", "fmhip_vec_create_filled",
     "fmhip_vec_create_uninitialized", "fmhip_vec_retain", "fmhip_vec_release", "fmhip_vec_size", "fmhip_vec_give_up_values",
@@ -135,7 +135,7 @@ def lib():
     vec, i64, i32, dbl, vp = C.c_int64, C.c_int64, C.c_int, C.c_double, C.c_void_p
     pv = C.POINTER(C.c_int64)
     sig = {
-        "fmhip_init": [i32], "fmhip_init_devices": [C.POINTER(C.c_int), i32], "fmhip_device_count": [C.POINTER(C.c_int)], "fmhip_shutdown": [], "fmhip_is_initialized": [], "fmhip_abi_version": [],
+        "fmhip_init": [i32], "fmhip_init_devices": [C.POINTER(C.c_int), i32], "fmhip_device_count": [C.POINTER(C.c_int)], "fmhip_set_thread_engines": [i32, C.POINTER(C.c_int)], "fmhip_shutdown": [], "fmhip_is_initialized": [], "fmhip_abi_version": [],
         "fmhip_device_info": [C.c_char_p, i32, C.POINTER(i32), C.POINTER(i64)],
         "fmhip_synchronize": [], "fmhip_get_stream": [C.POINTER(vp)],
         "fmhip_vec_create_from_double": [C.POINTER(dbl), i64, pv],

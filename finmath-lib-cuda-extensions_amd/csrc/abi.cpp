@@ -19,11 +19,129 @@ namespace fm { void set_last_error(const std::string& message) { g_last_error = 
 namespace front = fm::front;
 #define FRONT(call) do { if (fm::front_active()) return front::call; } while (0)
 
+// ---------------------------------------------------------------- thread engines (fmhip_set_thread_engines)
+// An engine per CALLER THREAD on one device: its own stream, pool, pending graph, time-step grouping, lock.  Threads that simulate side by
+// side (finmath-lib's optimiser evaluates the columns of a Jacobian on a thread pool, LIBORMarketModelCalibrationATMTest.java:319) record
+// without meeting each other, and their launches meet on the device.  A handle carries its engine's number (Engine::OWNER_SHIFT).  What a
+// thread does with ANOTHER thread's vector: as an operand, the vector enters this thread's engine as a leaf that aliases the owner's
+// storage (the owner computes it if it is still pending, keeps a reference for the import, and the two streams are ordered by events in
+// both directions); everything else — release, retain, read, its moments, a program or a ticket of another thread — runs on the owner's
+// engine, under the owner's lock, on the calling thread.  No two engine locks are ever held together.
+namespace te {
+static std::atomic<bool> on{ false };
+static std::mutex registry_mu;
+static constexpr int MAX_ENGINES = 64;
+static std::atomic<Engine*> engines[MAX_ENGINES];
+static std::atomic<int> count{ 0 };
+static std::vector<Engine*>& retired = *new std::vector<Engine*>();      // engines of earlier generations (threads may still be bound to them: kept, shut down, never destroyed)
+static thread_local int inside = 0;                          // > 0: a nested call of an entry point on behalf of this layer (no second look at the handles)
+static bool active() { return on.load(std::memory_order_acquire) && inside == 0; }
+static bool foreign(int64_t h) { return h > 0 && Engine::owner_of(h) != Engine::get().index(); }
+static Engine* owner(int64_t h) {
+    const int i = Engine::owner_of(h);
+    Engine* e = (i >= 0 && i < count.load(std::memory_order_acquire)) ? engines[i].load(std::memory_order_acquire) : nullptr;
+    if (!e) throw Error(FMHIP_ERR_INVALID_HANDLE, "handle " + std::to_string(h) + " names an engine that does not exist");
+    return e;
+}
+struct Inside { Inside() { ++inside; } ~Inside() { --inside; } };
+struct Rebind {                                              // the calling thread acts on engine e until the end of the scope
+    Engine* previous; Inside nested;
+    explicit Rebind(Engine* e) : previous(Engine::thread_is_bound() ? &Engine::get() : nullptr) { Engine::bind_thread(e); }
+    ~Rebind() { Engine::bind_thread(previous); }
+};
+// An engine outlives the thread it served: when the thread ends, the engine (its pool, its code objects, the vectors it owns) waits for
+// the next thread without one — a thread pool that replaces its threads does not leave an engine behind per thread it ever had.
+static std::vector<int>& idle = *new std::vector<int>();     // (registry_mu)
+struct Binding {
+    Engine* engine = nullptr;
+    ~Binding() {
+        if (!engine || engine->retired.load(std::memory_order_acquire) || !on.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lock(registry_mu);
+        if (engine->index() > 0 && engines[engine->index()].load(std::memory_order_acquire) == engine) idle.push_back(engine->index());
+    }
+};
+static thread_local Binding binding;
+// this thread's engine: the one it is bound to, an idle one, or a new one with the first engine's settings
+static void ensure() {
+    if (Engine::thread_is_bound()) return;                    // (an engine retired by fmhip_shutdown no longer counts: Engine::get)
+    std::lock_guard<std::mutex> lock(registry_mu);
+    if (!idle.empty()) {
+        Engine* e = engines[idle.back()].load(std::memory_order_acquire);
+        idle.pop_back();
+        if (e) { (void)hipSetDevice(e->device_index()); Engine::bind_thread(e); binding.engine = e; return; }      // (the current device is a property of the thread)
+    }
+    const int i = count.load(std::memory_order_acquire);
+    if (i >= MAX_ENGINES) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "more caller threads than thread engines (" + std::to_string(MAX_ENGINES) + ")");
+    Engine* first = engines[0].load(std::memory_order_acquire);
+    int device = 0, fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0;
+    { std::lock_guard<std::recursive_mutex> l0(first->mu); device = first->device_index(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
+    Engine* e = Engine::create();
+    e->set_index(i);
+    {
+        std::lock_guard<std::recursive_mutex> l(e->mu);
+        e->init(device);
+        e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
+    }
+    engines[i].store(e, std::memory_order_release);
+    count.store(i + 1, std::memory_order_release);
+    Engine::bind_thread(e);
+    binding.engine = e;
+}
+// the references owners hold for imports that have died in e go back (e's lock is NOT held here)
+static void drain(Engine& e) {
+    std::vector<Engine::ForeignDone> done;
+    { std::lock_guard<std::recursive_mutex> l(e.mu); if (!e.has_foreign_done()) return; done = e.take_foreign_done(); }
+    for (const Engine::ForeignDone& d : done) {
+        Engine* o = engines[d.owner].load(std::memory_order_acquire);
+        if (o) { std::lock_guard<std::recursive_mutex> l(o->mu); try { if (o->initialized()) o->release_exported(d.handle, d.done); } catch (...) {} }
+        if (d.done) (void)hipEventDestroy(d.done);
+    }
+}
+// operands of a call that runs on THIS thread's engine: foreign ones become imports (one reference each, given back by the destructor)
+struct Localized {
+    std::vector<fmhip_vec> local, taken;
+    Localized(const fmhip_vec* h, int n) : local(h, h + (n > 0 ? n : 0)) {
+        Engine& mine = Engine::get();
+        for (fmhip_vec& v : local) {
+            if (!(v > 0 && Engine::owner_of(v) != mine.index())) continue;
+            fmhip_vec loc = 0;
+            { std::lock_guard<std::recursive_mutex> l(mine.mu); loc = mine.find_import(v); }
+            if (!loc) {
+                Engine* o = owner(v);
+                hipEvent_t ready = nullptr;
+                if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) throw Error(FMHIP_ERR_HIP, "hipEventCreate(import)");
+                try {
+                    Engine::Exported x;
+                    { std::lock_guard<std::recursive_mutex> l(o->mu); x = o->export_vector(v, ready); }
+                    try { std::lock_guard<std::recursive_mutex> l(mine.mu); loc = mine.import_vector(o->index(), v, x, ready); }
+                    catch (...) { std::lock_guard<std::recursive_mutex> l(o->mu); try { o->release(v); } catch (...) {} throw; }
+                } catch (...) { (void)hipEventDestroy(ready); throw; }
+                (void)hipEventDestroy(ready);                  // (destroyed when the waits on it have been served)
+            }
+            taken.push_back(loc);
+            v = loc;
+        }
+    }
+    ~Localized() {
+        if (taken.empty()) return;
+        Engine& mine = Engine::get();
+        { std::lock_guard<std::recursive_mutex> l(mine.mu); for (fmhip_vec v : taken) { try { mine.release(v); } catch (...) {} } }
+    }
+    bool any() const { return !taken.empty(); }
+};
+}
+
 template <typename F>
 static int guarded(F&& f) {
     try {
-        std::lock_guard<std::recursive_mutex> lock(Engine::get().mu);
-        f();
+        const bool thread_engines = te::on.load(std::memory_order_acquire);
+        if (thread_engines) te::ensure();
+        Engine& e = Engine::get();
+        {
+            std::lock_guard<std::recursive_mutex> lock(e.mu);
+            f();
+        }
+        if (thread_engines) te::drain(e);
         return FMHIP_OK;
     } catch (const Error& e) {
         g_last_error = e.what();
@@ -41,6 +159,54 @@ static void need(const void* p, const char* what) {
     if (!p) throw Error(FMHIP_ERR_INVALID_ARGUMENT, std::string("null pointer: ") + what);
 }
 
+namespace te {
+static constexpr int NOT_MINE_TO_HANDLE = 1;                 // (no status is positive)
+template <typename F> static int status_of(F&& f) {
+    try { return f(); }
+    catch (const Error& e) { g_last_error = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { g_last_error = "host allocation failed"; return FMHIP_ERR_OUT_OF_MEMORY; }
+    catch (const std::exception& e) { g_last_error = e.what(); return FMHIP_ERR_HIP; }
+}
+// `call` on the engine that owns h, if that is not this thread's
+template <typename F> static int owner_routed(int64_t h, F&& call) {
+    return status_of([&]() -> int { ensure(); if (!foreign(h)) return NOT_MINE_TO_HANDLE; Rebind r(owner(h)); return call(); });
+}
+// `call(local handles)` on this thread's engine, foreign operands imported
+template <typename F> static int with_local(const fmhip_vec* h, int n, F&& call) {
+    return status_of([&]() -> int {
+        ensure();
+        bool any = false;
+        for (int i = 0; h && i < n; ++i) any |= foreign(h[i]);
+        if (!any) return NOT_MINE_TO_HANDLE;
+        Localized L(h, n);
+        int rc;
+        { Inside nested; rc = call(L.local.data()); }
+        return rc;
+    });
+}
+// `call(engine is this thread's)` on every engine, this thread's first; the first failure is the status
+template <typename F> static int on_all(F&& call) {
+    return status_of([&]() -> int {
+        ensure();
+        Engine* mine = &Engine::get();
+        int rc;
+        { Inside nested; rc = call(true); }
+        const int n = count.load(std::memory_order_acquire);
+        for (int i = 0; i < n; ++i) {
+            Engine* e = engines[i].load(std::memory_order_acquire);
+            if (!e || e == mine) continue;
+            Rebind r(e);
+            const int st = call(false);
+            if (rc == FMHIP_OK) rc = st;
+        }
+        return rc;
+    });
+}
+}
+#define TE_OWNER(h, call) do { if (te::active()) { const int te_rc = te::owner_routed((h), [&]() -> int { return call; }); if (te_rc != te::NOT_MINE_TO_HANDLE) return te_rc; } } while (0)
+#define TE_LOCAL(arr, n, L, call) do { if (te::active()) { const int te_rc = te::with_local((arr), (n), [&](const fmhip_vec* L) -> int { return call; }); if (te_rc != te::NOT_MINE_TO_HANDLE) return te_rc; } } while (0)
+#define TE_ALL(mine, call) do { if (te::active()) return te::on_all([&](bool mine) -> int { (void)mine; return call; }); } while (0)
+
 extern "C" {
 
 int fmhip_init(int device_index) {
@@ -56,14 +222,61 @@ int fmhip_init_devices(const int* devices, int count) {
     static const bool worker_thread = [] { const char* e = std::getenv("FMHIP_WORKER_THREAD"); return e && e[0] == '1'; }();
     if (count == 1 && devices && !worker_thread) return fmhip_init(devices[0]);
     if (fm::front_active()) { g_last_error = "a device list is active already"; return FMHIP_ERR_INVALID_ARGUMENT; }
+    if (te::on.load(std::memory_order_acquire)) { g_last_error = "thread engines are active (fmhip_set_thread_engines): fmhip_shutdown first"; return FMHIP_ERR_INVALID_ARGUMENT; }
     return front::init_devices(devices, count);
 }
 int fmhip_device_count(int* count) {
     FRONT(device_count(count));
     return guarded([&] { need(count, "count"); Engine::get().require_init(); *count = 1; });
 }
+// An engine per caller thread (see the top of this file).  Switched on by the thread that initialised the library, which keeps the
+// process-wide engine; every other thread gets an engine of its own at its first call.  Off again: fmhip_shutdown.
+int fmhip_set_thread_engines(int enabled, int* previous) {
+    if (fm::front_active()) return front::unsupported("fmhip_set_thread_engines");
+    const bool was = te::on.load(std::memory_order_acquire);
+    if (previous) *previous = was ? 1 : 0;
+    if ((enabled != 0) == was) return FMHIP_OK;
+    if (!enabled) { g_last_error = "thread engines end with fmhip_shutdown"; return FMHIP_ERR_INVALID_ARGUMENT; }
+    return te::status_of([&]() -> int {
+        std::lock_guard<std::mutex> lock(te::registry_mu);
+        Engine& first = Engine::get();
+        { std::lock_guard<std::recursive_mutex> l(first.mu); first.require_init(); }
+        if (first.index() != 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "thread engines are switched on from the thread that initialised the library");
+        te::engines[0].store(&first, std::memory_order_release);
+        te::count.store(1, std::memory_order_release);
+        Engine::bind_thread(&first);
+        te::on.store(true, std::memory_order_release);
+        return FMHIP_OK;
+    });
+}
+static int shutdown_thread_engines() {
+    // every engine but the first is shut down and destroyed; the caller's thread goes back to the process-wide engine, which the ordinary path below shuts down
+    std::lock_guard<std::mutex> lock(te::registry_mu);
+    te::on.store(false, std::memory_order_release);
+    const int n = te::count.load(std::memory_order_acquire);
+    int rc = FMHIP_OK;
+    for (int i = 0; i < n; ++i) { Engine* e = te::engines[i].load(std::memory_order_acquire); if (e) te::drain(*e); }      // imports that died: their owners' references go back while the owners exist
+    for (int i = n - 1; i >= 1; --i) {
+        Engine* e = te::engines[i].load(std::memory_order_acquire);
+        if (!e) continue;
+        Engine::bind_thread(e);
+        for (;;) {
+            { std::lock_guard<std::recursive_mutex> l(e->mu); if (e->waits_in_flight.load(std::memory_order_acquire) == 0) { const int st = te::status_of([&]() -> int { if (e->initialized()) e->shutdown(); return FMHIP_OK; }); if (rc == FMHIP_OK) rc = st; break; } }
+            std::this_thread::yield();
+        }
+        te::engines[i].store(nullptr, std::memory_order_release);
+        e->retired.store(true, std::memory_order_release);       // the object stays: a thread still bound to it is unbound at its next call (Engine::get)
+        te::retired.push_back(e);
+    }
+    te::idle.clear();
+    te::count.store(0, std::memory_order_release);
+    te::engines[0].store(nullptr, std::memory_order_release);
+    Engine::bind_thread(nullptr);
+    return rc;
+}
 int fmhip_shutdown(void) {
     FRONT(shutdown());
+    if (te::on.load(std::memory_order_acquire)) { const int rc = shutdown_thread_engines(); if (rc != FMHIP_OK) return rc; }
     // a thread that waits for its moments outside the lock still holds a result slot, a pinned block or an event of this engine: the
     // teardown starts when the last such wait is over (they end by themselves: the device finishes what was launched)
     for (;;) {
@@ -82,7 +295,7 @@ int fmhip_device_info(char* name_buf, int name_buf_len, int* n_compute_units, in
     FRONT(device_info(name_buf, name_buf_len, n_compute_units, hbm_bytes));
     return guarded([&] { Engine::get().device_info(name_buf, name_buf_len, n_compute_units, hbm_bytes); });
 }
-int fmhip_synchronize(void) { FRONT(synchronize()); return guarded([&] { Engine::get().synchronize(); }); }
+int fmhip_synchronize(void) { FRONT(synchronize()); TE_ALL(mine, fmhip_synchronize()); return guarded([&] { Engine::get().synchronize(); }); }
 int fmhip_get_stream(void** stream_out) {
     FRONT(unsupported("fmhip_get_stream"));
     return guarded([&] { need(stream_out, "stream_out"); Engine::get().require_init(); *stream_out = (void*)Engine::get().stream(); });
@@ -104,48 +317,58 @@ int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
     FRONT(vec_create_filled(n, 0.0, false, out));
     return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
 }
-int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
-int fmhip_vec_release(fmhip_vec v) { FRONT(vec_release(v)); return guarded([&] { Engine::get().release(v); }); }
+int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); TE_OWNER(v, fmhip_vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
+int fmhip_vec_release(fmhip_vec v) { FRONT(vec_release(v)); TE_OWNER(v, fmhip_vec_release(v)); return guarded([&] { Engine::get().release(v); }); }
 int fmhip_vec_size(fmhip_vec v, int64_t* n_out) {
     FRONT(vec_size(v, n_out));
+    TE_OWNER(v, fmhip_vec_size(v, n_out));
     return guarded([&] { need(n_out, "n_out"); Engine::get().require_init(); *n_out = Engine::get().node(v)->n; });
 }
 int fmhip_vec_read_double(fmhip_vec v, double* host_out, int64_t n) {
     FRONT(vec_read(v, host_out, true, n));
+    TE_OWNER(v, fmhip_vec_read_double(v, host_out, n));
     return guarded([&] { Engine::get().read(v, host_out, true, n); });
 }
 int fmhip_vec_read_float(fmhip_vec v, float* host_out, int64_t n) {
     FRONT(vec_read(v, host_out, false, n));
+    TE_OWNER(v, fmhip_vec_read_float(v, host_out, n));
     return guarded([&] { Engine::get().read(v, host_out, false, n); });
 }
 int fmhip_vec_device_ptr(fmhip_vec v, void** device_ptr_out) {
     FRONT(unsupported("fmhip_vec_device_ptr"));
+    TE_OWNER(v, fmhip_vec_device_ptr(v, device_ptr_out));
     return guarded([&] { need(device_ptr_out, "device_ptr_out"); *device_ptr_out = Engine::get().device_ptr(v); });
 }
 
 int fmhip_call_v1s0(int opcode, fmhip_vec a, fmhip_vec* out) {
+    { const fmhip_vec te_in[1] = { a }; TE_LOCAL(te_in, 1, L, fmhip_call_v1s0(opcode, L[0], out)); }
     if (fm::front_active()) { const fmhip_vec in[1] = { a }; return front::call(opcode, 1, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, 0.0, false); });
 }
 int fmhip_call_v1s1(int opcode, fmhip_vec a, double s, fmhip_vec* out) {
+    { const fmhip_vec te_in[1] = { a }; TE_LOCAL(te_in, 1, L, fmhip_call_v1s1(opcode, L[0], s, out)); }
     if (fm::front_active()) { const fmhip_vec in[1] = { a }; return front::call(opcode, 1, in, s, true, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[1] = { a }; *out = Engine::get().call(opcode, 1, in, s, true); });
 }
 int fmhip_call_v2s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec* out) {
+    { const fmhip_vec te_in[2] = { a, b }; TE_LOCAL(te_in, 2, L, fmhip_call_v2s0(opcode, L[0], L[1], out)); }
     if (fm::front_active()) { const fmhip_vec in[2] = { a, b }; return front::call(opcode, 2, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, 0.0, false); });
 }
 int fmhip_call_v2s1(int opcode, fmhip_vec a, fmhip_vec b, double s, fmhip_vec* out) {
+    { const fmhip_vec te_in[2] = { a, b }; TE_LOCAL(te_in, 2, L, fmhip_call_v2s1(opcode, L[0], L[1], s, out)); }
     if (fm::front_active()) { const fmhip_vec in[2] = { a, b }; return front::call(opcode, 2, in, s, true, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[2] = { a, b }; *out = Engine::get().call(opcode, 2, in, s, true); });
 }
 int fmhip_call_v3s0(int opcode, fmhip_vec a, fmhip_vec b, fmhip_vec c, fmhip_vec* out) {
+    { const fmhip_vec te_in[3] = { a, b, c }; TE_LOCAL(te_in, 3, L, fmhip_call_v3s0(opcode, L[0], L[1], L[2], out)); }
     if (fm::front_active()) { const fmhip_vec in[3] = { a, b, c }; return front::call(opcode, 3, in, 0.0, false, out); }
     return guarded([&] { need(out, "out"); const fmhip_vec in[3] = { a, b, c }; *out = Engine::get().call(opcode, 3, in, 0.0, false); });
 }
 
 int fmhip_set_fusion(int enabled, int* previous) {
     FRONT(set_int(0, enabled, previous));
+    TE_ALL(mine, fmhip_set_fusion(enabled, mine ? previous : nullptr));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -165,6 +388,7 @@ int fmhip_fusion_hold(int hold, int* previous) {
 }
 int fmhip_set_step_grouping(int steps, int* previous) {
     FRONT(set_int(2, steps, previous));
+    TE_ALL(mine, fmhip_set_step_grouping(steps, mine ? previous : nullptr));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -176,6 +400,19 @@ int fmhip_set_step_grouping(int steps, int* previous) {
 int fmhip_graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, const fmhip_vec* leaf_from, const fmhip_vec* leaf_to, int n_map,
                       const double* scalars, int n_scalars, fmhip_vec* out) {
     FRONT(graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out));
+    if (te::active()) {
+        const int te_rc = te::status_of([&]() -> int {
+            te::ensure();
+            bool any = false;
+            for (int i = 0; leaf_from && i < n_map; ++i) any |= te::foreign(leaf_from[i]);
+            for (int i = 0; leaf_to && i < n_map * n_copies; ++i) any |= te::foreign(leaf_to[i]);
+            if (!any) return te::NOT_MINE_TO_HANDLE;
+            te::Localized from(leaf_from, n_map), to(leaf_to, n_map * n_copies);
+            te::Inside nested;
+            return fmhip_graph_clone(roots, n_roots, n_copies, from.local.data(), to.local.data(), n_map, scalars, n_scalars, out);
+        });
+        if (te_rc != te::NOT_MINE_TO_HANDLE) return te_rc;
+    }
     return guarded([&] { Engine::get().graph_clone(roots, n_roots, n_copies, leaf_from, leaf_to, n_map, scalars, n_scalars, out); });
 }
 int fmhip_graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int capacity, int* n_scalars) {
@@ -187,6 +424,7 @@ int fmhip_graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out
 }
 int fmhip_set_math_mode(int mode, int* previous) {
     FRONT(set_int(3, mode, previous));
+    TE_ALL(mine, fmhip_set_math_mode(mode, mine ? previous : nullptr));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -244,6 +482,7 @@ int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int coun
 // own; this thread polls its flag, then takes the lock again to copy them out and give the launch's buffers back.
 int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
     if (fm::front_active()) { const fmhip_vec one[1] = { v }; const double sh[1] = { shift }; return front::reduce_moments_batch(one, 1, sh, out); }
+    TE_OWNER(v, fmhip_reduce_moments(v, shift, out));
     Engine::RedLaunch pending;
     int rc = guarded([&] { need(out, "out"); Engine::get().reduce(v, shift, out, nullptr, &pending); if (pending.pending) Engine::get().waits_in_flight.fetch_add(1, std::memory_order_acq_rel); });
     if (rc == FMHIP_OK && pending.pending) {
@@ -255,22 +494,32 @@ int fmhip_reduce_moments(fmhip_vec v, double shift, fmhip_moments* out) {
 }
 int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out) {
     FRONT(reduce_moments_batch(vectors, count, shifts, out));
+    TE_LOCAL(vectors, count, L, fmhip_reduce_moments_batch(L, count, shifts, out));
     return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine& e = Engine::get(); e.reduce_batch(vectors, count, shifts, out, nullptr); exchange_moments(e, out, count); });
 }
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
     FRONT(unsupported("fmhip_reduce_moments_batch_device"));
+    TE_LOCAL(vectors, count, L, fmhip_reduce_moments_batch_device(L, count, shifts, device_out));
     return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch_device(vectors, count, shifts, device_out); });
 }
 int fmhip_reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out) {
     FRONT(reduce_moments_batch_begin(vectors, count, shifts, ticket_out));
+    TE_LOCAL(vectors, count, L, fmhip_reduce_moments_batch_begin(L, count, shifts, ticket_out));
     return guarded([&] { need(vectors, "vectors"); need(ticket_out, "ticket_out"); *ticket_out = Engine::get().reduce_batch_begin(vectors, count, shifts); });
 }
 int fmhip_vec_give_up_values(const fmhip_vec* vectors, int count) {
     FRONT(vec_give_up_values(vectors, count));
+    if (te::active()) {          // a value of another thread's engine: that engine's to give up
+        bool any_foreign = false;
+        const int st = te::status_of([&]() -> int { te::ensure(); for (int i = 0; vectors && i < count; ++i) any_foreign |= te::foreign(vectors[i]); return FMHIP_OK; });
+        if (st != FMHIP_OK) return st;
+        if (any_foreign) { for (int i = 0; i < count; ++i) { const fmhip_vec one = vectors[i]; int rc = te::owner_routed(one, [&]() -> int { return fmhip_vec_give_up_values(&one, 1); }); if (rc == te::NOT_MINE_TO_HANDLE) { te::Inside nested; rc = fmhip_vec_give_up_values(&one, 1); } if (rc != FMHIP_OK) return rc; } return FMHIP_OK; }
+    }
     return guarded([&] { need(vectors, "vectors"); Engine::get().give_up_values(vectors, count); });
 }
 int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count) {
     FRONT(reduce_moments_batch_end(ticket, out, count));
+    TE_OWNER(ticket, fmhip_reduce_moments_batch_end(ticket, out, count));
     Engine::MomentsTicket t;
     int rc = guarded([&] {
         need(out, "out");
@@ -295,6 +544,7 @@ int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int 
 }
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
     FRONT(unsupported("fmhip_reduce_moments_device"));
+    TE_OWNER(v, fmhip_reduce_moments_device(v, shift, device_out_4_doubles));
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
 }
 
@@ -308,6 +558,7 @@ int fmhip_program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
 }
 int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_reduce) {
     FRONT(program_shape(p, n_inputs, n_outputs, n_reduce));
+    TE_OWNER(p, fmhip_program_shape(p, n_inputs, n_outputs, n_reduce));
     return guarded([&] {
         Engine& e = Engine::get();
         e.require_init();
@@ -319,6 +570,7 @@ int fmhip_program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_r
 }
 int fmhip_set_jit(int mode, int* previous) {
     FRONT(set_int(4, mode, previous));
+    TE_ALL(mine, fmhip_set_jit(mode, mine ? previous : nullptr));
     return guarded([&] {
         if (mode != FMHIP_JIT_OFF && mode != FMHIP_JIT_AUTO && mode != FMHIP_JIT_SYNC) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "unknown JIT mode");
         if (previous) *previous = Engine::get().jit_mode;
@@ -327,11 +579,14 @@ int fmhip_set_jit(int mode, int* previous) {
 }
 int fmhip_jit_wait(void) {
     FRONT(jit_wait());
+    TE_ALL(mine, fmhip_jit_wait());
     // not under the engine mutex: other threads keep launching while this one waits for the compiler thread
     try { Engine::get().jit_wait(); return FMHIP_OK; } catch (...) { return FMHIP_ERR_HIP; }
 }
 int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double* compile_seconds, int64_t* disk_cache_hits) {
     FRONT(jit_stats(compiled, failed, pending, compile_seconds, disk_cache_hits));
+    if (te::active()) { int64_t c = 0, f = 0, pd = 0, d = 0; double sec = 0; const int rc = te::on_all([&](bool) -> int { int64_t c1 = 0, f1 = 0, p1 = 0, d1 = 0; double s1 = 0; const int st = fmhip_jit_stats(&c1, &f1, &p1, &s1, &d1); c += c1; f += f1; pd += p1; d += d1; sec += s1; return st; });
+        if (compiled) *compiled = c; if (failed) *failed = f; if (pending) *pending = pd; if (compile_seconds) *compile_seconds = sec; if (disk_cache_hits) *disk_cache_hits = d; return rc; }
     return guarded([&] {
         const fm::JitStats s = Engine::get().jit_stats();
         if (compiled) *compiled = s.compiled;
@@ -342,6 +597,7 @@ int fmhip_jit_stats(int64_t* compiled, int64_t* failed, int64_t* pending, double
     });
 }
 int fmhip_program_tier(fmhip_program p, int* tier, int* vgprs) {
+    if (!fm::front_active()) TE_OWNER(p, fmhip_program_tier(p, tier, vgprs));
     FRONT(program_tier(p, tier, vgprs));
     return guarded([&] {
         Engine::get().require_init();
@@ -363,9 +619,10 @@ int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
         }
     });
 }
-int fmhip_program_release(fmhip_program p) { FRONT(program_release(p)); return guarded([&] { Engine::get().program_release(p); }); }
+int fmhip_program_release(fmhip_program p) { FRONT(program_release(p)); TE_OWNER(p, fmhip_program_release(p)); return guarded([&] { Engine::get().program_release(p); }); }
 int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
     if (fm::front_active()) { int a = 0; const int st = front::program_shape(p, &a, nullptr, nullptr); if (st == FMHIP_OK && n_launches) *n_launches = 1; return st; }
+    TE_OWNER(p, fmhip_program_launch_count(p, n_launches));
     return guarded([&] {
         need(n_launches, "n_launches");
         Engine::get().require_init();
@@ -376,11 +633,40 @@ int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
 int fmhip_program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs,
                       const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
     if (fm::front_active()) return device_moments ? front::unsupported("fmhip_program_run with device_moments") : front::program_run(p, batch, inputs, outputs, false, reduce_shift, moments);
+    if (te::active()) {
+        const int te_rc = te::status_of([&]() -> int {
+            te::ensure();
+            int n_in = 0;
+            { te::Rebind r(te::owner(p)); const int st = fmhip_program_shape(p, &n_in, nullptr, nullptr); if (st != FMHIP_OK) return st; }
+            bool any = te::foreign(p);
+            for (int i = 0; inputs && i < batch * n_in; ++i) any |= Engine::owner_of(inputs[i]) != Engine::owner_of(p);
+            if (!any) return te::NOT_MINE_TO_HANDLE;
+            te::Rebind r(te::owner(p));
+            te::Localized L(inputs, batch * n_in);
+            return fmhip_program_run(p, batch, L.local.data(), outputs, reduce_shift, moments, device_moments);
+        });
+        if (te_rc != te::NOT_MINE_TO_HANDLE) return te_rc;
+    }
     return guarded([&] { Engine::get().program_run(p, batch, inputs, outputs, false, reduce_shift, moments, device_moments); });
 }
 int fmhip_program_run_into(fmhip_program p, int batch, const fmhip_vec* inputs, const fmhip_vec* outputs,
                            const double* reduce_shift, fmhip_moments* moments, void* device_moments) {
     if (fm::front_active()) return device_moments ? front::unsupported("fmhip_program_run_into with device_moments") : front::program_run(p, batch, inputs, const_cast<fmhip_vec*>(outputs), true, reduce_shift, moments);
+    if (te::active()) {
+        const int te_rc = te::status_of([&]() -> int {
+            te::ensure();
+            int n_in = 0, n_out = 0;
+            { te::Rebind r(te::owner(p)); const int st = fmhip_program_shape(p, &n_in, &n_out, nullptr); if (st != FMHIP_OK) return st; }
+            bool any = te::foreign(p);
+            for (int i = 0; inputs && i < batch * n_in; ++i) any |= Engine::owner_of(inputs[i]) != Engine::owner_of(p);
+            for (int i = 0; outputs && i < batch * n_out; ++i) if (Engine::owner_of(outputs[i]) != Engine::owner_of(p)) throw Error(FMHIP_ERR_UNSUPPORTED, "fmhip_program_run_into writes into vectors of the program's own engine (thread engines)");
+            if (!any) return te::NOT_MINE_TO_HANDLE;
+            te::Rebind r(te::owner(p));
+            te::Localized L(inputs, batch * n_in);
+            return fmhip_program_run_into(p, batch, L.local.data(), outputs, reduce_shift, moments, device_moments);
+        });
+        if (te_rc != te::NOT_MINE_TO_HANDLE) return te_rc;
+    }
     return guarded([&] {
         Engine::get().program_run(p, batch, inputs, const_cast<fmhip_vec*>(outputs), true, reduce_shift, moments, device_moments);
     });
@@ -425,20 +711,30 @@ int fmhip_bm_generate_mersenne(int32_t seed, int n_steps, int n_factors, int64_t
 }
 double fmhip_inverse_normal_cdf(double p) { return fm::inverse_normal_cdf(p); }
 
-int fmhip_pool_clean(void) { FRONT(pool(0)); return guarded([&] { Engine::get().pool_clean(); }); }
-int fmhip_pool_purge(void) { FRONT(pool(1)); return guarded([&] { Engine::get().pool_purge(); }); }
-int fmhip_pool_stats(fmhip_pool_stats_t* out) { FRONT(pool_stats(out)); return guarded([&] { Engine::get().pool_stats(out); }); }
+int fmhip_pool_clean(void) { FRONT(pool(0)); TE_ALL(mine, fmhip_pool_clean()); return guarded([&] { Engine::get().pool_clean(); }); }
+int fmhip_pool_purge(void) { FRONT(pool(1)); TE_ALL(mine, fmhip_pool_purge()); return guarded([&] { Engine::get().pool_purge(); }); }
+int fmhip_pool_stats(fmhip_pool_stats_t* out) { FRONT(pool_stats(out)); if (te::active()) { if (!out) { g_last_error = "null pointer: out"; return FMHIP_ERR_INVALID_ARGUMENT; } fmhip_pool_stats_t sum; std::memset(&sum, 0, sizeof sum); bool first = true;
+        const int rc = te::on_all([&](bool) -> int { fmhip_pool_stats_t one; const int st = fmhip_pool_stats(&one); if (st != FMHIP_OK) return st;
+            if (first) { sum = one; first = false; } else { sum.bytes_reserved += one.bytes_reserved; sum.bytes_in_use += one.bytes_in_use; sum.bytes_cached += one.bytes_cached; sum.n_alloc_hits += one.n_alloc_hits; sum.n_alloc_misses += one.n_alloc_misses; sum.n_live_vectors += one.n_live_vectors; sum.n_kernel_launches += one.n_kernel_launches; sum.n_ops_executed += one.n_ops_executed; }
+            return FMHIP_OK; });
+        if (rc == FMHIP_OK) *out = sum;
+        return rc; }
+    return guarded([&] { Engine::get().pool_stats(out); }); }
 
 int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches) {
     FRONT(traffic_stats(algorithmic_bytes, specialised_launches));
+    if (te::active()) { int64_t b = 0, l = 0; const int rc = te::on_all([&](bool) -> int { int64_t b1 = 0, l1 = 0; const int st = fmhip_traffic_stats(&b1, &l1); b += b1; l += l1; return st; });
+        if (algorithmic_bytes) *algorithmic_bytes = b; if (specialised_launches) *specialised_launches = l; return rc; }
     return guarded([&] {
         if (algorithmic_bytes) *algorithmic_bytes = Engine::get().algorithmic_bytes();
         if (specialised_launches) *specialised_launches = Engine::get().jit_launches();
     });
 }
-int fmhip_profile_enable(int enabled) { FRONT(profile_enable(enabled)); return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
+int fmhip_profile_enable(int enabled) { FRONT(profile_enable(enabled)); TE_ALL(mine, fmhip_profile_enable(enabled)); return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches) {
     FRONT(profile_read(kernel_ms_total, n_launches));
+    if (te::active()) { double ms = 0; int64_t n = 0; const int rc = te::on_all([&](bool) -> int { double m1 = 0; int64_t n1 = 0; const int st = fmhip_profile_read(&m1, &n1); ms += m1; n += n1; return st; });
+        if (kernel_ms_total) *kernel_ms_total = ms; if (n_launches) *n_launches = n; return rc; }
     return guarded([&] { Engine::get().profile_read(kernel_ms_total, n_launches); });
 }
 

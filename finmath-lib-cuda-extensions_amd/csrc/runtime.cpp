@@ -121,10 +121,14 @@ void Pool::purge() {
 // The engine of the calling thread: the process-wide one — or, on a worker thread of a device list (sharded.cpp: one engine per
 // device shard, each driven by a thread of its own), that worker's.
 static thread_local Engine* tls_engine = nullptr;
-Engine& Engine::get() { if (tls_engine) return *tls_engine; static Engine* e = new Engine(); return *e; }
+Engine& Engine::get() {
+    if (tls_engine) { if (!tls_engine->retired.load(std::memory_order_acquire)) return *tls_engine; tls_engine = nullptr; }      // (a thread engine that fmhip_shutdown has retired)
+    static Engine* e = new Engine();
+    return *e;
+}
 Engine* Engine::create() { return new Engine(); }
 void Engine::bind_thread(Engine* e) { tls_engine = e; }
-bool Engine::thread_is_bound() { return tls_engine != nullptr; }
+bool Engine::thread_is_bound() { if (tls_engine && tls_engine->retired.load(std::memory_order_acquire)) tls_engine = nullptr; return tls_engine != nullptr; }
 
 void Engine::require_init() const {
     if (!initialized_) throw Error(FMHIP_ERR_NOT_INITIALIZED, "fmhip_init has not been called");
@@ -292,9 +296,67 @@ Buffer* Engine::new_buffer(int64_t n_floats) {
 
 void Engine::buffer_unref(Buffer* b) {
     if (--b->refs > 0) return;
-    if (b->parent) buffer_unref(b->parent);
+    if (b->foreign >= 0) {          // another engine's storage: whatever this stream still does with it comes before `done`; the owner's reference goes back later, outside this lock
+        Foreign& f = foreign_[(size_t)b->foreign];
+        hipEvent_t done = nullptr;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(done, stream_);
+        foreign_done_.push_back({ f.owner, f.handle, done });
+        import_of_.erase(f.handle);
+        f.live = false;
+        foreign_free_.push_back(b->foreign);
+    } else if (b->parent) buffer_unref(b->parent);
     else pool_.release(b->ptr, b->cap);
     delete b;
+}
+
+void Engine::set_index(int i) {
+    index_ = i;
+    next_id_ = ((int64_t)i << OWNER_SHIFT) + 1;
+    next_ticket_ = ((int64_t)i << OWNER_SHIFT) + 1;
+}
+
+Engine::Exported Engine::export_vector(fmhip_vec h, hipEvent_t ready) {
+    require_init();
+    Node* nd = node(h);
+    if (!nd->buf) materialize({ nd });
+    nd->refs_ext++;
+    hip_check(hipEventRecord(ready, stream_), "hipEventRecord(export)");
+    Exported x;
+    x.ptr = nd->buf->ptr; x.n = nd->n;
+    if (nd->bm_id) { x.bm_id = ((uint32_t)(index_ + 1) << 24) | (nd->bm_id & 0xffffffu); x.bm_step = nd->bm_step; x.bm_steps = nd->bm_steps; }
+    return x;
+}
+
+fmhip_vec Engine::import_vector(int owner, fmhip_vec owner_handle, const Exported& x, hipEvent_t ready) {
+    require_init();
+    hip_check(hipStreamWaitEvent(stream_, ready, 0), "hipStreamWaitEvent(import)");
+    int32_t slot;
+    if (!foreign_free_.empty()) { slot = foreign_free_.back(); foreign_free_.pop_back(); } else { slot = (int32_t)foreign_.size(); foreign_.push_back({}); }
+    foreign_[(size_t)slot] = { owner, owner_handle, true };
+    Buffer* b = new Buffer();
+    b->ptr = x.ptr; b->cap = 0; b->refs = 1; b->foreign = slot;
+    Node* nd = new_node(x.n);
+    nd->buf = b;
+    nd->moments_blocked = true;                                // (its moments, if anybody asks, are the owner's to keep)
+    nd->bm_id = x.bm_id; nd->bm_step = x.bm_step; nd->bm_steps = x.bm_steps;
+    import_of_[owner_handle] = nd;
+    return nd->id;
+}
+
+fmhip_vec Engine::find_import(fmhip_vec foreign_handle) {
+    auto it = import_of_.find(foreign_handle);
+    if (it == import_of_.end()) return 0;
+    Node* nd = it->second;                   // alive: it leaves the map when its storage goes (buffer_unref)
+    if (++nd->refs_ext == 1) nodes_.put(nd->id, nd);          // kept by pending consumers only: a handle again
+    return nd->id;
+}
+
+std::vector<Engine::ForeignDone> Engine::take_foreign_done() { std::vector<ForeignDone> out; out.swap(foreign_done_); return out; }
+
+void Engine::release_exported(fmhip_vec h, hipEvent_t done) {
+    require_init();
+    if (done) (void)hipStreamWaitEvent(stream_, done, 0);
+    release(h);
 }
 
 Node* Engine::new_node(int64_t n) {
@@ -309,6 +371,7 @@ Node* Engine::new_node(int64_t n) {
 }
 
 Node* Engine::node(fmhip_vec h) {
+    if (owner_of(h) != index_) throw Error(FMHIP_ERR_INVALID_HANDLE, "vector handle " + std::to_string(h) + " belongs to another engine");
     Node* nd = nodes_.get(h);
     if (!nd) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid vector handle " + std::to_string(h));
     return nd;

@@ -55,6 +55,7 @@ struct Buffer {                 // refcounted device storage; views keep their p
     size_t  cap = 0;            // bytes owned (0 for views)
     int     refs = 0;
     Buffer* parent = nullptr;
+    int32_t foreign = -1;       // >= 0: storage of ANOTHER engine's vector (thread engines: Engine::import_vector); index into foreign_
 };
 
 // ---------------------------------------------------------------- vectors / lazy nodes
@@ -149,13 +150,16 @@ struct Program {
 // no hashing and no allocation per handle on the path of every recorded method (a hash map was a third of its 80 ns).
 class HandleTable {
 public:
+    // (the top 16 bits of a handle name the engine that owns it — thread engines, FM_OWNER_SHIFT; the table of an engine is indexed by the rest)
     Node* get(int64_t id) const {
         if (id <= 0) return nullptr;
+        id &= LOCAL;
         const size_t page = (size_t)(id >> BITS);
         if (page >= pages_.size() || !pages_[page].slot) return nullptr;
         return pages_[page].slot[(size_t)id & MASK];
     }
     void put(int64_t id, Node* nd) {
+        id &= LOCAL;
         const size_t page = (size_t)(id >> BITS);
         if (page >= pages_.size()) pages_.resize(page + 1);
         Page& pg = pages_[page];
@@ -166,6 +170,7 @@ public:
     }
     void erase(int64_t id) {
         if (id <= 0) return;
+        id &= LOCAL;
         const size_t page = (size_t)(id >> BITS);
         if (page >= pages_.size() || !pages_[page].slot) return;
         Page& pg = pages_[page];
@@ -184,6 +189,7 @@ public:
     HandleTable(const HandleTable&) = delete;
     HandleTable& operator=(const HandleTable&) = delete;
 private:
+    static constexpr int64_t LOCAL = (int64_t(1) << 48) - 1;
     static constexpr int BITS = 12;
     static constexpr size_t MASK = ((size_t)1 << BITS) - 1;
     struct Page { Node** slot = nullptr; uint32_t live = 0; };
@@ -195,6 +201,22 @@ class Engine {
 public:
     static Engine& get();
     static Engine* create();                 // a further engine (sharded.cpp: one per device of a device list); the caller owns it
+    // Thread engines (fmhip_set_thread_engines): an engine per caller thread on one device.  index() is in the top 16 bits of every handle
+    // this engine hands out; a vector of another engine enters this one as a LEAF that aliases the owner's storage (the owner keeps a
+    // reference for it; the two streams are ordered by events in both directions).
+    static constexpr int OWNER_SHIFT = 48;
+    static int owner_of(int64_t handle) { return (int)((uint64_t)handle >> OWNER_SHIFT); }
+    int index() const { return index_; }
+    std::atomic<bool> retired{ false };                        // a thread engine after fmhip_shutdown: threads bound to it fall back to the process-wide engine
+    void set_index(int i);                                     // before init(): the engine's number among the thread engines
+    struct Exported { float* ptr = nullptr; int64_t n = 0; uint32_t bm_id = 0; int32_t bm_step = -1, bm_steps = 0; };
+    Exported export_vector(fmhip_vec h, hipEvent_t ready);     // owner side: computed, one more reference, `ready` recorded on this stream
+    fmhip_vec import_vector(int owner, fmhip_vec owner_handle, const Exported& x, hipEvent_t ready);      // this stream waits for `ready`; returns a handle of THIS engine (one reference)
+    struct ForeignDone { int owner; fmhip_vec handle; hipEvent_t done; };
+    fmhip_vec find_import(fmhip_vec foreign_handle);           // the import of that vector if one is alive here (one more reference), else 0
+    bool has_foreign_done() const { return !foreign_done_.empty(); }
+    std::vector<ForeignDone> take_foreign_done();              // imports that have died: their owners' references are to be given back (outside this engine's lock)
+    void release_exported(fmhip_vec h, hipEvent_t done);       // owner side: this stream waits for `done`, then the reference goes
     static void bind_thread(Engine* e);      // Engine::get() of THIS thread returns e from now on (nullptr: the process-wide engine again)
     static bool thread_is_bound();
     std::recursive_mutex mu;
@@ -205,6 +227,7 @@ public:
     void init(int device_index);
     void shutdown();
     bool initialized() const { return initialized_; }
+    int device_index() const { return device_; }
     void require_init() const;
     void synchronize();
     hipStream_t stream() const { return stream_; }
@@ -309,6 +332,12 @@ private:
     Pool pool_;
     Jit jit_;
     int64_t next_id_ = 1;
+    int index_ = 0;
+    struct Foreign { int owner = 0; fmhip_vec handle = 0; bool live = false; };
+    std::vector<Foreign> foreign_;                               // imports alive in this engine (Buffer::foreign indexes it)
+    std::vector<int32_t> foreign_free_;
+    std::unordered_map<fmhip_vec, Node*> import_of_;            // foreign handle → its live import in this engine
+    std::vector<ForeignDone> foreign_done_;
     HandleTable nodes_;
     Node pending_head_;                                          // circular list of the nodes without storage (lazy expressions)
     void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; ++n_pending_; }

@@ -21,6 +21,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
+#include <thread>
 #include <cstdlib>
 #include <functional>
 #include <string>
@@ -199,6 +201,8 @@ struct Backend {
     // true: every time step's state keeps its handle until the evaluation is over, as finmath-lib's Euler scheme stores the whole
     // discretised process (80 x 80 vectors, SURVEY.md §8d config 4: 25.6 GB) — measurement of a caller that knows nothing about the engine
     bool keepAllStates = false;
+    int threads = 1;                                       // > 1 (with jacobianBatch 1): the columns of a Jacobian are evaluated by this many threads side by side, as finmath-lib's
+                                                           // optimiser does with its thread pool (…ATMTest.java:319); the back end must allow it (fmhip_set_thread_engines)
 };
 
 // Simulates SEVERAL parameter sets in lock-step (same Brownian increments = common random numbers): the operations of
@@ -493,6 +497,32 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
             }
             f.valid = false;
         };
+        if (be.threads > 1 && be.jacobianBatch <= 1) {
+            // one column per evaluation, the evaluations dealt out to the threads: nothing is shared but the model's inputs and the Brownian motion
+            const auto tj0 = clk::now();
+            std::vector<Valuation> column((size_t)np);
+            std::vector<std::string> failures((size_t)be.threads);
+            std::atomic<int> next{ 0 };
+            std::vector<std::thread> pool;
+            for (int t = 0; t < be.threads; ++t)
+                pool.emplace_back([&, t] {
+                    try {
+                        for (int a = next.fetch_add(1); a < np; a = next.fetch_add(1)) {
+                            VolatilityModel bumped = vol;
+                            bumped.parameter[(size_t)active[(size_t)a]] += parameterStep;
+                            column[(size_t)a] = evaluate(m, bumped, be);
+                        }
+                    } catch (const std::exception& e) { failures[(size_t)t] = e.what(); }
+                });
+            for (std::thread& th : pool) th.join();
+            if (std::getenv("FMHIP_LMM_TIMELINE")) std::fprintf(stderr, "[lmm timeline] iteration %d: %d columns on %d threads, %.3f … %.3f ms\n", it, np, be.threads, std::chrono::duration<double, std::milli>(tj0 - start).count(), std::chrono::duration<double, std::milli>(clk::now() - start).count());
+            for (const std::string& f : failures) if (!f.empty()) throw std::runtime_error("a Jacobian column failed: " + f);
+            for (int a = 0; a < np; ++a) {
+                const Valuation& val = column[(size_t)a];
+                res.evaluations++; res.seconds_simulation += val.seconds_simulation; res.seconds_valuation += val.seconds_valuation;
+                for (int k = 0; k < nr; ++k) J[(size_t)k * np + a] = (val.modelVolatility[(size_t)k] - m.swaptions[(size_t)k].targetVolatility - r[(size_t)k]) / parameterStep;
+            }
+        } else {
         InFlight previous;
         for (int a0 = 0; a0 < np; a0 += std::max(1, be.jacobianBatch)) {
             const int a1 = std::min(np, a0 + std::max(1, be.jacobianBatch));
@@ -524,6 +554,7 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
             previous = std::move(current);
         }
         collect(previous);
+        }
         std::vector<double> JtJ((size_t)np * np, 0.0), Jtr((size_t)np, 0.0);
         for (int a = 0; a < np; ++a) {
             for (int b = 0; b < np; ++b) { double s = 0; for (int k = 0; k < nr; ++k) s += J[(size_t)k * np + a] * J[(size_t)k * np + b]; JtJ[(size_t)a * np + b] = s; }

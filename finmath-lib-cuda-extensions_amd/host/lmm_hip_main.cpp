@@ -37,7 +37,12 @@ int main(int argc, char** argv) {
             be.flush = [] {}; be.hold = [](bool) {}; be.clone = nullptr; be.recordedScalars = nullptr; be.averagesAsync = nullptr; be.expectationsRunPending = false;
             be.averages = [](const std::vector<RV>& v) { std::vector<double> a; for (const RV& x : v) a.push_back(x->getAverage()); return a; };
             be.jacobianBatch = 1; be.stepsPerLaunch = 1; be.chunk = 1 << 30; be.keepAllStates = true;
-        }
+            if (o.threads > 1) {                            // the optimiser's thread pool: an engine per thread (fmhip_set_thread_engines)
+                if (!o.devices.empty() || o.world > 1) throw std::runtime_error("--threads: one device, one process");
+                check(fmhip_set_thread_engines(1, nullptr));
+                be.threads = o.threads;
+            }
+        } else if (o.threads > 1) throw std::runtime_error("--threads belongs to --finmath-like (the native driver batches its Jacobian columns instead)");
         ncclComm_t comm = nullptr;
         std::vector<std::pair<double*, hipEvent_t>> sparePinned;      // pinned blocks and events of finished sharded expectations, used again
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)

@@ -20,6 +20,7 @@ struct Options {
     int stepsPerLaunch = 0;                                // Euler steps recorded per engine flush; 0 = back end default (4)
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     std::string brownian = "philox";                        // philox (counter-based, on the device) | mersenne (finmath's CPU generator through the factory)
+    int threads = 1;                                       // --threads T (with --finmath-like): Jacobian columns on T threads, an engine each
     bool finmathLike = false;                              // no hints to the engine: no hold / flush / replication / lock-step batches, all states kept, one getAverage per product
     bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU
 };
@@ -42,6 +43,7 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--nccl-nonce") o.ncclNonce = std::atoll(next());
         else if (a == "--profile") o.profile = true;
         else if (a == "--finmath-like") o.finmathLike = true;
+        else if (a == "--threads") o.threads = std::atoi(next());
         else if (a == "--brownian") o.brownian = next();
         else if (a == "--jacobian-batch") o.jacobianBatch = std::atoi(next());
         else if (a == "--chunk") o.chunk = std::atoi(next());

@@ -22,6 +22,7 @@
 #include <functional>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -497,7 +498,7 @@ public:
     BrownianMotionHip(TimeDiscretization td, int numberOfFactors, int64_t numberOfPaths, int64_t seed, int64_t pathOffset = 0)
         : td_(std::move(td)), factors_(numberOfFactors), paths_(numberOfPaths), seed_(seed), offset_(pathOffset) {}
     RV getBrownianIncrement(int timeIndex, int factor) const override {
-        if (inc_.empty()) generate();
+        std::call_once(generated_, [this] { generate(); });       // (threads that simulate side by side share one Brownian motion)
         return inc_.at((size_t)timeIndex * factors_ + factor);
     }
     // Time-step grouping on the caller's behalf is the engine's business since round 3 (fmhip_set_step_grouping: it watches for the
@@ -530,6 +531,7 @@ private:
     int factors_;
     int64_t paths_, seed_, offset_;
     mutable std::vector<RV> inc_;
+    mutable std::once_flag generated_;
 };
 
 // ------------------------------------------------------------------ BrownianMotionFromMersenneRandomNumbers
@@ -541,7 +543,7 @@ public:
     BrownianMotionFromMersenneRandomNumbers(TimeDiscretization td, int numberOfFactors, int64_t numberOfPaths, int seed, const RandomVariableFactory* factory)
         : td_(std::move(td)), factors_(numberOfFactors), paths_(numberOfPaths), seed_(seed), factory_(factory) {}
     RV getBrownianIncrement(int timeIndex, int factor) const override {
-        if (inc_.empty()) generate();
+        std::call_once(generated_, [this] { generate(); });       // (threads that simulate side by side share one Brownian motion)
         return inc_.at((size_t)timeIndex * factors_ + factor);
     }
     const TimeDiscretization& getTimeDiscretization() const override { return td_; }
@@ -569,6 +571,7 @@ private:
     int seed_;
     const RandomVariableFactory* factory_;
     mutable std::vector<RV> inc_;
+    mutable std::once_flag generated_;
 };
 
 } // namespace fmhost

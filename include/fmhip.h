@@ -145,6 +145,16 @@ int fmhip_init(int device_index);
  * UNMEASURED on more than one physical GPU. */
 int fmhip_init_devices(const int* devices, int count);
 int fmhip_device_count(int* count);           /* devices (shards) behind the handles: 1 after fmhip_init */
+/* An ENGINE PER CALLER THREAD on the one device of fmhip_init: every thread that calls into the library gets a pending graph, a stream,
+ * a memory pool, a time-step grouping and a lock of its own (the thread that switches this on keeps the engine it initialised).  Threads
+ * that simulate side by side — finmath-lib's optimiser evaluates the columns of a Jacobian on a thread pool
+ * (LIBORMarketModelCalibrationATMTest.java:319) — record without meeting each other and their launches share the device.  Handles stay
+ * valid everywhere: a vector of another thread is computed by ITS engine if it is still pending and enters a method as an operand that
+ * aliases that storage (streams ordered by events); release, retain, read, moments, programs and tickets of another thread run on the
+ * owner's engine.  Settings (fusion, math mode, JIT mode, step grouping) apply to every engine; fmhip_flush and fmhip_fusion_hold to the
+ * calling thread's; statistics are summed; fmhip_synchronize waits for all.  Not together with a device list.  Ends with fmhip_shutdown.
+ * The reference funnels every thread through one executor thread (RandomVariableCuda.java:155). */
+int fmhip_set_thread_engines(int enabled, int* previous);
 int fmhip_shutdown(void);
 int fmhip_is_initialized(void);
 int fmhip_abi_version(void);

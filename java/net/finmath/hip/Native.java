@@ -27,6 +27,7 @@ final class Native {
 	static native int init(int deviceIndex);
 	static native int initDevices(int[] devices);
 	static native int deviceCount(int[] count);
+	static native int    setThreadEngines(int enabled, int[] previous);   // fmhip_set_thread_engines: an engine per caller thread
 	static native int shutdown();
 	static native int isInitialized();
 	static native int abiVersion();

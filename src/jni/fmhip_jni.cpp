@@ -70,6 +70,12 @@ FMJ(jint, deviceCount)(JNIEnv* env, jclass, jintArray count) {
     if (st == FMHIP_OK) { const jint v = c; env->SetIntArrayRegion(count, 0, 1, &v); }
     return st;
 }
+FMJ(jint, setThreadEngines)(JNIEnv* env, jclass, jint enabled, jintArray previous) {
+    int prev = 0;
+    const int st = fmhip_set_thread_engines(enabled, &prev);
+    if (st == FMHIP_OK && previous && env->GetArrayLength(previous) >= 1) { const jint v = prev; env->SetIntArrayRegion(previous, 0, 1, &v); }
+    return st;
+}
 FMJ(jint, shutdown)(JNIEnv*, jclass) { return fmhip_shutdown(); }
 FMJ(jint, isInitialized)(JNIEnv*, jclass) { return fmhip_is_initialized(); }
 FMJ(jint, abiVersion)(JNIEnv*, jclass) { return fmhip_abi_version(); }

@@ -85,6 +85,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCre
 hipError_t hipEventDestroy(hipEvent_t e) { delete reinterpret_cast<int*>(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { *reinterpret_cast<volatile int*>(e) = 1; return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 hipError_t hipModuleLoadData(hipModule_t* m, const void* image) {
     if (std::memcmp(image, "FMNULLCO", 8) != 0) return hipErrorInvalidImage;

@@ -75,12 +75,16 @@ def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_p
     cases = [["--mode", "calibrate", "--max-iterations", "1"],
              ["--mode", "evaluate", "--evaluations", "3", "--finmath-like"],
              ["--mode", "calibrate", "--max-iterations", "1", "--devices", "0,0"],
-             ["--mode", "calibrate", "--max-iterations", "1", "--world", "1", "--rank", "0", "--nccl-id-file", str(tmp_path / "id"), "--nccl-nonce", "5"]]
+             ["--mode", "calibrate", "--max-iterations", "1", "--world", "1", "--rank", "0", "--nccl-id-file", str(tmp_path / "id"), "--nccl-nonce", "5"],
+             # an engine per caller thread (fmhip_set_thread_engines): the Jacobian's columns on four threads, the Brownian increments and the
+             # initial curve owned by the first engine and imported by the others, results read and released across threads; two iterations,
+             # so that the second pool of threads takes over the engines the first one left behind
+             ["--mode", "calibrate", "--max-iterations", "2", "--finmath-like", "--threads", "4"]]
     for args in cases:
         r = run(asan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stdout[-500:] + r.stderr[-6000:])
         assert '"evaluations"' in r.stdout
-    for args in (cases[0], cases[2]):
+    for args in (cases[0], cases[2], cases[4]):
         t = run(tsan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
 
