@@ -316,6 +316,19 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                                    "what": "the same calibration through methods + getAverage() only; the engine groups time steps itself (fmhip_set_step_grouping)"}
         except Exception as e:
             lmm["finmath_like"] = {"error": str(e)[-500:]}
+        # … and with the optimiser's thread pool (LIBORMarketModelCalibrationATMTest.java:319: finmath-lib evaluates the columns of a Jacobian on
+        # several threads): the same caller on four threads, an engine each (fmhip_set_thread_engines).  At 1 M paths the calibration is bound by
+        # the device and the threads gain nothing; where it is bound by the host (100 k paths) they do.
+        try:
+            th = {}
+            for label, p_, t_ in (("paths_1000000_threads_4", paths, 4), ("paths_100000_threads_1", 100000, 1), ("paths_100000_threads_4", 100000, 4)):
+                tj, _ = run([LMM_HIP, "--paths", str(p_), "--mode", "calibrate", "--max-iterations", str(args.lmm_iterations), "--finmath-like", "--threads", str(t_)])
+                th[label] = {"seconds": tj["seconds"], "mean_deviation": tj["mean_deviation"], "evaluations": tj["evaluations"]}
+            th["identical_to_one_thread_at_1000000_paths"] = th["paths_1000000_threads_4"]["mean_deviation"] == lmm.get("finmath_like", {}).get("mean_deviation")
+            th["what"] = "lmm_hip --finmath-like --threads T: Jacobian columns on T caller threads, an engine per thread on the one GPU"
+            lmm["finmath_like_threads"] = th
+        except Exception as e:
+            lmm["finmath_like_threads"] = {"error": str(e)[-500:]}
         # ONE process, a device LIST (fmhip_init_devices: an engine and a worker thread per shard behind the same handles).  A gpurun / driver
         # box lends this rank one GPU, so the list names it twice: two shards of ONE GPU — what the front costs and that it calibrates the
         # same parameters, NOT a scaling figure.  Unmeasured on more than one physical GPU.
