@@ -64,7 +64,7 @@ static thread_local Binding binding;
 // this thread's engine: the one it is bound to, an idle one, or a new one with the first engine's settings
 static void ensure() {
     if (Engine::thread_is_bound()) return;                    // (an engine retired by fmhip_shutdown no longer counts: Engine::get)
-    std::lock_guard<std::mutex> lock(registry_mu);
+    std::unique_lock<std::mutex> lock(registry_mu);
     if (!idle.empty()) {
         Engine* e = engines[idle.back()].load(std::memory_order_acquire);
         idle.pop_back();
@@ -77,13 +77,14 @@ static void ensure() {
     { std::lock_guard<std::recursive_mutex> l0(first->mu); device = first->device_index(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
     Engine* e = Engine::create();
     e->set_index(i);
-    {
-        std::lock_guard<std::recursive_mutex> l(e->mu);
-        e->init(device);
-        e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
-    }
-    engines[i].store(e, std::memory_order_release);
+    engines[i].store(e, std::memory_order_release);           // (its lock is held until it is initialised: whoever finds it in the registry waits)
     count.store(i + 1, std::memory_order_release);
+    std::unique_lock<std::recursive_mutex> l(e->mu);
+    lock.unlock();                                            // the other threads' engines start side by side (an engine's start is ≈ 60 ms of allocations)
+    e->share_jit_of(*first);
+    e->init(device);
+    e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
+    l.unlock();
     Engine::bind_thread(e);
     binding.engine = e;
 }

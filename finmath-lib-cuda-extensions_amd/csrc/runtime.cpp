@@ -20,6 +20,7 @@
 #endif
 
 namespace fm {
+static std::atomic<uint64_t> g_te_malloc_ns{ 0 }, g_te_malloc_calls{ 0 }, g_te_init_ns{ 0 };     // FMHIP_TE_TRACE: where an engine's start goes
 
 void hip_check(hipError_t e, const char* what) {
     if (e == hipSuccess) return;
@@ -67,6 +68,8 @@ void* Pool::alloc(size_t bytes, size_t* cap_out) {
     size_t blocks = grow ? std::min<size_t>(grow * 2, 64) : 1;
     while (blocks > 1 && blocks * cap > (size_t(1) << 30)) blocks /= 2;
     void* base = nullptr;
+    const auto tm0 = std::chrono::steady_clock::now();
+    struct Tm { std::chrono::steady_clock::time_point t0; ~Tm() { g_te_malloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++g_te_malloc_calls; } } tm{ tm0 };
     hipError_t e = hipMalloc(&base, blocks * cap);
     if (e != hipSuccess && blocks > 1) { (void)hipGetLastError(); blocks = 1; e = hipMalloc(&base, cap); }
     if (e != hipSuccess) {              // last resort of the reference pool (:340): drop every cached buffer, retry once
@@ -149,6 +152,8 @@ void HostProfile::report() const {
 }
 
 void Engine::init(int device_index) {
+    const auto ti0 = std::chrono::steady_clock::now();
+    struct Ti { std::chrono::steady_clock::time_point t0; ~Ti() { g_te_init_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } ti{ ti0 };
     if (device_index < 0) {
         const char* e = std::getenv("FMHIP_DEVICE_INDEX");
         if (!e) e = std::getenv("LOCAL_RANK");
@@ -191,7 +196,7 @@ void Engine::init(int device_index) {
         else if (v == "sync" || v == "2") jit_mode = FMHIP_JIT_SYNC;
         else if (v == "auto" || v == "1") jit_mode = FMHIP_JIT_AUTO;
     }
-    jit_.start(device_index);
+    if (!jit_shared_) jit_.start(device_index);              // (a thread engine uses the first engine's compiler and code objects)
     { static std::once_flag once; std::call_once(once, [] { g_host_profile.on = std::getenv("FMHIP_HOST_PROFILE") != nullptr; }); }      // (process-wide: several engines initialise side by side behind a device list)
     for (const char* name : { "FMHIP_BM_GROUP_STEPS", "FMHIP_GROUP_STEPS" })       // (the first: where round 2 had this, in BrownianMotionHip)
         if (const char* e = std::getenv(name)) { const int v = std::atoi(e); if (v >= 0) group_steps = v; }
@@ -201,11 +206,13 @@ void Engine::init(int device_index) {
 }
 
 void Engine::shutdown() {
+    if (std::getenv("FMHIP_TE_TRACE")) std::fprintf(stderr, "[fmhip te] engine %d: so far in the process: hipMalloc of the pools %.1f ms in %llu calls, Engine::init %.1f ms\n", index_, g_te_malloc_ns.load() / 1e6, (unsigned long long)g_te_malloc_calls.load(), g_te_init_ns.load() / 1e6);
     if (!initialized_) return;
     if (g_host_profile.on) g_host_profile.report();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
-    jit_.stop();                        // joins the compiler thread, unloads the specialised kernels
+    if (!jit_shared_) jit_.stop();      // joins the compiler thread, unloads the specialised kernels
+    jit_shared_ = nullptr;
     nodes_.for_each([&](Node* nd) {     // leak-safe teardown: free storage of every live vector
         if (nd->buf) buffer_unref(nd->buf);     // back to the pool (blocks belong to slabs); purge() below frees the slabs
         delete nd;
@@ -710,12 +717,12 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
     // A kernel that EXISTS (the user's code-object cache, the build-time pack) is used from the program's first launch: looked up once, on
     // this thread (two hashes of the generated source and a file).  Round 3's calibration ran 563 launches on the interpreter although
     // every one of those programs had its kernel in the pack.
-    if (jit_mode == FMHIP_JIT_AUTO && !p->jit && !p->jit_probed) { p->jit_probed = true; p->jit = jit_.request_cached(p->proto); }
+    if (jit_mode == FMHIP_JIT_AUTO && !p->jit && !p->jit_probed) { p->jit_probed = true; p->jit = jit().request_cached(p->proto); }
     if (jit_mode != FMHIP_JIT_OFF && !p->jit) {
         p->interpreted_work += (double)n * batch * std::max(1, p->n_ops);       // (the stand-alone reduction has no ops: it counts as one)
-        if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);
+        if (jit_mode == FMHIP_JIT_SYNC || p->interpreted_work >= JIT_HOT_WORK) p->jit = jit().request(p->proto, jit_mode == FMHIP_JIT_SYNC);
     } else if (jit_mode == FMHIP_JIT_SYNC && p->jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)
-        p->jit = jit_.request(p->proto, true);      // queued earlier in auto mode: finish it now
+        p->jit = jit().request(p->proto, true);      // queued earlier in auto mode: finish it now
     const bool use_jit = jit_mode != FMHIP_JIT_OFF && p->jit && p->jit->state.load(std::memory_order_acquire) == JitSlot::READY;
     // the specialised kernel may process a different number of elements per lane and pass than the interpreter variant
     const int64_t elems_per_pass = (int64_t)FM_BLOCK * (use_jit ? p->jit->elems : FM_VARIANT_ELEMS[args.variant]);
@@ -1953,7 +1960,7 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
         body.ops.push_back({ uop, name[q][0], uv.r1_pos >= 0 ? name[q][(size_t)uv.r1_pos] : std::string(), uv.r2_pos >= 0 ? name[q][(size_t)uv.r2_pos] : std::string(),
                              op_info(nd->opcode).scalar });
     }
-    jit_.record(jit_describe(body));
+    jit().record(jit_describe(body));
     *source = jit_generate_rolled_source(body);
     if (body_out) *body_out = body;
     return true;
@@ -2030,7 +2037,7 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     pe.n_pre_scal = (uint32_t)pe.pre_scal.size(); pe.n_post_scal = (uint32_t)pe.post_scal.size(); pe.n_ops = (uint32_t)n;
     const size_t NX = pe.extra_leaf.size(), G = ro.global_leaf.size(), CO = ro.final_pos.size(), NXO = pe.pre_out.size() + pe.post_out.size(), LI = ro.leaf_in.size(), LO = ro.out_pos.size(), LS = ro.scal_pos.size();
     pe.row_words = (uint32_t)(NX + G + CO + NXO + R * (LI + LO) + (pe.n_pre_scal + R * LS + pe.n_post_scal + 1) / 2);
-    jit_.record(jit_describe(body));
+    jit().record(jit_describe(body));
     pe.source = jit_generate_rolled_source(body);
     pe.elems = body.elems;
     pe.present = true;
@@ -2038,7 +2045,7 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     if (body.elems == 8) {
         if (n > end) pl.reduce = "q" + std::to_string(n - 1 - end);
         else if (final_of[(n - 1 - begin) % P] >= 0) pl.reduce = "F" + std::to_string(final_of[(n - 1 - begin) % P]);
-        if (!pl.reduce.empty()) { jit_.record(jit_describe(body)); pe.source_red = jit_generate_rolled_source(body); }
+        if (!pl.reduce.empty()) { jit().record(jit_describe(body)); pe.source_red = jit_generate_rolled_source(body); }
     }
     ro.peeled = std::move(pe);
     return true;
@@ -2236,7 +2243,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
     { static const bool batch_trace = std::getenv("FMHIP_BATCH_TRACE") != nullptr;
       if (batch_trace && want_root_moments_) std::fprintf(stderr, "[fmhip batch] plan for a group of %zu, %zu nodes, %zu roots: rolled %d peeled %d segs %zu\n", group.size(), group[0].order.size(), group[0].roots.size(), plan.rolled.present ? 1 : 0, plan.rolled.peeled.present ? 1 : 0, plan.segs.size()); }
     if (plan.rolled.present && jit_mode != FMHIP_JIT_OFF && (!plan.rolled.jit || (jit_mode == FMHIP_JIT_SYNC && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
-        plan.rolled.jit = jit_.request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
+        plan.rolled.jit = jit().request_source(plan.rolled.source, plan.rolled.elems, jit_mode == FMHIP_JIT_SYNC);
     bool rolled = plan.rolled.present && jit_mode != FMHIP_JIT_OFF && plan.rolled.jit && plan.rolled.jit->state.load(std::memory_order_acquire) == JitSlot::READY;
     // The rolled launch carries one row table for all its members through the pinned ring (≈ 5 KB per row for the LMM step, but
     // iterations x (inputs + outputs) words in general): as many members per launch as fit; a single row that does not fit leaves the
@@ -2253,7 +2260,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
     {
         BigPlan::Rolled::Peeled& pe = plan.rolled.peeled;
         if (pe.present && jit_mode != FMHIP_JIT_OFF && (!pe.jit || (jit_mode == FMHIP_JIT_SYNC && pe.jit->state.load(std::memory_order_acquire) == JitSlot::QUEUED)))
-            pe.jit = jit_.request_source(pe.source, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+            pe.jit = jit().request_source(pe.source, pe.elems, jit_mode == FMHIP_JIT_SYNC);
         if (pe.present && jit_mode != FMHIP_JIT_OFF && pe.jit && pe.jit->state.load(std::memory_order_acquire) == JitSlot::READY && group[0].n > 0) {
             static const size_t PEEL_MAX_WORKGROUPS = [] { const char* e = std::getenv("FMHIP_PEEL_MAX_WORKGROUPS"); return e ? (size_t)std::atoll(e) : ~(size_t)0; }();
             const size_t tiles = (size_t)((group[0].n + (int64_t)FM_BLOCK * pe.jit->elems - 1) / ((int64_t)FM_BLOCK * pe.jit->elems));
@@ -2266,7 +2273,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                 if (rr && group.size() == 1 && !group[0].described() && !pe.source_red.empty() && group[0].order.back() == group[0].roots[0] &&
                     tiles <= (size_t)FM_SPAN_UNITS * 65536) {
                     if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
-                        pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+                        pe.jit_red = jit().request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
                     if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) fused = rr;
                 }
                 // … and with a flush that collects the moments of all pending roots (Engine::reduce): of every member, as rows of this launch
@@ -2279,7 +2286,7 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                     for (const BigDag& b : group) { Node* r = single_root(b, group[0]); roots_only &= r != nullptr && !r->moments_blocked && (!plan.discards_root || r->discard); }
                     if (roots_only) {
                         if (!pe.jit_red || (jit_mode == FMHIP_JIT_SYNC && pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::QUEUED))
-                            pe.jit_red = jit_.request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
+                            pe.jit_red = jit().request_source(pe.source_red, pe.elems, jit_mode == FMHIP_JIT_SYNC);
                         if (pe.jit_red->state.load(std::memory_order_acquire) == JitSlot::READY) {
                             if (async_moments_) { every.dev_out = arena_alloc(group.size()); if (every.dev_out) fused = &every; }
                             else { all.resize(group.size()); every.host_out = all.data(); fused = &every; }
@@ -2390,11 +2397,11 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
         RolledBody body;
         if (detect_loop(group[0], operand, plan.rolled, &source, &elems, &body)) {
             if (plan_peel(group[0], operand, plan.rolled, body) && jit_mode != FMHIP_JIT_OFF)
-                plan.rolled.peeled.jit = jit_.request_source(plan.rolled.peeled.source, plan.rolled.peeled.elems, jit_mode == FMHIP_JIT_SYNC);
+                plan.rolled.peeled.jit = jit().request_source(plan.rolled.peeled.source, plan.rolled.peeled.elems, jit_mode == FMHIP_JIT_SYNC);
             if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
             plan.rolled.present = true;
             plan.rolled.source = source; plan.rolled.elems = elems;
-            if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit_.request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
+            if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit().request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
             zone_begin = plan.rolled.begin; zone_end = zone_begin + (size_t)plan.rolled.period * plan.rolled.iterations;
         }
     }
@@ -2667,7 +2674,7 @@ Program* Engine::reduce_program() {
     auto it = program_cache_.find(key);
     if (it != program_cache_.end()) return it->second;
     Program* prog = compile({}, 1, {}, { 0 }, nullptr, true);
-    if (jit_mode != FMHIP_JIT_OFF) prog->jit = jit_.request(prog->proto, jit_mode == FMHIP_JIT_SYNC);      // every getAverage() runs it: specialised from the start (it is in the kernel pack)
+    if (jit_mode != FMHIP_JIT_OFF) prog->jit = jit().request(prog->proto, jit_mode == FMHIP_JIT_SYNC);      // every getAverage() runs it: specialised from the start (it is in the kernel pack)
     program_cache_[key] = prog;
     return prog;
 }
@@ -2979,7 +2986,7 @@ fmhip_program Engine::program_create(const fmhip_prog_op* ops, int n_ops, int n_
     std::vector<SsaOp> s(n_ops);
     for (int i = 0; i < n_ops; ++i) s[i] = { ops[i].opcode, ops[i].a, ops[i].b, ops[i].c, ops[i].scalar };
     Program* p = compile(s, n_in, std::vector<int>(outs, outs + n_out), std::vector<int>(reds, reds + n_red), nullptr, true);
-    if (jit_mode != FMHIP_JIT_OFF) p->jit = jit_.request(p->proto, jit_mode == FMHIP_JIT_SYNC);    // explicit = declared hot
+    if (jit_mode != FMHIP_JIT_OFF) p->jit = jit().request(p->proto, jit_mode == FMHIP_JIT_SYNC);    // explicit = declared hot
     const int64_t id = next_id_++;
     programs_[id] = p;
     return id;

@@ -302,8 +302,10 @@ public:
     void program_release(fmhip_program p);
     std::string program_source(const fmhip_prog_op* ops, int n_ops, int n_in, const int32_t* outs, int n_out, const int32_t* reds, int n_red);
     int jit_mode = FMHIP_JIT_AUTO;
-    void jit_wait() { jit_.wait_idle(); }
-    JitStats jit_stats() { return jit_.stats(); }
+    void jit_wait() { jit().wait_idle(); }
+    JitStats jit_stats() { return jit_shared_ ? JitStats() : jit_.stats(); }      // (a thread engine's kernels are counted where they live: in the first engine)
+    void share_jit_of(Engine& first) { jit_shared_ = &first.jit_; }     // before init(): thread engines on one device load every code object once
+    Jit& jit() { return jit_shared_ ? *jit_shared_ : jit_; }
     int64_t jit_launches() const { return n_jit_launches_; }
     int64_t rolled_launches() const { return n_rolled_launches_; }
     int64_t algorithmic_bytes() const { return algorithmic_bytes_; }
@@ -331,6 +333,7 @@ private:
     hipStream_t stream_ = nullptr;
     Pool pool_;
     Jit jit_;
+    Jit* jit_shared_ = nullptr;
     int64_t next_id_ = 1;
     int index_ = 0;
     struct Foreign { int owner = 0; fmhip_vec handle = 0; bool live = false; };
