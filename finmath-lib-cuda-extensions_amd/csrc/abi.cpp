@@ -73,8 +73,8 @@ static void ensure() {
     const int i = count.load(std::memory_order_acquire);
     if (i >= MAX_ENGINES) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "more caller threads than thread engines (" + std::to_string(MAX_ENGINES) + ")");
     Engine* first = engines[0].load(std::memory_order_acquire);
-    int device = 0, fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0;
-    { std::lock_guard<std::recursive_mutex> l0(first->mu); device = first->device_index(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
+    int device = 0, fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0; bool profiling = false;
+    { std::lock_guard<std::recursive_mutex> l0(first->mu); profiling = first->profiling(); device = first->device_index(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
     Engine* e = Engine::create();
     e->set_index(i);
     engines[i].store(e, std::memory_order_release);           // (its lock is held until it is initialised: whoever finds it in the registry waits)
@@ -84,6 +84,7 @@ static void ensure() {
     e->share_jit_of(*first);
     e->init(device);
     e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
+    if (profiling) e->profile_enable(true);
     l.unlock();
     Engine::bind_thread(e);
     binding.engine = e;

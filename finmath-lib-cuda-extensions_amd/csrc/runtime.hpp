@@ -324,6 +324,7 @@ public:
 
     // measurement
     void profile_enable(bool on);
+    bool profiling() const { return profiling_; }
     void profile_read(double* ms_total, int64_t* n);
 
 private:
