@@ -256,6 +256,50 @@ static void scenario_threads() {
     if (failures.load() != 0) { std::fprintf(stderr, "threads: %d failed calls (%s)\n", failures.load(), fmhip_last_error()); std::abort(); }
 }
 
+// Vectors, a pending expression, a program and tickets that cross threads (with FMNULL_THREAD_ENGINES=1: engines — a foreign operand is
+// imported, everything else runs on the owner's engine; without: the one engine's lock)
+static void scenario_shared() {
+    OK(fmhip_set_fusion(1, nullptr));
+    const int64_t n = 777;
+    V x = filled(n, 1.25), y = filled(n, 0.5);
+    V pending = s1(FMHIP_OP_MULT_S, x, 1.5);                       // not computed when the threads start
+    const fmhip_prog_op ops[] = { { FMHIP_OP_MULT, 0, 1, -1, 0.0 }, { FMHIP_OP_ADD_S, 2, -1, -1, 1.0 } };
+    const int32_t outv = 3;
+    fmhip_program prog = 0; OK(fmhip_program_create(ops, 2, 2, &outv, 1, &outv, 1, &prog));
+    std::vector<V> handed(6, 0);
+    std::vector<fmhip_ticket> tickets(6, 0);
+    std::atomic<int> failures{ 0 };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < 6; ++t)
+        ts.emplace_back([&, t] {
+            V cur = 0;
+            if (fmhip_call_v2s0(FMHIP_OP_ADD, pending, y, &cur) != FMHIP_OK) { ++failures; return; }          // a foreign, pending operand
+            for (int k = 0; k < 20; ++k) { V nx = 0; if (fmhip_call_v2s1(FMHIP_OP_DISCOUNT, cur, x, 0.25, &nx) != FMHIP_OK) { ++failures; return; } fmhip_vec_release(cur); cur = nx; }
+            fmhip_moments m;
+            if (fmhip_reduce_moments(cur, 0.0, &m) != FMHIP_OK) ++failures;
+            if (fmhip_reduce_moments(x, 0.0, &m) != FMHIP_OK) ++failures;                                       // the moments of another thread's vector
+            V in[2] = { cur, y }, out[1] = { 0 }; fmhip_moments pm[1];
+            if (fmhip_program_run(prog, 1, in, out, nullptr, pm, nullptr) != FMHIP_OK) ++failures;              // another thread's program, mixed operands
+            else fmhip_vec_release(out[0]);                                                                     // … its output belongs to the program's engine
+            V both[2] = { cur, pending };
+            if (fmhip_reduce_moments_batch_begin(both, 2, nullptr, &tickets[(size_t)t]) != FMHIP_OK) ++failures; // ended by the main thread
+            if (fmhip_vec_retain(y) != FMHIP_OK || fmhip_vec_release(y) != FMHIP_OK) ++failures;
+            int64_t size = 0; if (fmhip_vec_size(pending, &size) != FMHIP_OK || size != n) ++failures;
+            handed[(size_t)t] = cur;                                                                            // read and released by the main thread
+        });
+    for (auto& th : ts) th.join();
+    if (failures.load() != 0) { std::fprintf(stderr, "shared: %d failed calls (%s)\n", failures.load(), fmhip_last_error()); std::abort(); }
+    for (int t = 0; t < 6; ++t) {
+        fmhip_moments mm[2]; OK(fmhip_reduce_moments_batch_end(tickets[(size_t)t], mm, 2));
+        std::vector<float> h((size_t)n); OK(fmhip_vec_read_float(handed[(size_t)t], h.data(), n));
+        rel(handed[(size_t)t]);
+    }
+    OK(fmhip_synchronize());
+    fmhip_pool_stats_t st; OK(fmhip_pool_stats(&st));
+    OK(fmhip_program_release(prog));
+    rel(pending); rel(x); rel(y);
+}
+
 // FMHIP_TEST_FAIL_ALLOC_AT is set by the caller for this scenario: an allocation fails somewhere inside a replicated launch of 1100 members
 static void scenario_failure() {
     OK(fmhip_set_fusion(1, nullptr));
@@ -310,7 +354,7 @@ static void scenario_speed() {
 int main(int argc, char** argv) {
     struct Scenario { const char* name; void (*run)(); };
     const Scenario all[] = { { "basic", scenario_basic }, { "replicas", scenario_replicas }, { "expectations", scenario_expectations },
-                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "failure", scenario_failure }, { "speed", scenario_speed } };
+                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "shared", scenario_shared }, { "failure", scenario_failure }, { "speed", scenario_speed } };
     std::vector<std::string> wanted;
     for (int i = 1; i < argc; ++i) wanted.push_back(argv[i]);
     const bool only_failure = wanted.size() == 1 && wanted[0] == "failure";      // (the hook counts the allocations of the whole process: one cycle)
@@ -319,6 +363,8 @@ int main(int argc, char** argv) {
         const int n_devices = std::getenv("FMNULL_DEVICES") ? std::atoi(std::getenv("FMNULL_DEVICES")) : 1;
         if (n_devices > 1) { std::vector<int> devices((size_t)n_devices, 0); OK(fmhip_init_devices(devices.data(), n_devices)); int c = 0; OK(fmhip_device_count(&c)); if (c != n_devices) std::abort(); }
         else OK(fmhip_init(0));
+        // FMNULL_THREAD_ENGINES=1: an engine per caller thread (fmhip_set_thread_engines) — the scenarios' threads record side by side
+        if (n_devices <= 1 && std::getenv("FMNULL_THREAD_ENGINES")) { int was = -1; OK(fmhip_set_thread_engines(1, &was)); if (was != 0) std::abort(); }
         for (const Scenario& s : all) {
             bool run = wanted.empty() ? (std::strcmp(s.name, "failure") != 0 && std::strcmp(s.name, "speed") != 0) : false;
             for (const std::string& w : wanted) run |= w == s.name;

@@ -31,7 +31,7 @@ def run(binary, tmp_path, *scenarios, **extra_env):
 def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(built, tmp_path):
     r = run(os.path.join(built, "drive_asan"), tmp_path)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 10          # five scenarios, twice (shutdown and re-initialisation in between)
+    assert r.stdout.count("done") == 12          # six scenarios, twice (shutdown and re-initialisation in between)
     again = run(os.path.join(built, "drive_asan"), tmp_path)      # once more: the code objects of the first run come from the cache directory
     assert again.returncode == 0 and "Sanitizer" not in again.stderr, again.stderr[-6000:]
 
@@ -39,7 +39,7 @@ def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(
 def test_host_runtime_is_clean_under_thread_sanitizer(built, tmp_path):
     r = run(os.path.join(built, "drive_tsan"), tmp_path)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 10
+    assert r.stdout.count("done") == 12
 
 
 def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(built, tmp_path):
@@ -57,10 +57,10 @@ def test_a_device_list_is_clean_under_both_sanitizer_builds(built, tmp_path, sha
     through a single-producer ring per worker, reads and reductions gathered): ASan + UBSan, then ThreadSanitizer."""
     r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 10
+    assert r.stdout.count("done") == 12
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
-    assert t.stdout.count("done") == 10
+    assert t.stdout.count("done") == 12
 
 
 def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_path):
@@ -87,4 +87,17 @@ def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_p
     for args in (cases[0], cases[2], cases[4]):
         t = run(tsan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
+
+
+def test_thread_engines_are_clean_under_both_sanitizer_builds(built, tmp_path):
+    """Every scenario again with an engine per caller thread (fmhip_set_thread_engines; csrc/abi.cpp, namespace te): the eight threads of
+    `threads` record into engines of their own; `shared` crosses them — a pending vector of the main thread as an operand of six threads
+    (exported by its owner, imported as an aliasing leaf), the main thread's program run by the others with mixed operands, tickets begun
+    on one thread and ended on another, vectors handed over and released across engines; then shutdown (engines retired) and the same again."""
+    r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_THREAD_ENGINES="1")
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
+    assert r.stdout.count("done") == 12
+    t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_THREAD_ENGINES="1")
+    assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
+    assert t.stdout.count("done") == 12
 
