@@ -181,6 +181,18 @@ LMM_HIP = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd", "bin", "lmm_hip"
 LMM_CPU = os.path.join(ROOT, "oracle", "host", "lmm_cpu")
 
 
+def lmm_traffic_ratio():
+    """HBM bytes of the LMM op stream (FETCH_SIZE x 2 + WRITE_SIZE over every launch of 24 objective evaluations, separate rocprofv3 --pmc passes)
+    over the engine's algorithmic bytes for the same launches: measured OFFLINE (counters need profiler passes of their own), committed under
+    profiles/ (benchmarks/lmm_hbm_traffic.py); null if the file is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round04_lmm_hbm_traffic.json")) as fh:
+            t = json.load(fh)
+        return {"ratio": t["traffic_over_algorithmic"], "source": "profiles/round04_lmm_hbm_traffic.json"}
+    except Exception:
+        return None
+
+
 def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
     """BASELINE.json configs[3] / [4]: LMM ATM swaption calibration (LIBORMarketModelCalibrationATMTest.java:186-340 inputs,
     acceptance :466) at `--paths` paths per GPU in the native driver host/lmm.hpp over the C-ABI.  Runs in child processes
@@ -271,7 +283,8 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
            "rccl": {"calls": r.get("rccl_collectives", 0), "summed_latency_s": r.get("rccl_collective_seconds", 0.0),
                     "what": "one all-gather of 144 x {sum, sumsq, min, max} fp64 partials per objective evaluation; latency = enqueue to result on the host"},
            "roofline": {"bound": "hbm", "achieved": rp["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rp["achieved_GBps"] / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "all fused-program launches of the calibration itself (rank 0)",
+                        "traffic": None, "traffic_over_algorithmic_offline": lmm_traffic_ratio(),
+                        "kernel": "all fused-program launches of the calibration itself (rank 0)",
                         "launches": rp["profiled_launches"], "specialised_launches": rp["specialised_launches"],
                         "algorithmic_bytes": rp["algorithmic_bytes"], "summed_kernel_s": kernel_s,
                         "device_busy_fraction_of_wall": kernel_s / rp["seconds"],
