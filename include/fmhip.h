@@ -153,6 +153,8 @@ int fmhip_device_count(int* count);           /* devices (shards) behind the han
  * aliases that storage (streams ordered by events); release, retain, read, moments, programs and tickets of another thread run on the
  * owner's engine.  Settings (fusion, math mode, JIT mode, step grouping) apply to every engine; fmhip_flush and fmhip_fusion_hold to the
  * calling thread's; statistics are summed; fmhip_synchronize waits for all.  Not together with a device list.  Ends with fmhip_shutdown.
+ * Vectors are immutable, which is what makes sharing them safe; the two ways to WRITE into one (fmhip_program_run_into, a raw device pointer)
+ * are the caller's to order against other threads' use of that vector (fmhip_synchronize).
  * The reference funnels every thread through one executor thread (RandomVariableCuda.java:155). */
 int fmhip_set_thread_engines(int enabled, int* previous);
 int fmhip_shutdown(void);
