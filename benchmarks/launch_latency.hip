@@ -80,6 +80,24 @@ int main() {
         CK(hipDeviceSynchronize());
         printf("  \"host_enqueue\": {\"us_per_call\": %.2f},\n", std::chrono::duration<double, std::micro>(h1 - h0).count() / 2000);
     }
+    {   // the plain kernel at the headline's size: 64 x 10^6 elements, three vectors read, one written (1.024 GB)
+        const long N = 64000000, N4 = N / 4;
+        float4 *A, *B, *C, *O;
+        CK(hipMalloc(&A, N * 4)); CK(hipMalloc(&B, N * 4)); CK(hipMalloc(&C, N * 4)); CK(hipMalloc(&O, N * 4));
+        CK(hipMemset(A, 0x3c, N * 4)); CK(hipMemset(B, 0x3c, N * 4)); CK(hipMemset(C, 0x3c, N * 4));
+        for (int grid : { 7872, 31250, 62500 }) {
+            std::vector<float> s;
+            for (int r = 0; r < 6; ++r) {
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, 0));
+                for (int k = 0; k < 50; ++k) hipLaunchKernelGGL(row_kernel, grid, 256, 0, 0, A, B, C, O, N4);
+                CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (r > 0) s.push_back(ms * 1e3f / 50);
+            }
+            const double us = median(s);
+            printf("  \"plain_triad_64M_grid_%d\": {\"us\": %.1f, \"GBps\": %.0f, \"frac\": %.4f},\n", grid, us, 16.0 * N / (us * 1e-6) / 1e9, 16.0 * N / (us * 1e-6) / 8e12);
+        }
+    }
     printf("  \"what\": \"HIP events on the null stream; medians of %d repetitions, device idle before each\"\n}\n", REPS);
     return 0;
 }

@@ -106,6 +106,41 @@ int main() {
         }
         FM(fmhip_program_release(p_s_nored)); FM(fmhip_program_release(p_triad)); FM(fmhip_program_release(p_triad_red));
     }
+    printf("\n],\n\"sixty_four_rows_of_1000000_paths\": [\n");
+    {   // the headline shape: the engine's kernels for a + b*c and for stream S, with and without their fused reduction, K launches between one pair of events
+        const fmhip_prog_op triad[] = { { FMHIP_OP_ADDPRODUCT, 0, 1, 2, 0 } };
+        const int32_t triad_out = 3;
+        fmhip_program p_s_nored, p_triad, p_triad_red;
+        FM(fmhip_program_create(ops, 12, 3, &out_value, 1, nullptr, 0, &p_s_nored));
+        FM(fmhip_program_create(triad, 1, 3, &triad_out, 1, nullptr, 0, &p_triad));
+        FM(fmhip_program_create(triad, 1, 3, &triad_out, 1, &triad_out, 1, &p_triad_red));
+        struct Case { const char* name; fmhip_program p; } cases[] = { { "a + b*c", p_triad }, { "a + b*c + reduction", p_triad_red }, { "stream S, no reduction", p_s_nored }, { "stream S + reduction", prog } };
+        const long n = 1000000; const int B = 64;
+        std::vector<float> h((size_t)n);
+        std::vector<fmhip_vec> in((size_t)B * 3), out((size_t)B);
+        for (int k = 0; k < B * 3; ++k) {
+            for (long i = 0; i < n; ++i) h[(size_t)i] = 0.5f + 0.001f * (float)((i * 2654435761u + (unsigned)k * 40503u) % 1000);
+            FM(fmhip_vec_create_from_float(h.data(), n, &in[(size_t)k]));
+        }
+        for (int k = 0; k < B; ++k) FM(fmhip_vec_create_from_float(h.data(), n, &out[(size_t)k]));
+        bool first3 = true;
+        for (int round = 0; round < 2; ++round)
+        for (const Case& c : cases) {
+            for (int r = 0; r < 30; ++r) FM(fmhip_program_run_into(c.p, B, in.data(), out.data(), nullptr, nullptr, nullptr));
+            FM(fmhip_synchronize());
+            const int K = 200;
+            CK(hipEventRecord(e0, stream));
+            for (int r = 0; r < K; ++r) FM(fmhip_program_run_into(c.p, B, in.data(), out.data(), nullptr, nullptr, nullptr));
+            CK(hipEventRecord(e1, stream)); CK(hipEventSynchronize(e1));
+            float dev_ms = 0; CK(hipEventElapsedTime(&dev_ms, e0, e1));
+            const double us = dev_ms * 1e3 / K;
+            printf("%s {\"program\": \"%s\", \"us\": %.1f, \"GBps\": %.0f, \"frac\": %.4f}", first3 ? "" : ",\n", c.name, us, 16.0 * n * B / (us * 1e-6) / 1e9, 16.0 * n * B / (us * 1e-6) / 8e12);
+            first3 = false;
+        }
+        for (fmhip_vec v : in) FM(fmhip_vec_release(v));
+        for (fmhip_vec v : out) FM(fmhip_vec_release(v));
+        FM(fmhip_program_release(p_s_nored)); FM(fmhip_program_release(p_triad)); FM(fmhip_program_release(p_triad_red));
+    }
     printf("\n]}\n");
     FM(fmhip_program_release(prog));
     FM(fmhip_shutdown());
