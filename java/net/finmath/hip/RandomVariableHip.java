@@ -68,6 +68,9 @@ public class RandomVariableHip implements RandomVariable {
 	static {
 		Native.check(Native.init(Integer.getInteger("net.finmath.hip.device", -1)));		// -1: FMHIP_DEVICE_INDEX / LOCAL_RANK / 0
 		Native.check(Native.setFusion(Boolean.parseBoolean(System.getProperty("net.finmath.hip.fusion", "true")) ? 1 : 0, null));
+		// -Dnet.finmath.hip.threadEngines=true: an engine per Java thread (fmhip_set_thread_engines) — for a multi-threaded optimiser
+		// (LevenbergMarquardt with numberOfThreads > 1) at path counts where the host, not the device, is the bound
+		if (Boolean.getBoolean("net.finmath.hip.threadEngines")) Native.check(Native.setThreadEngines(1, null));
 	}
 
 	private static RandomVariableHip constant(final double time, final double value) {
