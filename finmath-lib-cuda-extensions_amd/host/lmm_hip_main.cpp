@@ -43,6 +43,8 @@ int main(int argc, char** argv) {
                 be.threads = o.threads;
             }
         } else if (o.threads > 1) throw std::runtime_error("--threads belongs to --finmath-like (the native driver batches its Jacobian columns instead)");
+        // --release-lag / --release-lag-bytes: the mirror's handles die when a collector thread says so (a JVM caller's lifetime contract)
+        if (o.releaseLagMs > 0.0 || o.releaseLagBytes > 0) ReleaseLag::instance().start(o.releaseLagMs, (size_t)o.releaseLagBytes);
         ncclComm_t comm = nullptr;
         std::vector<std::pair<double*, hipEvent_t>> sparePinned;      // pinned blocks and events of finished sharded expectations, used again
         fmhip_vec sums = 0;                              // device buffer of the expectation partials (count x 4 doubles)
@@ -185,11 +187,21 @@ int main(int argc, char** argv) {
                           (long long)(s.n_kernel_launches - s0.n_kernel_launches), (double)(s.n_ops_executed - s0.n_ops_executed) * (double)o.paths,
                           (long long)s.bytes_reserved, name, o.world, o.rank, (long long)o.world * (long long)o.paths, collectives, collective_seconds,
                           (long long)jc, (long long)jd, (long long)jp, js, (long long)(bytes1 - bytes0), (long long)jl);
-            return std::string(buf) + prof;
+            std::string lag;
+            if (ReleaseLag::instance().on()) {
+                const ReleaseLag::Stats ls = ReleaseLag::instance().stats();
+                char lb[384];
+                std::snprintf(lb, sizeof lb, ", \"release_lag\": {\"collect_every_ms\": %.3f, \"collect_at_bytes\": %lld, \"handles_queued\": %lld, \"handles_released\": %lld, "
+                              "\"collections\": %lld, \"collections_forced_by_out_of_memory\": %lld, \"peak_dead_handles\": %lld}",
+                              o.releaseLagMs, o.releaseLagBytes, ls.queued, ls.released, ls.collections, ls.forcedCollections, ls.peakQueue);
+                lag = lb;
+            }
+            return std::string(buf) + prof + lag;
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);
         else { lmm::Options quiet = o; quiet.verbose = false; lmm::runAndReport(quiet, be, "hip", extra); }        // every rank reports: the launcher compares the parameter vectors
         if (sums) fmhip_vec_release(sums);
+        ReleaseLag::instance().stop();                      // (the JVM exits: what is still queued is released)
         be = lmm::Backend();                                // (closures that may still hold a flight)
         for (auto& pe : sparePinned) { (void)hipHostFree(pe.first); (void)hipEventDestroy(pe.second); }
         if (comm) ncclCommDestroy(comm);

@@ -21,6 +21,8 @@ struct Options {
     int jacobianBatch = 0;                                 // finite-difference bumps simulated in lock-step (rows of one launch); 0 = back end default
     std::string brownian = "philox";                        // philox (counter-based, on the device) | mersenne (finmath's CPU generator through the factory)
     int threads = 1;                                       // --threads T (with --finmath-like): Jacobian columns on T threads, an engine each
+    double releaseLagMs = 0.0;                             // --release-lag MS: handles are released as a JVM would release them — by a collector thread, every MS milliseconds,
+    long long releaseLagBytes = 0;                         //   everything dead at that moment (ReleaseLag, random_variable.hpp); --release-lag-bytes B: … or once B bytes of dead wrappers have piled up
     bool finmathLike = false;                              // no hints to the engine: no hold / flush / replication / lock-step batches, all states kept, one getAverage per product
     bool profile = false;                                  // bracket every program launch with HIP events (device time of the op stream)      // path sharding over GPUs: one process per GPU
 };
@@ -44,6 +46,8 @@ inline Options parseOptions(int argc, char** argv) {
         else if (a == "--profile") o.profile = true;
         else if (a == "--finmath-like") o.finmathLike = true;
         else if (a == "--threads") o.threads = std::atoi(next());
+        else if (a == "--release-lag") o.releaseLagMs = std::atof(next());
+        else if (a == "--release-lag-bytes") o.releaseLagBytes = std::atoll(next());
         else if (a == "--brownian") o.brownian = next();
         else if (a == "--jacobian-batch") o.jacobianBatch = std::atoi(next());
         else if (a == "--chunk") o.chunk = std::atoi(next());

@@ -17,7 +17,10 @@
 // (LIBORMarketModelCalibrationATMTest.java:351-358).
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <limits>
@@ -25,6 +28,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fmhip.h"
@@ -162,6 +166,76 @@ struct FmhipError : std::runtime_error {
 };
 inline void check(int status) { if (status != FMHIP_OK) throw FmhipError(status, fmhip_last_error()); }
 
+// ------------------------------------------------------------------ a garbage collector's idea of a handle's lifetime
+//
+// The Java binding releases a handle when the collector says so: java/net/finmath/hip/DeviceVector.java registers a Cleaner action
+// per handle, the reference recycles device pointers through WeakReference / ReferenceQueue (RandomVariableCuda.java:96-106,
+// 293-305, 384-385).  The temporary of `x.add(y).mult(z)` is unreachable after the statement, but its release arrives at the NEXT
+// collection — tens to hundreds of milliseconds and thousands of recorded methods later —, in a burst, on the collector's thread.
+// This C++ mirror destroys temporaries at the end of the expression (RAII); ReleaseLag gives it the JVM's behaviour for measurements
+// and tests (lmm_hip --release-lag, tests/cpp/test_release_lag.cpp): every release the mirror would issue is queued instead and
+//   collectEveryMs > 0   a collector thread wakes every so many milliseconds and releases everything that was queued when it woke
+//                        (a periodic young collection: a dead object waits between 0 and one period);
+//   collectAtBytes > 0   … or releases everything once the dead wrappers amount to that many bytes of JVM heap (BYTES_PER_HANDLE each:
+//                        DeviceVector + its Cleaner registration + the RandomVariable around it) — "never, until the young
+//                        generation is full";
+//   a device allocation that fails (FMHIP_ERR_OUT_OF_MEMORY) runs a collection on the calling thread and is tried again once, as the
+//   reference does when device memory runs short (System.gc(), RandomVariableCuda.java:311-335).
+class ReleaseLag {
+public:
+    static constexpr size_t BYTES_PER_HANDLE = 128;
+    static ReleaseLag& instance() { static ReleaseLag r; return r; }
+    struct Stats { long long queued = 0, released = 0, collections = 0, forcedCollections = 0, peakQueue = 0; };
+    bool on() const { return on_.load(std::memory_order_relaxed); }
+    void start(double collectEveryMs, size_t collectAtBytes) {
+        stop();
+        if (!(collectEveryMs > 0.0) && collectAtBytes == 0) return;
+        everyMs_ = collectEveryMs; atBytes_ = collectAtBytes; quit_ = false;
+        on_.store(true);
+        collector_ = std::thread([this] { run(); });
+    }
+    void stop() {                                        // the JVM exits: whatever is queued is released
+        if (!on_.load()) return;
+        { std::lock_guard<std::mutex> lock(mu_); quit_ = true; }
+        cv_.notify_all();
+        if (collector_.joinable()) collector_.join();
+        on_.store(false);
+        collect(false);
+    }
+    void died(fmhip_vec h) {                             // a wrapper object has become unreachable
+        bool wake = false;
+        { std::lock_guard<std::mutex> lock(mu_); dead_.push_back(h); ++stats_.queued; stats_.peakQueue = std::max<long long>(stats_.peakQueue, (long long)dead_.size());
+          wake = atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_; }
+        if (wake) cv_.notify_one();
+    }
+    void collect(bool forced) {                          // one collection, on the calling thread
+        std::vector<fmhip_vec> batch;
+        { std::lock_guard<std::mutex> lock(mu_); batch.swap(dead_); ++stats_.collections; if (forced) ++stats_.forcedCollections; stats_.released += (long long)batch.size(); }
+        for (fmhip_vec h : batch) fmhip_vec_release(h);
+    }
+    Stats stats() { std::lock_guard<std::mutex> lock(mu_); return stats_; }
+    ~ReleaseLag() { if (collector_.joinable()) { { std::lock_guard<std::mutex> lock(mu_); quit_ = true; } cv_.notify_all(); collector_.join(); } }
+private:
+    void run() {
+        std::unique_lock<std::mutex> lock(mu_);
+        while (!quit_) {
+            if (everyMs_ > 0.0) cv_.wait_for(lock, std::chrono::duration<double, std::milli>(everyMs_), [this] { return quit_ || (atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_); });
+            else cv_.wait(lock, [this] { return quit_ || dead_.size() * BYTES_PER_HANDLE >= atBytes_; });
+            if (quit_) break;
+            lock.unlock();
+            collect(false);
+            lock.lock();
+        }
+    }
+    std::atomic<bool> on_{ false };
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<fmhip_vec> dead_;
+    std::thread collector_;
+    double everyMs_ = 0.0; size_t atBytes_ = 0; bool quit_ = false;
+    Stats stats_;
+};
+
 // Move-only owner of one handle, held BY VALUE inside a RandomVariableHip (no heap object of its own: a Monte-Carlo
 // driver creates tens of thousands of random variables per objective evaluation and is bound by host time).  Sharing a
 // vector between two random variables goes through the engine's own reference count (fmhip_vec_retain).
@@ -169,24 +243,31 @@ class DeviceVector {
 public:
     DeviceVector() = default;
     explicit DeviceVector(fmhip_vec h) : h_(h) {}
-    ~DeviceVector() { if (h_) fmhip_vec_release(h_); }
+    ~DeviceVector() { drop(); }
     DeviceVector(DeviceVector&& o) noexcept : h_(o.h_) { o.h_ = 0; }
-    DeviceVector& operator=(DeviceVector&& o) noexcept { if (this != &o) { if (h_) fmhip_vec_release(h_); h_ = o.h_; o.h_ = 0; } return *this; }
+    DeviceVector& operator=(DeviceVector&& o) noexcept { if (this != &o) { drop(); h_ = o.h_; o.h_ = 0; } return *this; }
     DeviceVector(const DeviceVector&) = delete;
     DeviceVector& operator=(const DeviceVector&) = delete;
     fmhip_vec handle() const { return h_; }
     bool valid() const { return h_ != 0; }
     DeviceVector share() const { if (!h_) return DeviceVector(); check(fmhip_vec_retain(h_)); return DeviceVector(h_); }
-    static DeviceVector fromHost(const std::vector<double>& v) { fmhip_vec h = 0; check(fmhip_vec_create_from_double(v.data(), (int64_t)v.size(), &h)); return DeviceVector(h); }
-    static DeviceVector filled(int64_t n, double value) { fmhip_vec h = 0; check(fmhip_vec_create_filled(n, value, &h)); return DeviceVector(h); }
+    static DeviceVector fromHost(const std::vector<double>& v) { fmhip_vec h = 0; guarded([&] { return fmhip_vec_create_from_double(v.data(), (int64_t)v.size(), &h); }); return DeviceVector(h); }
+    static DeviceVector filled(int64_t n, double value) { fmhip_vec h = 0; guarded([&] { return fmhip_vec_create_filled(n, value, &h); }); return DeviceVector(h); }
     // the five launch helpers of the reference (callFunctionv1s0 … v3s0, :483-537), on raw handles
-    static DeviceVector v1s0(int op, fmhip_vec a) { fmhip_vec o = 0; check(fmhip_call_v1s0(op, a, &o)); return DeviceVector(o); }
-    static DeviceVector v1s1(int op, fmhip_vec a, double s) { fmhip_vec o = 0; check(fmhip_call_v1s1(op, a, s, &o)); return DeviceVector(o); }
-    static DeviceVector v2s0(int op, fmhip_vec a, fmhip_vec b) { fmhip_vec o = 0; check(fmhip_call_v2s0(op, a, b, &o)); return DeviceVector(o); }
-    static DeviceVector v2s1(int op, fmhip_vec a, fmhip_vec b, double s) { fmhip_vec o = 0; check(fmhip_call_v2s1(op, a, b, s, &o)); return DeviceVector(o); }
-    static DeviceVector v3s0(int op, fmhip_vec a, fmhip_vec b, fmhip_vec c) { fmhip_vec o = 0; check(fmhip_call_v3s0(op, a, b, c, &o)); return DeviceVector(o); }
-    fmhip_moments moments(double shift = 0.0) const { fmhip_moments m; check(fmhip_reduce_moments(h_, shift, &m)); return m; }
+    static DeviceVector v1s0(int op, fmhip_vec a) { fmhip_vec o = 0; guarded([&] { return fmhip_call_v1s0(op, a, &o); }); return DeviceVector(o); }
+    static DeviceVector v1s1(int op, fmhip_vec a, double s) { fmhip_vec o = 0; guarded([&] { return fmhip_call_v1s1(op, a, s, &o); }); return DeviceVector(o); }
+    static DeviceVector v2s0(int op, fmhip_vec a, fmhip_vec b) { fmhip_vec o = 0; guarded([&] { return fmhip_call_v2s0(op, a, b, &o); }); return DeviceVector(o); }
+    static DeviceVector v2s1(int op, fmhip_vec a, fmhip_vec b, double s) { fmhip_vec o = 0; guarded([&] { return fmhip_call_v2s1(op, a, b, s, &o); }); return DeviceVector(o); }
+    static DeviceVector v3s0(int op, fmhip_vec a, fmhip_vec b, fmhip_vec c) { fmhip_vec o = 0; guarded([&] { return fmhip_call_v3s0(op, a, b, c, &o); }); return DeviceVector(o); }
+    fmhip_moments moments(double shift = 0.0) const { fmhip_moments m; guarded([&] { return fmhip_reduce_moments(h_, shift, &m); }); return m; }
+    // A call that may allocate device memory: out of memory under a lagging collector → collect, try once more (ReleaseLag).
+    template <class Call> static void guarded(Call&& call) {
+        int status = call();
+        if (status == FMHIP_ERR_OUT_OF_MEMORY && ReleaseLag::instance().on()) { ReleaseLag::instance().collect(true); status = call(); }
+        check(status);
+    }
 private:
+    void drop() { if (!h_) return; if (ReleaseLag::instance().on()) ReleaseLag::instance().died(h_); else fmhip_vec_release(h_); h_ = 0; }
     fmhip_vec h_ = 0;
 };
 
@@ -224,7 +305,7 @@ public:
     std::vector<double> getRealizations() const override {
         if (isDeterministic()) return { value_ };
         std::vector<double> out((size_t)n_);
-        check(fmhip_vec_read_double(vec_.handle(), out.data(), n_));
+        DeviceVector::guarded([&] { return fmhip_vec_read_double(vec_.handle(), out.data(), n_); });
         return out;
     }
     const DeviceVector& deviceVector() const { return vec_; }
@@ -476,7 +557,7 @@ inline std::vector<double> getAverages(const std::vector<RV>& values) {
     }
     if (!handles.empty() && uniform) {
         std::vector<fmhip_moments> m(handles.size());
-        check(fmhip_reduce_moments_batch(handles.data(), (int)handles.size(), nullptr, m.data()));
+        DeviceVector::guarded([&] { return fmhip_reduce_moments_batch(handles.data(), (int)handles.size(), nullptr, m.data()); });
         int world = 1; check(fmhip_expectation_world(&world, nullptr));
         for (size_t i = 0; i < handles.size(); ++i) out[where[i]] = m[i].sum / ((double)n * world);
     } else for (size_t k : where) out[k] = values[k]->getAverage();
