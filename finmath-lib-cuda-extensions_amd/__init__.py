@@ -235,6 +235,14 @@ def traffic_stats() -> tuple:
     return b.value, l.value
 
 
+def engine_stats() -> dict:
+    """fmhip_engine_stats: launches by tier, algorithmic bytes read + written and written alone, values left unstored (deferred) / wanted
+    after all (demanded), pending operations, the pool's peak."""
+    st = _native.EngineStats()
+    _native.check(lib().fmhip_engine_stats(_C.byref(st)))
+    return {n: getattr(st, n) for n, _ in _native.EngineStats._fields_ if n != "size"}
+
+
 def jit_stats() -> dict:
     c, f, p, s, d = _C.c_int64(0), _C.c_int64(0), _C.c_int64(0), _C.c_double(0), _C.c_int64(0)
     _native.check(lib().fmhip_jit_stats(_C.byref(c), _C.byref(f), _C.byref(p), _C.byref(s), _C.byref(d)))

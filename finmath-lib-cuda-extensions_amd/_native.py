@@ -29,7 +29,7 @@ SYMBOLS = [
     "fmhip_set_jit", "fmhip_jit_wait", "fmhip_jit_stats", "fmhip_program_tier", "fmhip_program_source",
     "fmhip_bm_generate", "fmhip_mersenne_increments", "fmhip_bm_generate_mersenne", "fmhip_inverse_normal_cdf",
     "fmhip_pool_clean", "fmhip_pool_purge", "fmhip_pool_stats",
-    "fmhip_profile_enable", "fmhip_profile_read", "fmhip_traffic_stats",
+    "fmhip_profile_enable", "fmhip_profile_read", "fmhip_traffic_stats", "fmhip_engine_stats",
 ]
 
 OK = 0
@@ -53,6 +53,12 @@ class PoolStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "bytes_reserved", "bytes_in_use", "bytes_cached", "device_bytes_free", "device_bytes_total",
         "n_alloc_hits", "n_alloc_misses", "n_live_vectors", "n_kernel_launches", "n_ops_executed")]
+
+
+class EngineStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "size", "kernel_launches", "specialised_launches", "interpreter_launches", "algorithmic_bytes", "algorithmic_bytes_written",
+        "values_deferred", "values_deferred_now", "values_demanded", "pending_operations", "peak_bytes_reserved")]
 
 
 class FmhipError(RuntimeError):
@@ -167,6 +173,7 @@ def lib():
         "fmhip_program_tier": [i64, C.POINTER(i32), C.POINTER(i32)],
         "fmhip_program_source": [C.POINTER(ProgOp), i32, i32, C.POINTER(i32), i32, C.POINTER(i32), i32, C.c_char_p, i64, C.POINTER(i64)],
         "fmhip_traffic_stats": [C.POINTER(i64), C.POINTER(i64)],
+        "fmhip_engine_stats": [C.POINTER(EngineStats)],
         "fmhip_profile_enable": [i32], "fmhip_profile_read": [C.POINTER(dbl), C.POINTER(i64)],
     }
     for name, args in sig.items():

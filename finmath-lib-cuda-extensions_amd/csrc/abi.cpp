@@ -1,9 +1,12 @@
-// abi.cpp — the extern "C" surface declared in include/fmhip.h.  No logic: argument checks, the engine
-// lock, exception → status translation.  A JNI layer maps 1:1 onto these.
+// abi.cpp — the extern "C" surface declared in include/fmhip.h: argument checks, the engine lock, exception → status translation —
+// and the one piece of logic that lives at this level because it is ABOUT the boundary: thread engines (namespace te), i.e. which
+// engine a call of which thread on which handle runs on, and how a vector of one engine enters another (import / export, events in both
+// directions).  A JNI layer maps 1:1 onto the entry points.
 #include "runtime.hpp"
 #include "sharded.hpp"
 #include <cmath>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -73,16 +76,23 @@ static void ensure() {
     const int i = count.load(std::memory_order_acquire);
     if (i >= MAX_ENGINES) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "more caller threads than thread engines (" + std::to_string(MAX_ENGINES) + ")");
     Engine* first = engines[0].load(std::memory_order_acquire);
-    int device = 0, fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0; bool profiling = false;
-    { std::lock_guard<std::recursive_mutex> l0(first->mu); profiling = first->profiling(); device = first->device_index(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
+    const int device = first->device_index();                 // (fixed since fmhip_init)
     Engine* e = Engine::create();
     e->set_index(i);
-    engines[i].store(e, std::memory_order_release);           // (its lock is held until it is initialised: whoever finds it in the registry waits)
-    count.store(i + 1, std::memory_order_release);
+    // Its lock is taken BEFORE it can be found: whoever finds it in the registry — a setter or fmhip_synchronize walking all engines —
+    // waits until it is initialised (until round 5 the engine was published first, and such a caller could lock it uninitialised).
     std::unique_lock<std::recursive_mutex> l(e->mu);
+    engines[i].store(e, std::memory_order_release);
+    count.store(i + 1, std::memory_order_release);
     lock.unlock();                                            // the other threads' engines start side by side (an engine's start is ≈ 60 ms of allocations)
     e->share_jit_of(*first);
     e->init(device);
+    // The settings are the first engine's as they are NOW, after this engine has become visible: a setter that ran before has changed the
+    // first engine already, one that comes later finds this engine, waits for its lock and sets it itself — none is missed (copied before
+    // the registration, a concurrent fmhip_set_math_mode left one thread on EXACT and the others on FAST).  Lock order e → first: nobody
+    // holds the first engine's lock while waiting for another engine's.
+    int fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0; bool profiling = false;
+    { std::lock_guard<std::recursive_mutex> l0(first->mu); profiling = first->profiling(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
     e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
     if (profiling) e->profile_enable(true);
     l.unlock();
@@ -103,6 +113,16 @@ static void drain(Engine& e) {
 struct Localized {
     std::vector<fmhip_vec> local, taken;
     Localized(const fmhip_vec* h, int n) : local(h, h + (n > 0 ? n : 0)) {
+        try { import_all(); }
+        catch (...) { give_back(); throw; }                   // (a constructor that throws has no destructor: the imports made so far go back here)
+    }
+    void give_back() {
+        if (taken.empty()) return;
+        Engine& mine = Engine::get();
+        { std::lock_guard<std::recursive_mutex> l(mine.mu); for (fmhip_vec v : taken) { try { mine.release(v); } catch (...) {} } }
+        taken.clear();
+    }
+    void import_all() {
         Engine& mine = Engine::get();
         for (fmhip_vec& v : local) {
             if (!(v > 0 && Engine::owner_of(v) != mine.index())) continue;
@@ -124,14 +144,12 @@ struct Localized {
             v = loc;
         }
     }
-    ~Localized() {
-        if (taken.empty()) return;
-        Engine& mine = Engine::get();
-        { std::lock_guard<std::recursive_mutex> l(mine.mu); for (fmhip_vec v : taken) { try { mine.release(v); } catch (...) {} } }
-    }
+    ~Localized() { give_back(); }
     bool any() const { return !taken.empty(); }
 };
 }
+
+static uint64_t thread_tag() { static std::atomic<uint64_t> next{ 1 }; static thread_local const uint64_t tag = next.fetch_add(1); return tag; }
 
 template <typename F>
 static int guarded(F&& f) {
@@ -141,6 +159,8 @@ static int guarded(F&& f) {
         Engine& e = Engine::get();
         {
             std::lock_guard<std::recursive_mutex> lock(e.mu);
+            e.note_driver(thread_tag());
+            if (e.late_count() >= Engine::LATE_DRAIN) e.drain_late();      // releases other threads have left (Engine::release_later): in batches — and at every flush
             f();
         }
         if (thread_engines) te::drain(e);
@@ -171,7 +191,10 @@ template <typename F> static int status_of(F&& f) {
 }
 // `call` on the engine that owns h, if that is not this thread's
 template <typename F> static int owner_routed(int64_t h, F&& call) {
-    return status_of([&]() -> int { ensure(); if (!foreign(h)) return NOT_MINE_TO_HANDLE; Rebind r(owner(h)); return call(); });
+    // (a thread WITHOUT an engine — a collector thread that only releases, a reader — gets none for this: the handle names its owner)
+    return status_of([&]() -> int {
+        if (!Engine::thread_is_bound() && h > 0) { Rebind r(owner(h)); return call(); }
+        ensure(); if (!foreign(h)) return NOT_MINE_TO_HANDLE; Rebind r(owner(h)); return call(); });
 }
 // `call(local handles)` on this thread's engine, foreign operands imported
 template <typename F> static int with_local(const fmhip_vec* h, int n, F&& call) {
@@ -320,7 +343,34 @@ int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
     return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
 }
 int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); TE_OWNER(v, fmhip_vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
-int fmhip_vec_release(fmhip_vec v) { FRONT(vec_release(v)); TE_OWNER(v, fmhip_vec_release(v)); return guarded([&] { Engine::get().release(v); }); }
+// A release by the thread that drives the engine is performed at once; one by another thread — a collector's cleaner — is queued and
+// performed by whoever enters the engine next (runtime.hpp: release_later).  Queued releases cannot report an invalid handle.
+static int release_vector(fmhip_vec v) {
+    try {
+        Engine& e = Engine::get();
+        static const bool LATE = [] { const char* s = std::getenv("FMHIP_LATE_RELEASES"); return !(s && s[0] == '0'); }();      // =0: every release takes the engine lock (rounds 1–4; A/B measurement)
+        if (LATE && !e.driven_by(thread_tag())) {
+            if (!e.release_later(v)) return FMHIP_OK;
+            std::lock_guard<std::recursive_mutex> lock(e.mu);
+            e.drain_late();
+            return FMHIP_OK;
+        }
+        std::lock_guard<std::recursive_mutex> lock(e.mu);
+        if (e.has_late()) e.drain_late();
+        e.release(v);
+        return FMHIP_OK;
+    } catch (const Error& e) { g_last_error = e.what(); return e.code; }
+    catch (const std::exception& e) { g_last_error = e.what(); return FMHIP_ERR_HIP; }
+}
+int fmhip_vec_release(fmhip_vec v) {
+    FRONT(vec_release(v));
+    if (te::active()) {
+        // (thread engines: the handle names its owner — a thread without an engine of its own, a cleaner, gets none for this)
+        const int rc = te::status_of([&]() -> int { if (v <= 0) return te::NOT_MINE_TO_HANDLE; te::Rebind r(te::owner(v)); return release_vector(v); });
+        if (rc != te::NOT_MINE_TO_HANDLE) return rc;
+    }
+    return release_vector(v);
+}
 int fmhip_vec_size(fmhip_vec v, int64_t* n_out) {
     FRONT(vec_size(v, n_out));
     TE_OWNER(v, fmhip_vec_size(v, n_out));
@@ -731,6 +781,19 @@ int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launche
         if (algorithmic_bytes) *algorithmic_bytes = Engine::get().algorithmic_bytes();
         if (specialised_launches) *specialised_launches = Engine::get().jit_launches();
     });
+}
+int fmhip_engine_stats(fmhip_engine_stats_t* out) {
+    FRONT(engine_stats(out));
+    if (te::active()) {
+        if (!out) { g_last_error = "null pointer: out"; return FMHIP_ERR_INVALID_ARGUMENT; }
+        fmhip_engine_stats_t sum; std::memset(&sum, 0, sizeof sum);
+        const int rc = te::on_all([&](bool) -> int { fmhip_engine_stats_t one; const int st = fmhip_engine_stats(&one); if (st != FMHIP_OK) return st;
+            int64_t* a = &sum.size; const int64_t* b = &one.size; for (size_t i = 1; i < sizeof sum / sizeof(int64_t); ++i) a[i] += b[i]; return FMHIP_OK; });
+        sum.size = (int64_t)sizeof sum;
+        if (rc == FMHIP_OK) *out = sum;
+        return rc;
+    }
+    return guarded([&] { Engine::get().engine_stats(out); });
 }
 int fmhip_profile_enable(int enabled) { FRONT(profile_enable(enabled)); TE_ALL(mine, fmhip_profile_enable(enabled)); return guarded([&] { Engine::get().profile_enable(enabled != 0); }); }
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches) {

@@ -21,6 +21,7 @@ hipError_t launch_program(const DevProgramArgs& a, const uint64_t* rows, double*
                           uint32_t blocks_per_row, uint32_t batch, hipStream_t st);
 hipError_t launch_bm(const DevBmArgs& a, uint32_t n_streams, hipStream_t st);
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st);
+hipError_t preload_kernels();        // makes the device code of every kernel above resident (the runtime would load it at first launch)
 
 // {Σ, Σ², min, max} blocks of 32 bytes collected from wherever the launches that took them left them (slots of the pinned moments arena,
 // mapped into the device's address space) into one contiguous device buffer — the send buffer of an RCCL exchange.

@@ -406,6 +406,31 @@ hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t st)
     return hipGetLastError();
 }
 
+// Every kernel of this library made resident NOW (Engine::init): the HIP runtime loads device code lazily, at a kernel's first launch,
+// and that load needs device memory — a caller whose pool has grown to the size of the device by then (handles released late, by a
+// garbage collector) met "no kernel image is available" at the interpreter tier's first launch, thousands of launches into its run.
+template <int NRED> static hipError_t preload_program_nred()
+{
+    hipFuncAttributes at;
+    hipError_t e = hipSuccess;
+    auto one = [&](const void* f) { if (e == hipSuccess) e = hipFuncGetAttributes(&at, f); };
+    one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, true, 8, 9, 3, f32x9>));   one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, false, 8, 9, 3, f32x9>));
+    one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, true, 8, 9, 8, f32x9>));   one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, false, 8, 9, 8, f32x9>));
+    one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, true, 4, 16, FM_MAX_IN, f32x16>)); one(reinterpret_cast<const void*>(&fm_program_kernel<NRED, false, 4, 16, FM_MAX_IN, f32x16>));
+    return e;
+}
+hipError_t preload_kernels()
+{
+    hipFuncAttributes at;
+    hipError_t e = preload_program_nred<0>();
+    if (e == hipSuccess) e = preload_program_nred<1>();
+    if (e == hipSuccess) e = preload_program_nred<2>();
+    if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_bm_kernel));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_fill_kernel));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_gather_moments_kernel));
+    return e;
+}
+
 hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t st)
 {
     if (a.count == 0) return hipSuccess;

@@ -53,7 +53,7 @@ void* Pool::alloc(size_t bytes, size_t* cap_out) {
     *cap_out = cap;
     // test hook (tests/test_gpu_replicas.py): the N-th allocation of the process fails like a device that is out of memory
     static const long long FAIL_AT = [] { const char* e = std::getenv("FMHIP_TEST_FAIL_ALLOC_AT"); return e ? std::atoll(e) : 0ll; }();
-    static long long calls = 0;
+    static std::atomic<long long> calls{ 0 };            // (several engines — thread engines, device lists — allocate side by side)
     if (FAIL_AT > 0 && ++calls == FAIL_AT) throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation failed (FMHIP_TEST_FAIL_ALLOC_AT)");
     std::vector<void*>& fl = free_[cap];
     if (!fl.empty()) {
@@ -64,29 +64,44 @@ void* Pool::alloc(size_t bytes, size_t* cap_out) {
     }
     // Miss.  Device allocations are expensive (≈ 100 µs each) and a Monte-Carlo state is thousands of equally sized vectors:
     // allocate SLABS of 1, 2, 4 … 64 blocks of this size class (≤ 1 GiB per slab) and hand the rest to the free list.
-    size_t& grow = slab_blocks_[cap];
-    size_t blocks = grow ? std::min<size_t>(grow * 2, 64) : 1;
+    const size_t grown = slab_blocks_[cap];
+    size_t blocks = grown ? std::min<size_t>(grown * 2, 64) : 1;
     while (blocks > 1 && blocks * cap > (size_t(1) << 30)) blocks /= 2;
     void* base = nullptr;
     const auto tm0 = std::chrono::steady_clock::now();
     struct Tm { std::chrono::steady_clock::time_point t0; ~Tm() { g_te_malloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++g_te_malloc_calls; } } tm{ tm0 };
-    hipError_t e = hipMalloc(&base, blocks * cap);
-    if (e != hipSuccess && blocks > 1) { (void)hipGetLastError(); blocks = 1; e = hipMalloc(&base, cap); }
+    // The pool never takes the LAST of the device: the HIP runtime itself allocates device memory while the process runs (code objects the
+    // JIT tier loads, kernels loaded at their first launch, scratch, signals), and a caller whose handles die late — a garbage-collected
+    // one — grows the pool until something fails.  With less than the headroom left a miss counts as out of memory (purge, then the error
+    // the caller answers with a collection: RandomVariableCuda.java:311-335 does the same below a free-memory percentage).  Asked on a miss
+    // only: a slab allocation costs ≈ 100 µs, the query a few.
+    static const size_t HEADROOM = [] { const char* e = std::getenv("FMHIP_POOL_HEADROOM_BYTES"); return e ? (size_t)std::atoll(e) : (size_t(2) << 30); }();
+    auto room_for = [&](size_t bytes) { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return true; } return fr >= bytes + HEADROOM; };
+    hipError_t e = hipErrorOutOfMemory;
+    if (blocks > 1 && !room_for(blocks * cap)) blocks = 1;
+    if (room_for(blocks * cap)) {
+        e = hipMalloc(&base, blocks * cap);
+        if (e != hipSuccess && blocks > 1) { (void)hipGetLastError(); blocks = 1; e = hipMalloc(&base, cap); }
+    }
     if (e != hipSuccess) {              // last resort of the reference pool (:340): drop every cached buffer, retry once
         (void)hipGetLastError();
         purge();
         blocks = 1;
-        e = hipMalloc(&base, cap);
+        if (room_for(cap)) e = hipMalloc(&base, cap);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e));
+        throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e) + " (the pool holds " + std::to_string(reserved >> 20) +
+                    " MiB, " + std::to_string(in_use >> 20) + " MiB of them in live vectors; " + std::to_string(HEADROOM >> 20) + " MiB of the device are left to the HIP runtime)");
     }
-    grow = blocks;
+    // (looked up again: purge() above drops the entries of size classes it has emptied — until round 5 a reference taken before the purge
+    // was written through here, into a freed map node: heap corruption whenever an allocation of a rarely used size met a full device)
+    slab_blocks_[cap] = blocks;
     slabs_.push_back({ base, cap, blocks });
     std::vector<void*>& fl2 = free_[cap];
     for (size_t i = blocks; i-- > 1;) { fl2.push_back((char*)base + i * cap); cached += (int64_t)cap; }
     misses++; reserved += (int64_t)(blocks * cap); in_use += (int64_t)cap;
+    peak_reserved = std::max(peak_reserved, reserved);
     return base;
 }
 
@@ -188,6 +203,7 @@ void Engine::init(int device_index) {
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
     hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
+    hip_check(preload_kernels(), "loading the device code");
     ring_off_ = 0;
     device_ = device_index;
     if (const char* e = std::getenv("FMHIP_JIT")) {
@@ -208,6 +224,7 @@ void Engine::init(int device_index) {
 void Engine::shutdown() {
     if (std::getenv("FMHIP_TE_TRACE")) std::fprintf(stderr, "[fmhip te] engine %d: so far in the process: hipMalloc of the pools %.1f ms in %llu calls, Engine::init %.1f ms\n", index_, g_te_malloc_ns.load() / 1e6, (unsigned long long)g_te_malloc_calls.load(), g_te_init_ns.load() / 1e6);
     if (!initialized_) return;
+    drain_late();
     if (g_host_profile.on) g_host_profile.report();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(stream_);
@@ -227,7 +244,7 @@ void Engine::shutdown() {
     programs_.clear();
     for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) { if (--seg.prog->refs == 0) delete seg.prog; delete seg.prog_red; }
     plan_cache_.clear();
-    schedule_cache_.clear(); schedule_cache_bytes_ = 0;
+    schedule_cache_.clear(); schedule_cache_bytes_ = 0; dag_policies_.clear(); policy_reset();
     for (auto& kv : program_cache_) if (--kv.second->refs == 0) delete kv.second;
     program_cache_.clear();
     pool_.purge();
@@ -253,7 +270,7 @@ void Engine::shutdown() {
     device_ = -1;
 }
 
-void Engine::synchronize() { require_init(); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
+void Engine::synchronize() { require_init(); if (has_late()) drain_late(); hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize"); }
 
 void Engine::device_info(char* name, int len, int* cus, int64_t* hbm) {
     require_init();
@@ -325,6 +342,7 @@ void Engine::set_index(int i) {
 Engine::Exported Engine::export_vector(fmhip_vec h, hipEvent_t ready) {
     require_init();
     Node* nd = node(h);
+    touch(nd);
     if (!nd->buf) materialize({ nd });
     nd->refs_ext++;
     hip_check(hipEventRecord(ready, stream_), "hipEventRecord(export)");
@@ -411,6 +429,16 @@ void Engine::release(fmhip_vec h) {
     if (--nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
 }
 
+void Engine::drain_late() {
+    std::vector<fmhip_vec> batch;
+    { std::lock_guard<std::mutex> lock(late_mu_); batch.swap(late_); late_count_.store(0, std::memory_order_release); }
+    if (!initialized_) return;
+    for (fmhip_vec h : batch) {
+        Node* nd = owner_of(h) == index_ ? nodes_.get(h) : nullptr;     // (a handle that is not one: nobody is left to tell)
+        if (nd && --nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
+    }
+}
+
 static void check_n(int64_t n) {
     if (n < 0 || n > (int64_t(1) << 31)) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "invalid vector size " + std::to_string(n));
 }
@@ -464,6 +492,7 @@ void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
     Node* nd = node(h);
     if (n != nd->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "read of " + std::to_string(n) + " elements from a vector of " + std::to_string(nd->n));
     if (n > 0 && !dst) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null host pointer");
+    touch(nd);
     if (!nd->buf) materialize({nd});
     const int64_t chunk = int64_t(16) << 20;
     for (int64_t off = 0; off < n; off += chunk) {
@@ -480,8 +509,11 @@ void* Engine::device_ptr(fmhip_vec h) {
     require_init();
     end_step_group();
     Node* nd = node(h);
+    touch(nd);
     if (!nd->buf) materialize({nd});
-    nd->has_moments = false; nd->moments_slot = nullptr; nd->moments_blocked = true;       // the caller may write through the pointer
+    // the caller may write through the pointer: whoever still reads this vector — pending expressions, recipes of deferred values — is computed first
+    if (nd->refs_int > 0) { flush_all(); materialize_deferred(); }
+    nd->has_moments = false; nd->moments_slot = nullptr; nd->moments_blocked = true;
     return nd->buf->ptr;
 }
 
@@ -821,6 +853,8 @@ void Engine::launch(Program* p, int64_t n, const std::vector<RowSpec>& rows, fmh
                           profile_tags_.push_back({ p->n_ops, p->n_in, p->n_out, n_red, batch, used_jit ? 1 : 0, n }); }
         n_launches_++; n_ops_executed_ += (int64_t)p->n_ops * batch;
         algorithmic_bytes_ += 4 * n * (int64_t)(p->n_in + p->n_out) * batch;
+        bytes_written_ += 4 * n * (int64_t)p->n_out * batch;
+        if (!used_jit) n_interpreter_launches_++;
         if (n_red > 0) {                     // the final combine ran inside the same launch (last workgroup of each row)
             if (defer_red_ && !defer_red_->pending && host_moments && red.on_host) {
                 red.pending = true; red.batch = batch; red.n_red = n_red; red.host = host_moments;
@@ -1014,6 +1048,9 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     for (int i = 1; i < n_in; ++i)
         if (ins[i]->n != ins[0]->n)
             throw Error(FMHIP_ERR_SIZE_MISMATCH, "operand sizes differ: " + std::to_string(ins[0]->n) + " vs " + std::to_string(ins[i]->n));
+    // the caller uses these handles again: what the escape policy has learnt about their positions; a value that was left unstored is
+    // computed from its recipe now and stored (once)
+    for (int i = 0; i < n_in; ++i) if (ins[i]->watch || ins[i]->deferred) demand(ins[i]);
     if (fusion && group_steps > 0 && fusion_hold == 0)         // a caller's own hold (or eager mode) leaves nothing to group on its behalf
         for (int i = 0; i < n_in; ++i)
             if (ins[i]->bm_id && (ins[i]->bm_step != group_last_step_ || ins[i]->bm_id != group_bm_id_)) step_boundary(ins[i]);
@@ -1160,16 +1197,18 @@ void Engine::graph_clone(const fmhip_vec* roots, int n_roots, int n_copies, cons
     std::vector<Node*> from((size_t)n_map);
     for (int i = 0; i < n_map; ++i) {
         Node* l = node(leaf_from[i]);
+        touch(l);
         if (l->mark == ep_graph) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "a substituted operand lies inside the graph to be replicated");
         l->mark = ep_leaf; l->tmp_id = i;
         from[(size_t)i] = l;
     }
     std::vector<Node*> root_nodes((size_t)n_roots);
-    for (int r = 0; r < n_roots; ++r) root_nodes[(size_t)r] = node(roots[r]);
+    for (int r = 0; r < n_roots; ++r) { root_nodes[(size_t)r] = node(roots[r]); touch(root_nodes[(size_t)r]); }
     std::vector<Node*> to((size_t)n_map * (size_t)n_copies);
     for (int j = 0; j < n_copies; ++j)
         for (int i = 0; i < n_map; ++i) {
             Node* t = node(leaf_to[(size_t)j * n_map + i]);
+            if (t->deferred) demand(t); else touch(t);
             if (t->n != from[(size_t)i]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "a substituted operand differs in size");
             to[(size_t)j * n_map + i] = t;
         }
@@ -1351,6 +1390,63 @@ void Engine::expand_replicas_below(const std::vector<Node*>& targets) {
     }
 }
 
+// ---------------------------------------------------------------- escape policy (runtime.hpp: policy_state_)
+
+static const bool ESCAPE_POLICY = [] { const char* e = std::getenv("FMHIP_ESCAPE_POLICY"); return !(e && e[0] == '0'); }();     // =0: whatever has a handle is stored (rounds 1–4; A/B measurement)
+
+void Engine::policy_reset() { policy_state_.clear(); ++policy_gen_; }       // (shapes bind again, lazily: their generation no longer matches)
+
+void Engine::policy_bind(ShapePolicy& p, size_t size) {
+    if (p.gen != policy_gen_ || p.size != size) {
+        if (policy_state_.size() + size > (size_t(1) << 28)) policy_reset();                // shapes that never repeat: start again
+        p.base = (uint32_t)policy_state_.size(); p.size = (uint32_t)size; p.gen = policy_gen_;
+        policy_state_.resize(policy_state_.size() + size, (uint8_t)POLICY_NEW);
+        p.decided.assign(size, 0); p.flush = flush_seq_;
+    } else if (p.flush != flush_seq_) { std::fill(p.decided.begin(), p.decided.end(), (uint8_t)0); p.flush = flush_seq_; }
+}
+
+// Is the value at `pos`, whose only claim to storage is a live handle, stored by this flush?  Decided once per position and flush: the
+// members of a launch group must agree on their shape.  optimistic: the component comes from a caller that does not free its temporaries
+// (most internally consumed values carry handles) — a position never seen is then assumed dead.
+bool Engine::policy_store(ShapePolicy& p, size_t pos, bool optimistic) {
+    uint8_t& d = p.decided[pos];
+    if (d) return d == 1;
+    uint8_t& st = policy_state_[p.base + pos];
+    bool store = false;
+    switch (st) {
+    case POLICY_NEW:       if (optimistic) st = POLICY_DEFER; else { st = POLICY_OBSERVING; store = true; } break;
+    case POLICY_OBSERVING: st = POLICY_DEFER; break;                // stored last time, and nobody came for it (touch() would have made it POLICY_STORE)
+    case POLICY_STORE:     store = true; break;
+    default:               break;
+    }
+    d = store ? 1 : 2;
+    return store;
+}
+
+void Engine::defer_node(Node* nd, const ShapePolicy* p, size_t pos) {
+    if (!nd->deferred) {
+        pend_erase(nd);
+        nd->deferred = true;
+        nd->pend_prev = deferred_head_.pend_prev; nd->pend_next = &deferred_head_; deferred_head_.pend_prev->pend_next = nd; deferred_head_.pend_prev = nd;
+        ++n_deferred_; ++n_deferred_total_;
+    }
+    if (p) watch_node(nd, *p, pos);
+}
+
+void Engine::demand(Node* nd) {
+    touch(nd);
+    if (!nd->buf) materialize({ nd });
+}
+
+void Engine::materialize_deferred() {
+    std::vector<int64_t> ids;
+    for (Node* nd = deferred_head_.pend_next; nd != &deferred_head_; nd = nd->pend_next) if (nd->refs_ext > 0) ids.push_back(nd->id);
+    for (int64_t id : ids) {                        // (storing one dismantles its recipe: others may go away with it)
+        Node* nd = nodes_.get(id);
+        if (nd && nd->id == id && !nd->buf && nd->deferred && !nd->discarded) materialize({ nd });
+    }
+}
+
 struct Engine::Dag {
     std::vector<Node*> roots;       // the values asked for
     std::vector<Node*> order;       // pending nodes, operands before users
@@ -1420,11 +1516,38 @@ bool Engine::build_dag(const std::vector<Node*>& roots, Dag& dag) {
     if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
     // outputs: every root, plus every intermediate somebody else still needs (tmp_uses = consumers inside this DAG)
     for (Node* r : roots) if (r->tmp_uses >= 0) { dag.outs.push_back(r); dag.out_ids.push_back(r->tmp_id); r->tmp_uses = -1 - r->tmp_uses; }
-    for (Node* nd : dag.order) {
+    // … an intermediate with a consumer outside this DAG is a fact; one whose only claim is a live handle is the escape policy's decision
+    // (1: stored, 2: a candidate, 3: not stored — deferred —, 4: a candidate the policy stores)
+    const size_t n_ops = dag.order.size();
+    std::vector<char> flag(n_ops, 0);
+    size_t n_cand = 0, interior = 0;
+    for (size_t i = 0; i < n_ops; ++i) {
+        Node* nd = dag.order[i];
         if (nd->tmp_uses < 0) continue;             // already an output (root)
-        if (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) { dag.outs.push_back(nd); dag.out_ids.push_back(nd->tmp_id); }
+        ++interior;
+        if (nd->refs_int > nd->tmp_uses) flag[i] = 1;
+        else if (nd->refs_ext > 0) {
+            if (nd->rep_id || !ESCAPE_POLICY) flag[i] = 1;
+            else if (nd->deferred) flag[i] = 3;
+            else { flag[i] = 2; ++n_cand; }
+        }
     }
+    ShapePolicy* policy = nullptr;
+    if (n_cand) {
+        if (dag_policies_.size() > 65536) { dag_policies_.clear(); }      // (shapes that never repeat)
+        policy = &dag_policies_[dag.sig];                                  // the structural signature: nothing in it says who holds a handle
+        policy_bind(*policy, n_ops);
+        const bool optimistic = n_cand * 2 > interior;
+        for (size_t i = 0; i < n_ops; ++i) if (flag[i] == 2) flag[i] = policy_store(*policy, i, optimistic) ? 4 : 3;
+    }
+    for (size_t i = 0; i < n_ops; ++i) if (flag[i] == 1 || flag[i] == 4) { dag.outs.push_back(dag.order[i]); dag.out_ids.push_back(dag.order[i]->tmp_id); }
     if ((int)dag.outs.size() > FM_MAX_OUT) return false;
+    for (size_t i = 0; i < n_ops; ++i) {
+        Node* nd = dag.order[i];
+        if (flag[i] == 4) watch_node(nd, *policy, i);
+        else if (flag[i] == 3) defer_node(nd, nd->deferred ? nullptr : policy, i);
+        else if (flag[i] == 0 && nd->tmp_uses >= 0) pend_erase(nd);      // lives on as somebody's operand only: no flush starts from it
+    }
     dag.sig.push_back((char)0xff);
     for (int v : dag.out_ids) dag.sig.push_back((char)(v + 1));
     return true;
@@ -1510,14 +1633,12 @@ bool Engine::run_dags(std::vector<Dag>& dags, const double* reduce_shift, fmhip_
     }
     // commit: outputs become materialised leaves; their expressions (and unreferenced intermediates) go away
     for (size_t i = 0; i < dags.size(); ++i)
-        for (size_t k = 0; k < dags[i].outs.size(); ++k) { dags[i].outs[k]->buf = out_bufs[i][k]; pend_erase(dags[i].outs[k]); }
-    for (size_t i = 0; i < dags.size(); ++i)
-        for (size_t k = 0; k < dags[i].outs.size(); ++k) {
-            Node* nd = dags[i].outs[k];
-            nd->refs_int++;                 // keep alive while its expression is dismantled
-            drop_expression(nd);
-            nd->refs_int--;
-        }
+        for (size_t k = 0; k < dags[i].outs.size(); ++k) commit_node(dags[i].outs[k], out_bufs[i][k]);
+    // (all outputs are kept alive until every expression has been dismantled: one that nobody holds — stored for the sake of a launch shape
+    // whose kernel exists, build_big — goes away with its last consumer)
+    for (size_t i = 0; i < dags.size(); ++i) for (Node* nd : dags[i].outs) nd->refs_int++;
+    for (size_t i = 0; i < dags.size(); ++i) for (Node* nd : dags[i].outs) drop_expression(nd);
+    for (size_t i = 0; i < dags.size(); ++i) for (Node* nd : dags[i].outs) { nd->refs_int--; node_maybe_free(nd); }
     return true;
 }
 
@@ -1596,29 +1717,19 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
         }
     }
     if (big.order.size() > 60000) return false;
-    // The signature of a list of nodes: per node its opcode, its operands (positions in the list; leaves by order of discovery) and
-    // whether it is needed outside the component; and its hash, 8 bytes at a time.
-    auto sign = [&](const std::vector<Node*>& order, std::string& sig, std::vector<char>* escapes_out) {
-        // one byte for the math mode, then 8 bytes per node — opcode, three operands of 16 bits, the flag — written as ONE word each and
-        // hashed as they are written (until round 4: eight push_backs per node and a second pass for the hash; ≈ 15 ns per node, a tenth of
-        // the host's time for a caller without hints)
+    // The STRUCTURAL signature of a list of nodes: per node its opcode and its operands (positions in the list; leaves by order of
+    // discovery) as one 8-byte word whose top byte — the flag: is the value stored? — stays zero; and its hash, as it is written (until
+    // round 4 the flag was part of it, so that a shape's identity depended on who held handles when the flush came).
+    auto sign = [&](const std::vector<Node*>& order, std::string& sig) {
         const size_t count = order.size();
         sig.resize(1 + count * 8);
         sig[0] = (char)('0' + math_mode);
         char* p = &sig[1];
-        if (escapes_out) escapes_out->resize(count);
         uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)math_mode;
         for (size_t i = 0; i < count; ++i, p += 8) {
             const Node* nd = order[i];
-            // needed outside the component — unless it is a root whose VALUE the caller has given up (moments only, Node::discard): not an
-            // output of the component then ('m': a shape of its own, its peeled kernels do not store it; launches that cannot take the
-            // moments along — segments — go by the nodes' references and store it all the same)
-            const bool moments_only = nd->discard && nd->refs_int == 0;
-            const bool escapes = !moments_only && (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses);
-            if (escapes_out) (*escapes_out)[i] = escapes ? 1 : 0;
             uint64_t w = (uint64_t)(uint8_t)nd->opcode;
             for (int k = 0; k < 3; ++k) w |= (uint64_t)(uint16_t)(k < nd->n_in ? nd->in[k]->tmp_id + 32768 : 0) << (8 + 16 * k);
-            w |= (uint64_t)(uint8_t)(moments_only ? 'm' : escapes ? 'x' : '.') << 56;
             std::memcpy(p, &w, 8);
             h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32;
         }
@@ -1626,70 +1737,178 @@ bool Engine::build_big(const std::vector<Node*>& roots, BigDag& big) {
     };
     const size_t m = big.order.size();
     for (size_t i = 0; i < m; ++i) big.order[i]->tmp_id = (int)i;
-    // A shape seen before (same walk, same operands, same escapes) is scheduled the way it was then: the schedule below is a function
-    // of the structure up to ties, and any topological order computes the same values — a caller that asks for one expectation after
-    // the other (144 products per objective evaluation, each a graph of 50–250 nodes) pays for the walk and ONE signature, not for
-    // the scheduling pass and a second one (≈ 6 → 3 µs per product, all of it time the device waits).
-    const bool memoise = m <= 4096;                           // (the memo holds 21 bytes per node: not for graphs of tens of thousands of nodes)
-    const uint64_t walk_hash = memoise ? sign(big.order, walk_sig_, nullptr) : 0;
-    auto known = memoise ? schedule_cache_.find(walk_hash) : schedule_cache_.end();
-    if (known != schedule_cache_.end() && known->second.walk_sig == walk_sig_) {
-        const ScheduleMemo& memo = known->second;
-        std::vector<Node*> scheduled(m);
-        for (size_t i = 0; i < m; ++i) { scheduled[i] = big.order[memo.perm[i]]; scheduled[i]->tmp_id = (int)i; }
-        big.order.swap(scheduled);
-        big.escapes = memo.escapes;
-        big.sig = memo.sig;
-        big.hash = memo.hash;
-        return true;
-    }
-    // Schedule: the DFS post-order above is A topological order, but not a good one to cut into launches — it lists a whole
-    // dependency chain (e.g. the running factor sum over all LIBOR components of an Euler step) before the values that merely
-    // consume one link of it, so every link would have to be materialised for a later segment.  List scheduling, consumers
-    // first: emit a ready node, then prefer the nodes it has just made ready (LIFO; ties by creation order).  A value is
-    // consumed as soon as possible after it is produced: short live ranges, few values crossing a cut — two Euler steps
-    // recorded back to back come out component by component, both steps of a component adjacent, and the intermediate state
-    // never touches HBM.  Every op computes the same thing in any topological order: results are unchanged bit for bit.
-    std::vector<uint32_t> perm(m);
-    {
-        std::vector<int> indeg(m, 0), head(m + 1, 0);
-        for (size_t i = 0; i < m; ++i)
-            for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) { indeg[i]++; head[(size_t)c->tmp_id + 1]++; } }
-        for (size_t i = 0; i < m; ++i) head[i + 1] += head[i];
-        std::vector<int> consumers((size_t)head[m]), fill(head.begin(), head.end() - 1);
-        for (size_t i = 0; i < m; ++i)
-            for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) consumers[(size_t)fill[(size_t)c->tmp_id]++] = (int)i; }
-        auto by_id_desc = [&](int a, int b) { return big.order[(size_t)a]->id > big.order[(size_t)b]->id; };
-        std::vector<int> stack_ready;
-        for (size_t i = 0; i < m; ++i) if (indeg[i] == 0) stack_ready.push_back((int)i);
-        std::sort(stack_ready.begin(), stack_ready.end(), by_id_desc);             // oldest node on top
-        std::vector<Node*> scheduled;
-        scheduled.reserve(m);
-        std::vector<int> fresh;
-        while (!stack_ready.empty()) {
-            const int i = stack_ready.back(); stack_ready.pop_back();
-            scheduled.push_back(big.order[(size_t)i]);
-            fresh.clear();
-            for (int q = head[(size_t)i]; q < head[(size_t)i + 1]; ++q) if (--indeg[(size_t)consumers[(size_t)q]] == 0) fresh.push_back(consumers[(size_t)q]);
-            std::sort(fresh.begin(), fresh.end(), by_id_desc);
-            stack_ready.insert(stack_ready.end(), fresh.begin(), fresh.end());
+    // A shape seen before (same walk, same operands) is scheduled the way it was then: the schedule below is a function of the structure
+    // up to ties, and any topological order computes the same values — a caller that asks for one expectation after the other (144
+    // products per objective evaluation, each a graph of 50–250 nodes) pays for the walk and ONE signature, not for the scheduling pass
+    // and a second one (≈ 6 → 3 µs per product, all of it time the device waits).  The memo also carries what the engine has learnt about
+    // the shape's handles (escape policy).
+    static const size_t MEMO_MAX_NODES = 16384;               // (a memo holds ≈ 30 bytes per node)
+    const bool memoise = m <= MEMO_MAX_NODES;
+    ScheduleMemo* memo = nullptr;
+    if (memoise) {
+        const uint64_t walk_hash = sign(big.order, walk_sig_);
+        auto known = schedule_cache_.find(walk_hash);
+        if (known != schedule_cache_.end() && known->second.walk_sig == walk_sig_) {
+            memo = &known->second;
+            std::vector<Node*> scheduled(m);
+            for (size_t i = 0; i < m; ++i) { scheduled[i] = big.order[memo->perm[i]]; scheduled[i]->tmp_id = (int)i; }
+            big.order.swap(scheduled);
+        } else {
+            if (schedule_cache_.size() >= 4096 || schedule_cache_bytes_ > (size_t(128) << 20)) { schedule_cache_.clear(); schedule_cache_bytes_ = 0; policy_reset(); }     // (shapes that never repeat: start again)
+            memo = &schedule_cache_[walk_hash];
+            schedule_cache_bytes_ -= std::min(schedule_cache_bytes_, memo->walk_sig.size() * 3 + memo->perm.size() * 6);       // (the same walk hash again: replaced)
+            *memo = ScheduleMemo();
+            memo->walk_sig = walk_sig_;
         }
-        if (scheduled.size() == m) big.order.swap(scheduled);                      // (always: the pending graph is acyclic)
-        for (size_t i = 0; i < m; ++i) perm[i] = (uint32_t)big.order[i]->tmp_id;     // scheduled position → position in the walk
     }
-    for (size_t i = 0; i < m; ++i) big.order[i]->tmp_id = (int)i;
-    big.hash = sign(big.order, big.sig, &big.escapes);
-    if (!memoise) return true;
-    if (schedule_cache_.size() >= 4096 || schedule_cache_bytes_ > (size_t(64) << 20)) { schedule_cache_.clear(); schedule_cache_bytes_ = 0; }     // (shapes that never repeat: start again)
-    ScheduleMemo& memo = schedule_cache_[walk_hash];
-    schedule_cache_bytes_ -= std::min(schedule_cache_bytes_, memo.walk_sig.size() * 2 + memo.perm.size() * 5);       // (the same walk hash again: replaced)
-    memo.walk_sig = walk_sig_; memo.perm.swap(perm); memo.escapes = big.escapes; memo.sig = big.sig; memo.hash = big.hash;
-    schedule_cache_bytes_ += memo.walk_sig.size() * 2 + memo.perm.size() * 5;
+    if (!memo || memo->perm.empty()) {
+        // Schedule: the DFS post-order above is A topological order, but not a good one to cut into launches — it lists a whole
+        // dependency chain (e.g. the running factor sum over all LIBOR components of an Euler step) before the values that merely
+        // consume one link of it, so every link would have to be materialised for a later segment.  List scheduling, consumers
+        // first: emit a ready node, then prefer the nodes it has just made ready (LIFO; ties by creation order).  A value is
+        // consumed as soon as possible after it is produced: short live ranges, few values crossing a cut — two Euler steps
+        // recorded back to back come out component by component, both steps of a component adjacent, and the intermediate state
+        // never touches HBM.  Every op computes the same thing in any topological order: results are unchanged bit for bit.
+        std::vector<uint32_t> perm(m);
+        {
+            std::vector<int> indeg(m, 0), head(m + 1, 0);
+            for (size_t i = 0; i < m; ++i)
+                for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) { indeg[i]++; head[(size_t)c->tmp_id + 1]++; } }
+            for (size_t i = 0; i < m; ++i) head[i + 1] += head[i];
+            std::vector<int> consumers((size_t)head[m]), fill(head.begin(), head.end() - 1);
+            for (size_t i = 0; i < m; ++i)
+                for (int k = 0; k < big.order[i]->n_in; ++k) { Node* c = big.order[i]->in[k]; if (!c->buf) consumers[(size_t)fill[(size_t)c->tmp_id]++] = (int)i; }
+            auto by_id_desc = [&](int a, int b) { return big.order[(size_t)a]->id > big.order[(size_t)b]->id; };
+            std::vector<int> stack_ready;
+            for (size_t i = 0; i < m; ++i) if (indeg[i] == 0) stack_ready.push_back((int)i);
+            std::sort(stack_ready.begin(), stack_ready.end(), by_id_desc);             // oldest node on top
+            std::vector<Node*> scheduled;
+            scheduled.reserve(m);
+            std::vector<int> fresh;
+            while (!stack_ready.empty()) {
+                const int i = stack_ready.back(); stack_ready.pop_back();
+                scheduled.push_back(big.order[(size_t)i]);
+                fresh.clear();
+                for (int q = head[(size_t)i]; q < head[(size_t)i + 1]; ++q) if (--indeg[(size_t)consumers[(size_t)q]] == 0) fresh.push_back(consumers[(size_t)q]);
+                std::sort(fresh.begin(), fresh.end(), by_id_desc);
+                stack_ready.insert(stack_ready.end(), fresh.begin(), fresh.end());
+            }
+            if (scheduled.size() == m) big.order.swap(scheduled);                      // (always: the pending graph is acyclic)
+            for (size_t i = 0; i < m; ++i) perm[i] = (uint32_t)big.order[i]->tmp_id;     // scheduled position → position in the walk
+        }
+        for (size_t i = 0; i < m; ++i) big.order[i]->tmp_id = (int)i;
+        if (memo) {
+            memo->perm.swap(perm);
+            memo->sched_hash = sign(big.order, memo->sched_sig);
+            schedule_cache_bytes_ += memo->walk_sig.size() * 3 + memo->perm.size() * 6;
+        }
+    }
+    // Which values are stored.  A consumer outside the component, or being a root of this walk, is a fact; a value whose only claim is a
+    // live handle is the escape policy's decision ('?' → 'X' stored and watched / 'D' deferred); 'd': deferred earlier, stays so.
+    std::vector<char> flags(m);
+    size_t n_cand = 0, interior = 0;
+    for (size_t i = 0; i < m; ++i) {
+        const Node* nd = big.order[i];
+        // (a root whose VALUE the caller has given up — moments only, Node::discard — is not an output of the component: 'm', a shape of
+        // its own, its peeled kernels do not store it; launches that cannot take the moments along — segments — store it all the same)
+        char f = '.';
+        if (nd->discard && nd->refs_int == 0) f = 'm';
+        else if (nd->refs_int > nd->tmp_uses) f = 'x';
+        else if (nd->refs_ext > 0) {
+            if (nd->tmp_uses == 0 || nd->rep_id || !memo || !ESCAPE_POLICY) f = 'x';
+            else if (nd->deferred) f = 'd';
+            else { f = '?'; ++n_cand; }
+        }
+        interior += nd->tmp_uses > 0 ? 1 : 0;
+        flags[i] = f;
+    }
+    const std::vector<char> facts = flags;                     // 'x' / 'm' here are facts; '?' and 'd' the policy's to decide, '.' nobody's
+    if (n_cand) {
+        policy_bind(memo->policy, m);
+        const bool optimistic = n_cand * 2 > interior;
+        for (size_t i = 0; i < m; ++i) if (flags[i] == '?') flags[i] = policy_store(memo->policy, i, optimistic) ? 'x' : '.';
+    }
+    for (size_t i = 0; i < m; ++i) if (flags[i] == 'd') flags[i] = '.';
+    // the shape's full signature and hash: the structure with the flags in the top byte of every word
+    auto finish = [&](const std::string& structural, uint64_t structural_hash, const std::vector<char>& fl, std::string& sig, uint64_t& hash) {
+        sig = structural;
+        uint64_t h = structural_hash;
+        for (size_t i = 0; i < m; ++i) { sig[1 + i * 8 + 7] = fl[i]; h = (h ^ ((uint64_t)(uint8_t)fl[i] + (i << 8))) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+        hash = h;
+    };
+    if (memo) {
+        // The variants of this shape — the same structure, other values stored — the engine has used: the escape policy moves a shape
+        // through a few of them while it learns (stored for observation → left unstored → stored after all), and each needs its own loop
+        // kernel.  A variant whose kernel is still being compiled does not run as segments on the interpreter meanwhile: the launch goes
+        // through the variant used last whose kernel exists, as long as that one stores every value somebody outside the component needs
+        // (the facts) — a value stored without need costs a write, one left unstored against the policy's wish is computed from its recipe
+        // if somebody asks (and watched all the same).  The wanted variant's kernel is asked for now, and used once it is there.
+        std::vector<ScheduleMemo::Variant>& vs = memo->variants;
+        size_t at = vs.size();
+        for (size_t v = 0; v < vs.size(); ++v) if (vs[v].flags == flags) { at = v; break; }
+        if (at == vs.size()) {
+            if (vs.size() >= 6) { vs.erase(vs.begin() + 1, vs.begin() + 2); at = vs.size(); }     // (the oldest but the first — the one that stores everything it was asked to at first sight)
+            vs.emplace_back();
+            vs[at].flags = flags;
+            finish(memo->sched_sig, memo->sched_hash, flags, vs[at].sig, vs[at].hash);
+            schedule_cache_bytes_ += vs[at].sig.size() + m;
+        }
+        size_t use = at;
+        static const bool HYSTERESIS = [] { const char* e = std::getenv("FMHIP_VARIANT_HYSTERESIS"); return !(e && e[0] == '0'); }();
+        if (HYSTERESIS && ESCAPE_POLICY && vs.size() > 1 && jit_mode == FMHIP_JIT_AUTO) {
+            auto plan_of = [&](const ScheduleMemo::Variant& v) -> BigPlan* { auto it = plan_cache_.find(v.hash); return it != plan_cache_.end() && it->second.sig == v.sig ? &it->second : nullptr; };
+            auto kernel_there = [&](const BigPlan& p) {
+                if (!p.rolled.present) return true;
+                const std::shared_ptr<JitSlot>& slot = p.rolled.peeled.present ? p.rolled.peeled.jit : p.rolled.jit;
+                return slot && slot->state.load(std::memory_order_acquire) != JitSlot::QUEUED;
+            };
+            BigPlan* wanted = plan_of(vs[at]);
+            if (!wanted && plan_cache_.count(vs[at].hash) == 0) {          // never planned: its loop is looked for and its kernels are asked for, nothing runs
+                big.escapes.resize(m);
+                for (size_t i = 0; i < m; ++i) big.escapes[i] = flags[i] == 'x' ? 1 : 0;
+                BigPlan np;
+                plan_loop(np, big);
+                np.sig = vs[at].sig; np.discards_root = big.discard_root; np.segs_missing = true;
+                wanted = &(plan_cache_[vs[at].hash] = std::move(np));
+            }
+            if (wanted && !kernel_there(*wanted)) {
+                for (size_t back = memo->last_variant < vs.size() ? memo->last_variant : 0, tried = 0; tried < vs.size(); ++tried, back = (back + 1) % vs.size()) {
+                    if (back == at) continue;
+                    const ScheduleMemo::Variant& v = vs[back];
+                    bool legal = true;
+                    for (size_t i = 0; i < m && legal; ++i) legal = (facts[i] != 'x' || v.flags[i] == 'x') && ((facts[i] == 'm') == (v.flags[i] == 'm'));
+                    if (!legal) continue;
+                    const BigPlan* p = plan_of(v);
+                    if (p && kernel_there(*p)) { use = back; break; }
+                }
+            }
+        }
+        memo->last_variant = use;
+        if (use != at) flags = vs[use].flags;
+        big.sig = vs[use].sig; big.hash = vs[use].hash;
+    } else {
+        std::string structural;
+        const uint64_t h = sign(big.order, structural);
+        finish(structural, h, flags, big.sig, big.hash);
+    }
+    // the nodes learn what has been decided: a handle whose value is stored is watched (a use makes its position a stored one for good), one
+    // whose value is not is deferred; whatever lives on as somebody's operand only leaves the pending list — no flush starts from it
+    big.escapes.resize(m);
+    for (size_t i = 0; i < m; ++i) {
+        Node* nd = big.order[i];
+        const bool policy_position = facts[i] == '?' || facts[i] == 'd';
+        if (flags[i] == 'x') { if (policy_position && facts[i] == '?') watch_node(nd, memo->policy, i); }
+        else if (flags[i] == '.') {
+            if (nd->refs_ext > 0 && nd->tmp_uses > 0 && nd->refs_int <= nd->tmp_uses) defer_node(nd, facts[i] == '?' ? &memo->policy : nullptr, i);
+            else if (!nd->deferred) pend_erase(nd);
+        }
+        big.escapes[i] = flags[i] == 'x' ? 1 : 0;
+    }
     return true;
 }
 
-// The launchable DAG of order[s, e): inputs in first-use order, outputs = values needed outside the segment.
-bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag) {
+// uses: per position of the component's order, the consumers INSIDE the component (structural: equal for all members of a group)
+bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag, const std::vector<int32_t>& uses) {
     const uint64_t ep = ++epoch_, ep_leaf = ++epoch_;          // mark == ep: produced inside the segment; == ep_leaf: registered input
     dag = Dag();
     for (size_t i = s; i < e; ++i) { Node* nd = big.order[i]; nd->mark = ep; nd->tmp_uses = 0; }
@@ -1723,7 +1942,9 @@ bool Engine::segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag) {
     if (dag.scalars.empty()) dag.scalars.push_back(0.0f);
     for (size_t i = s; i < e; ++i) {
         Node* nd = big.order[i];
-        if (nd->refs_ext > 0 || nd->refs_int > nd->tmp_uses) { dag.outs.push_back(nd); dag.out_ids.push_back(nd->tmp_id); }   // a consumer outside [s, e)
+        // an output of the component (build_big's decision — a handle alone does not make one), a consumer in a later segment, or the
+        // component's root (also where its value has been given up: a segment cannot take the moments along, it stores it all the same)
+        if (big.escapes[i] || uses[i] > nd->tmp_uses || (uses[i] == 0 && nd->refs_ext > 0)) { dag.outs.push_back(nd); dag.out_ids.push_back(nd->tmp_id); }
     }
     if (dag.outs.empty() || (int)dag.outs.size() > FM_MAX_OUT) return false;
     dag.roots = dag.outs;
@@ -1740,8 +1961,8 @@ void Engine::commit_described(BigDag& big, size_t pos, Buffer* b) {
     if (root < 0) return;
     const ReplicaGroup* g = big.view->g;
     Node* c = g->copy_roots[(size_t)big.copy * g->n_roots + root];
-    c->buf = b; b->refs++;
-    pend_erase(c);
+    b->refs++;
+    commit_node(c, b);
 }
 
 // One segment of a planned component for every member of a group: gather the row blocks by index, launch, commit.
@@ -1776,19 +1997,18 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
         for (size_t k = 0; k < seg.out.size(); ++k) {
             Buffer* b = out_bufs[c * seg.out.size() + k];
             if (big.described()) commit_described(big, (size_t)seg.out[k], b);
-            else { Node* nd = big.order[(size_t)seg.out[k]]; nd->buf = b; pend_erase(nd); }
+            else commit_node(big.order[(size_t)seg.out[k]], b);
         }
     }
+    std::vector<Node*> done;
     for (size_t c = 0; c < count; ++c) {
         BigDag& big = group[first + c];
         if (big.described()) continue;
-        for (size_t k = 0; k < seg.out.size(); ++k) {
-            Node* nd = big.order[(size_t)seg.out[k]];
-            nd->refs_int++;                 // keep alive while its expression is dismantled
-            drop_expression(nd);
-            nd->refs_int--;
-        }
+        for (size_t k = 0; k < seg.out.size(); ++k) done.push_back(big.order[(size_t)seg.out[k]]);
     }
+    for (Node* nd : done) nd->refs_int++;       // keep alive while the expressions are dismantled
+    for (Node* nd : done) drop_expression(nd);
+    for (Node* nd : done) { nd->refs_int--; node_maybe_free(nd); }
 }
 
 // ---------------------------------------------------------------- rolled loops
@@ -1824,11 +2044,14 @@ bool Engine::detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 
         }
     }
     auto is_global = [&](size_t l) { return last_leaf_use[l] - first_use[l] >= GLOBAL_SPAN; };
-    // position-independent signature of every node: what it does, how far back its operands are, whether it escapes
+    // position-independent signature of every node: what it does and how far back its operands are.  NOT whether it is stored: an
+    // iteration that stores a value the others only pass on (a state one product reads, a handle the escape policy keeps for one
+    // component and not for the next) is the same iteration — the loop stores that position in EVERY iteration (out_needed below is the
+    // union over the iterations): a few vectors more written, against a stretch that would not roll at all.
     std::vector<uint64_t> sig(n);
     for (size_t i = 0; i < n; ++i) {
         const Node* nd = g.order[i];
-        uint64_t h = mix64(0x1234, (uint64_t)nd->opcode * 8 + (uint64_t)nd->n_in * 2 + (g.escapes[i] ? 1 : 0));
+        uint64_t h = mix64(0x1234, (uint64_t)nd->opcode * 8 + (uint64_t)nd->n_in * 2);
         for (int k = 0; k < nd->n_in; ++k) {
             const int32_t o = operand[i][(size_t)k];
             if (o >= 0) h = mix64(h, 0x100000000ull + (uint64_t)((int64_t)i - o));
@@ -2100,6 +2323,7 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             n_launches_++; n_jit_launches_++; n_rolled_launches_++;
             n_ops_executed_ += (int64_t)(R * P) * (int64_t)count;
             algorithmic_bytes_ += 4 * n * (int64_t)(G + CI + CO + R * (LI + LO)) * (int64_t)count;
+            bytes_written_ += 4 * n * (int64_t)(CO + R * LO) * (int64_t)count;
         }
     } catch (...) { for (Buffer* b : out_bufs) buffer_unref(b); throw; }
     // commit (as run_dags): outputs become materialised vectors; their expressions (and the inner values) go away
@@ -2111,13 +2335,17 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
         auto commit = [&](size_t pos) {
             Buffer* b = out_bufs[k++];
             if (big.described()) commit_described(big, pos, b);
-            else { Node* nd = big.order[pos]; nd->buf = b; pend_erase(nd); outs.push_back(nd); }
+            else { Node* nd = big.order[pos]; commit_node(nd, b); outs.push_back(nd); }
         };
         for (size_t r = 0; r < R; ++r)
             for (size_t m = 0; m < LO; ++m) commit(ro.begin + r * P + ro.out_pos[m]);
         for (size_t m = 0; m < CO; ++m) commit(ro.begin + (R - 1) * P + ro.final_pos[m]);
     }
-    for (Node* nd : outs) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
+    // (a stored value nobody holds — a position the loop stores in every iteration for the sake of one — goes away with its last consumer:
+    // all of them are kept alive until every expression has been dismantled)
+    for (Node* nd : outs) nd->refs_int++;
+    for (Node* nd : outs) drop_expression(nd);
+    for (Node* nd : outs) { nd->refs_int--; node_maybe_free(nd); }
 }
 
 // The whole component of every member of a group as ONE launch of its peeled kernel (plan_peel): row tables by index, launch, commit.
@@ -2201,6 +2429,7 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
                 n_launches_++; n_jit_launches_++; n_rolled_launches_++;
                 n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
                 algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
+                bytes_written_ += 4 * n * (int64_t)stored * (int64_t)count;
                 if (rr) {
                     rr->done = true;
                     if (count == 1 && defer_red_ && !defer_red_->pending && rr->host_out && red.on_host) {
@@ -2218,9 +2447,11 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
     for (Out& o : outs) {
         BigDag& big = group[o.member];
         if (big.described()) commit_described(big, o.pos, o.buf);
-        else { Node* nd = big.order[o.pos]; nd->buf = o.buf; pend_erase(nd); done.push_back(nd); }
+        else { Node* nd = big.order[o.pos]; commit_node(nd, o.buf); done.push_back(nd); }
     }
-    for (Node* nd : done) { nd->refs_int++; drop_expression(nd); nd->refs_int--; }
+    for (Node* nd : done) nd->refs_int++;
+    for (Node* nd : done) drop_expression(nd);
+    for (Node* nd : done) { nd->refs_int--; node_maybe_free(nd); }
 }
 
 // A component shape with a plan, for every member of a group: segment by segment (the rolled stretch as one launch once its kernel
@@ -2313,6 +2544,17 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
             }
         }
     }
+    if (plan.segs_missing) {
+        // this shape has never run as segments: the members with nodes take the general path now, which writes the cuts into the plan
+        std::vector<BigDag> described, with_nodes;
+        for (BigDag& b : group) (b.described() ? described : with_nodes).push_back(std::move(b));
+        if (with_nodes.empty()) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "a group of copies without their original");
+        plan_segments(plan, with_nodes);
+        plan.segs_missing = false;
+        for (BigPlan::Seg& seg : plan.segs) seg.prog->refs++;              // the plan holds its programs (pool_purge drops both caches together)
+        if (!described.empty()) run_plan(plan, described);
+        return;
+    }
     bool any_described = false;
     for (const BigDag& b : group) any_described |= b.described();
     auto release_temps = [&](const std::vector<int32_t>& positions) {
@@ -2361,50 +2603,22 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
     }
 }
 
-void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
-    HostTimer timer(HostProfile::RUN_BIG);
-    BigDag& g0 = group[0];
-    const size_t n_ops = g0.order.size();
+// The general path: the members WITH nodes of a group whose shape has no segments yet are cut into launches (longest segment that fits
+// one launch, again and again; cuts forced at the ends of the loop plan.rolled describes, so that either form can run between them), run
+// segment by segment, and the cuts are written into the plan.
+void Engine::plan_segments(BigPlan& plan, std::vector<BigDag>& group) {
+    const size_t n_ops = group[0].order.size();
     const size_t max_batch = 1024;
-    auto planned = plan_cache_.find(g0.hash);
-    if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
-    const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
-    if (planned != plan_cache_.end()) { run_plan(planned->second, group, rr); return; }
-    // Members without nodes (copies that exist as a description) cannot take the general path below, which works on nodes: they
-    // follow through the plan it writes down.
-    std::vector<BigDag> described;
-    {
-        std::vector<BigDag> with_nodes;
-        for (BigDag& b : group) (b.described() ? described : with_nodes).push_back(std::move(b));
-        group.swap(with_nodes);
-    }
-    // First component of this shape: find the cuts (longest segment that fits one launch, again and again), run it through the
-    // general path, and write the plan down.  Node -> index in g0 for the plan (segment_dag reuses the nodes' scratch fields).
+    // Node -> index in group[0] for the plan (segment_dag reuses the nodes' scratch fields)
     std::unordered_map<const Node*, int32_t> index_of;
     index_of.reserve(n_ops + group[0].leaves.size());
     for (size_t i = 0; i < n_ops; ++i) index_of[group[0].order[i]] = (int32_t)i;
     for (size_t i = 0; i < group[0].leaves.size(); ++i) index_of[group[0].leaves[i]] = -1 - (int32_t)i;
-    BigPlan plan;
-    // A periodic stretch of the order becomes a rolled loop (one launch) as soon as its kernel is compiled; the segments cut
-    // below remain its fallback, with cuts forced at the loop's ends so that either form can run between them.
-    static const bool ROLL = [] { const char* e = std::getenv("FMHIP_ROLL"); return !(e && e[0] == '0'); }();
+    std::vector<int32_t> uses(n_ops, 0);                    // consumers inside the component, per position (before anything runs)
+    for (size_t i = 0; i < n_ops; ++i)
+        for (int k = 0; k < group[0].order[i]->n_in; ++k) { const int32_t o = index_of.at(group[0].order[i]->in[k]); if (o >= 0) uses[(size_t)o]++; }
     size_t zone_begin = n_ops, zone_end = n_ops;
-    if (ROLL) {
-        std::vector<std::array<int32_t, 3>> operand(n_ops);
-        for (size_t i = 0; i < n_ops; ++i)
-            for (int k = 0; k < group[0].order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(group[0].order[i]->in[k]);
-        std::string source; int elems = 0;
-        RolledBody body;
-        if (detect_loop(group[0], operand, plan.rolled, &source, &elems, &body)) {
-            if (plan_peel(group[0], operand, plan.rolled, body) && jit_mode != FMHIP_JIT_OFF)
-                plan.rolled.peeled.jit = jit().request_source(plan.rolled.peeled.source, plan.rolled.peeled.elems, jit_mode == FMHIP_JIT_SYNC);
-            if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
-            plan.rolled.present = true;
-            plan.rolled.source = source; plan.rolled.elems = elems;
-            if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit().request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
-            zone_begin = plan.rolled.begin; zone_end = zone_begin + (size_t)plan.rolled.period * plan.rolled.iterations;
-        }
-    }
+    if (plan.rolled.present) { zone_begin = plan.rolled.begin; zone_end = zone_begin + (size_t)plan.rolled.period * plan.rolled.iterations; }
     size_t s = 0;
     while (s < n_ops) {
         size_t e = 0;
@@ -2415,12 +2629,12 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
             std::vector<size_t> cheap;
             for (size_t cand = s + 1; cand <= limit && cand - s <= (size_t)FM_MAX_OPS; ++cand) {
                 Dag d;
-                if (segment_dag(group[0], s, cand, d)) cheap.push_back(cand);
+                if (segment_dag(group[0], s, cand, d, uses)) cheap.push_back(cand);
                 else if ((int)d.leaves.size() > FM_MAX_IN) break;
             }
             for (size_t k = cheap.size(); k-- > 0 && e == 0;) {
                 Dag d;
-                segment_dag(group[0], s, cheap[k], d);
+                segment_dag(group[0], s, cheap[k], d, uses);
                 if (!program_cache_.count(d.sig)) {
                     try { program_cache_[d.sig] = compile(d.ops, (int)d.leaves.size(), d.out_ids, {}, nullptr, false); }
                     catch (const Error& err) { if (err.code == FMHIP_ERR_PROGRAM_LIMIT) continue; throw; }
@@ -2431,7 +2645,7 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
         }
         std::vector<Dag> dags(group.size());
         for (size_t c = 0; c < group.size(); ++c)
-            if (!segment_dag(group[c], s, e, dags[c])) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "inconsistent segment of a split component");
+            if (!segment_dag(group[c], s, e, dags[c], uses)) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "inconsistent segment of a split component");
         {
             BigPlan::Seg seg;
             seg.prog = program_cache_.at(dags[0].sig);
@@ -2454,13 +2668,64 @@ void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
         for (size_t k = 0; k < plan.segs.size(); ++k) for (int32_t i : plan.segs[k].in) if (i >= 0) last_reader[i] = k;
         for (const auto& kv : last_reader) plan.segs[kv.second].free_after.push_back(kv.first);
     }
-    if (collision) { if (!described.empty()) run_plan(plan, described); return; }
-    for (BigPlan::Seg& seg : plan.segs) seg.prog->refs++;              // the plan holds its programs (pool_purge drops both caches together)
-    plan.sig = group[0].sig;
-    plan.discards_root = group[0].discard_root;
-    const uint64_t key = group[0].hash;
-    plan_cache_[key] = std::move(plan);
-    if (!described.empty()) run_plan(plan_cache_[key], described);
+}
+
+// The loop of a component shape (detect_loop) and its peeled form (plan_peel), their kernels asked of the specialised tier; nothing runs.
+void Engine::plan_loop(BigPlan& plan, const BigDag& g) {
+    static const bool ROLL = [] { const char* e = std::getenv("FMHIP_ROLL"); return !(e && e[0] == '0'); }();
+    if (!ROLL) return;
+    const size_t n_ops = g.order.size();
+    std::vector<std::array<int32_t, 3>> operand(n_ops);      // (build_big left every node's position, resp. -1 - leaf number, in tmp_id)
+    std::unordered_map<const Node*, int32_t> index_of;
+    index_of.reserve(n_ops + g.leaves.size());
+    for (size_t i = 0; i < n_ops; ++i) index_of[g.order[i]] = (int32_t)i;
+    for (size_t i = 0; i < g.leaves.size(); ++i) index_of[g.leaves[i]] = -1 - (int32_t)i;
+    for (size_t i = 0; i < n_ops; ++i)
+        for (int k = 0; k < g.order[i]->n_in; ++k) operand[i][(size_t)k] = index_of.at(g.order[i]->in[k]);
+    std::string source; int elems = 0;
+    RolledBody body;
+    if (!detect_loop(g, operand, plan.rolled, &source, &elems, &body)) return;
+    if (plan_peel(g, operand, plan.rolled, body) && jit_mode != FMHIP_JIT_OFF)
+        plan.rolled.peeled.jit = jit().request_source(plan.rolled.peeled.source, plan.rolled.peeled.elems, jit_mode == FMHIP_JIT_SYNC);
+    if (const char* dump = std::getenv("FMHIP_ROLL_DUMP")) { if (FILE* f = std::fopen(dump, "a")) { std::fputs(source.c_str(), f); std::fputs("\n// ----\n", f); std::fclose(f); } }
+    plan.rolled.present = true;
+    plan.rolled.source = source; plan.rolled.elems = elems;
+    if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit().request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
+}
+
+void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
+    HostTimer timer(HostProfile::RUN_BIG);
+    BigDag& g0 = group[0];
+    auto planned = plan_cache_.find(g0.hash);
+    if (planned != plan_cache_.end() && planned->second.sig != g0.sig) planned = plan_cache_.end();       // hash collision: general path, nothing cached
+    const bool collision = planned == plan_cache_.end() && plan_cache_.count(g0.hash) != 0;
+    if (planned != plan_cache_.end()) { run_plan(planned->second, group, rr); return; }
+    // First component of this shape.  Its loop, if it has one, is found first: a periodic stretch of the order becomes a rolled loop (one
+    // launch) as soon as its kernel exists; segments remain its fallback.
+    BigPlan plan;
+    size_t first_with_nodes = 0;
+    while (first_with_nodes < group.size() && group[first_with_nodes].described()) ++first_with_nodes;
+    if (first_with_nodes == group.size()) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "a group of copies without their original");
+    plan_loop(plan, group[first_with_nodes]);
+    plan.sig = g0.sig;
+    plan.discards_root = g0.discard_root;
+    plan.segs_missing = true;
+    if (collision) {                                        // (practically never) nothing is cached: segments for the members with nodes, the plan they leave for the copies
+        std::vector<BigDag> described, with_nodes;
+        for (BigDag& b : group) (b.described() ? described : with_nodes).push_back(std::move(b));
+        plan_segments(plan, with_nodes);
+        plan.segs_missing = false;
+        if (!described.empty()) run_plan(plan, described);
+        return;
+    }
+    // The plan is written down WITHOUT its segments: where the whole component is one launch of a kernel that exists already (the peeled
+    // form, from the code-object caches or the build-time pack) nothing else is ever needed; run_plan cuts the segments — by running the
+    // component through the general path — the first time that launch is not available (until round 5 every shape's first occurrence ran as
+    // segments on the interpreter, whatever kernels existed: a tenth of a second per calibration, and again for every variant of a shape
+    // the escape policy moves through).
+    BigPlan& cached = plan_cache_[g0.hash];
+    cached = std::move(plan);
+    run_plan(cached, group, rr);
 }
 
 bool Engine::try_fused(const std::vector<Node*>& roots) {
@@ -2470,6 +2735,7 @@ bool Engine::try_fused(const std::vector<Node*>& roots) {
 }
 
 void Engine::materialize(const std::vector<Node*>& targets) {
+    ++flush_seq_;
     for (Node* t : targets)
         if (t->discarded && !t->buf) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "the value of this vector does not exist: it was given up (fmhip_vec_give_up_values: only its moments were taken), or lost in a launch that failed");
     expand_replicas_below(targets);                 // a single expression is executed, not everything pending: descriptions of copies it touches become nodes first
@@ -2489,6 +2755,8 @@ void Engine::materialize(const std::vector<Node*>& targets) {
 void Engine::flush_all() {
     HostTimer timer(HostProfile::FLUSH);
     require_init();
+    if (has_late()) drain_late();
+    ++flush_seq_;
     for (int round = 0; round < 1000000; ++round) {
         std::unique_ptr<HostTimer> t_components(new HostTimer(HostProfile::FLUSH_COMPONENTS));
         std::vector<Node*> roots;                   // live pending vectors nobody pending depends on
@@ -2690,6 +2958,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     };
     if (cached()) return;
     if (nd->moments_slot && shift == 0.0 && host_out && !dev_out && slot_wait(nd) && cached()) return;
+    ++flush_seq_;
     // One expectation is asked for while much else is pending (a caller that records the payoffs of all its products and then takes
     // their averages one by one — 144 per objective evaluation of the LIBOR market model calibration): everything pending runs NOW,
     // components of equal shape as rows of the same launches, and those launches take the moments of their roots along.  The other
@@ -2703,6 +2972,7 @@ void Engine::reduce(fmhip_vec h, double shift, fmhip_moments* host_out, void* de
     }
     if (cached()) return;
     if (nd->moments_slot && shift == 0.0 && host_out && !dev_out && slot_wait(nd) && cached()) return;
+    touch(nd);
     RedLaunch deferred;
     struct Defer {                      // the launch that takes the moments hands its wait to this scope (RedLaunch::pending)
         Engine* e; RedLaunch* r; RedLaunch* hand_over;
@@ -2958,7 +3228,7 @@ void Engine::reduce_batch(const fmhip_vec* hs, int count, const double* shifts, 
     for (int i = 1; i < count; ++i)
         if (nds[(size_t)i]->n != nds[0]->n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "batched reduction over vectors of different size");
     bool pending = false;
-    for (Node* nd : nds) pending |= !nd->buf;
+    for (Node* nd : nds) { touch(nd); pending |= !nd->buf; }
     if (pending) flush_all();                                   // one batched flush instead of one launch per vector
     for (Node* nd : nds) if (!nd->buf) materialize({ nd });
     Program* prog = reduce_program();
@@ -3030,7 +3300,7 @@ void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fm
             if (nd->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program inputs differ in size");
             in_nodes[(size_t)b * p->n_in + k] = nd;
         }
-    for (Node* nd : in_nodes) if (!nd->buf) materialize({ nd });
+    for (Node* nd : in_nodes) { touch(nd); if (!nd->buf) materialize({ nd }); }
     std::vector<Buffer*> fresh;
     std::vector<Node*> out_nodes;
     try {
@@ -3040,7 +3310,9 @@ void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fm
                 if (into) {
                     Node* o = node(outputs[(size_t)b * p->n_out + k]);
                     if (o->n != n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "program output differs in size");
+                    touch(o);
                     if (!o->buf) materialize({ o });
+                    if (o->refs_int > 0) { flush_all(); materialize_deferred(); }      // overwritten in place: whoever still reads the old contents (pending expressions, recipes of deferred values) is computed first
                     o->has_moments = false; o->moments_slot = nullptr;      // overwritten
                     rows[b].out.push_back(o->buf->ptr);
                 } else {
@@ -3097,6 +3369,7 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
                 if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
                                   profile_tags_.push_back({ 0, 0, (int)ns, 0, 1, 3, n_paths }); }
                 algorithmic_bytes_ += 4 * n_paths * ns;
+                bytes_written_ += 4 * n_paths * ns;
                 n_launches_++;
             }
         }
@@ -3120,20 +3393,37 @@ void Engine::bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_pat
 
 // ---------------------------------------------------------------- pool entry points
 
-void Engine::pool_clean() { require_init(); hip_check(hipStreamSynchronize(stream_), "sync"); pool_.purge(); }
+// (values that were left unstored are computed and stored first: their recipes may be all that keeps other vectors alive)
+void Engine::pool_clean() { require_init(); if (has_late()) drain_late(); materialize_deferred(); hip_check(hipStreamSynchronize(stream_), "sync"); pool_.purge(); }
 
 void Engine::pool_purge() {
     require_init();
+    if (has_late()) drain_late();
     hip_check(hipStreamSynchronize(stream_), "sync");
     pool_.purge();
     for (auto& kv : plan_cache_) for (BigPlan::Seg& seg : kv.second.segs) { if (--seg.prog->refs == 0) delete seg.prog; delete seg.prog_red; }
     plan_cache_.clear();
     for (auto it = program_cache_.begin(); it != program_cache_.end();) { if (--it->second->refs == 0) delete it->second; it = program_cache_.erase(it); }
+    schedule_cache_.clear(); schedule_cache_bytes_ = 0; dag_policies_.clear(); policy_reset();      // … and what was learnt about the shapes' handles
+}
+
+void Engine::engine_stats(fmhip_engine_stats_t* out) {
+    require_init();
+    if (!out) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null stats pointer");
+    if (has_late()) drain_late();
+    std::memset(out, 0, sizeof *out);
+    out->size = (int64_t)sizeof *out;
+    out->kernel_launches = n_launches_; out->specialised_launches = n_jit_launches_; out->interpreter_launches = n_interpreter_launches_;
+    out->algorithmic_bytes = algorithmic_bytes_; out->algorithmic_bytes_written = bytes_written_;
+    out->values_deferred = n_deferred_total_; out->values_deferred_now = (int64_t)n_deferred_; out->values_demanded = n_demanded_;
+    out->pending_operations = (int64_t)n_pending_;
+    out->peak_bytes_reserved = pool_.peak_reserved;
 }
 
 void Engine::pool_stats(fmhip_pool_stats_t* out) {
     require_init();
     if (!out) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null stats pointer");
+    if (has_late()) drain_late();
     size_t fr = 0, tot = 0;
     hip_check(hipMemGetInfo(&fr, &tot), "hipMemGetInfo");
     out->bytes_reserved = pool_.reserved; out->bytes_in_use = pool_.in_use; out->bytes_cached = pool_.cached;

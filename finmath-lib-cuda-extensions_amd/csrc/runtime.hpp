@@ -42,7 +42,7 @@ public:
     void* alloc(size_t bytes, size_t* cap_out);       // throws Error(OOM)
     void  release(void* p, size_t cap);               // back to the free list (stream-ordered reuse)
     void  purge();                                    // hipFree everything cached
-    int64_t reserved = 0, in_use = 0, cached = 0, hits = 0, misses = 0;
+    int64_t reserved = 0, in_use = 0, cached = 0, hits = 0, misses = 0, peak_reserved = 0;
 private:
     struct Slab { void* base; size_t cap; size_t blocks; };
     std::unordered_map<size_t, std::vector<void*>> free_;
@@ -82,6 +82,13 @@ struct Node {
     // (a root nobody else references); `discarded`: a flush took the moments in the launch that computed the value and did NOT store
     // it — the node stays without storage, is not a root of later flushes, and reading it is an error.
     bool    discard = false, discarded = false;
+    // DEFERRED: a launch computed this value in registers for its consumers and did not store it, although the caller still holds a
+    // handle (Engine: escape policy).  The node keeps its expression — the recipe: references on its operands —, is on the engine's
+    // deferred list instead of the pending list (no flush executes it on its own account), and is computed and stored once if the
+    // handle is ever used again (an operand of a later call, a read, an expectation).  The release that eventually arrives frees the recipe.
+    bool    deferred = false;
+    // escape policy: the slot (index + 1 into Engine::policy_state_, of generation watch_gen) that learns from what happens to this handle
+    uint32_t watch = 0, watch_gen = 0;
     // scratch fields of the DAG builder (valid when mark == the builder's current epoch): no hash maps on the hot path
     uint64_t mark = 0;
     int     tmp_id = 0, tmp_uses = 0;
@@ -220,6 +227,29 @@ public:
     static void bind_thread(Engine* e);      // Engine::get() of THIS thread returns e from now on (nullptr: the process-wide engine again)
     static bool thread_is_bound();
     std::recursive_mutex mu;
+    // Releases from a thread that is NOT driving the engine — a garbage collector's cleaner thread handing back, in bursts, the handles of
+    // objects that died a while ago (java/net/finmath/hip/DeviceVector.java; the reference's ReferenceQueue, RandomVariableCuda.java:293-305)
+    // — never take the engine lock one by one: a caller thread that records two million methods a second would meet the releaser on the
+    // lock at every other call and sleep on it (measured, lmm_hip --finmath-like --release-lag 100, 1 M paths: 14.1 s against 4.3 s with
+    // the same launches).  They are queued (a tiny lock of their own) and performed by whoever enters the engine next; the releasing thread
+    // performs them itself, all at once, when LATE_BATCH have piled up or the oldest has waited 10 ms (the driving thread has gone quiet).
+    static constexpr size_t LATE_BATCH = 4096;
+    void note_driver(uint64_t thread_tag) { driver_tag_.store(thread_tag, std::memory_order_relaxed); driver_seq_.store(driver_seq_.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed); }
+    bool driven_by(uint64_t thread_tag) const { return driver_tag_.load(std::memory_order_relaxed) == thread_tag; }
+    uint64_t driver_seq() const { return driver_seq_.load(std::memory_order_relaxed); }
+    // (returns true when the caller should perform the queue itself: LATE_BATCH releases wait, or the oldest has waited 10 ms — the driving thread has gone quiet)
+    bool release_later(fmhip_vec h) {
+        const auto now = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lock(late_mu_);
+        if (late_.empty()) late_since_ = now;
+        late_.push_back(h);
+        late_count_.store(late_.size(), std::memory_order_release);
+        return late_.size() >= LATE_BATCH || now - late_since_ > std::chrono::milliseconds(10);
+    }
+    bool has_late() const { return late_count_.load(std::memory_order_acquire) != 0; }
+    size_t late_count() const { return late_count_.load(std::memory_order_relaxed); }
+    static constexpr size_t LATE_DRAIN = 512;                  // a driving thread performs queued releases when this many wait (a releaser that feeds them one by one must not make it take the queue's lock at every call)
+    void drain_late();                                         // under `mu`
     // Callers that wait for moments WITHOUT the engine lock (abi.cpp: fmhip_reduce_moments, fmhip_reduce_moments_batch_end) hold slots,
     // pinned blocks and events of this engine meanwhile: counted here (under the lock, before it is dropped); fmhip_shutdown waits for zero.
     std::atomic<int> waits_in_flight{ 0 };
@@ -309,6 +339,7 @@ public:
     int64_t jit_launches() const { return n_jit_launches_; }
     int64_t rolled_launches() const { return n_rolled_launches_; }
     int64_t algorithmic_bytes() const { return algorithmic_bytes_; }
+    void engine_stats(fmhip_engine_stats_t* out);
     Program* program(fmhip_program p);
     void program_run(fmhip_program p, int batch, const fmhip_vec* inputs, fmhip_vec* outputs, bool into,
                      const double* shifts, fmhip_moments* moments, void* dev_moments);
@@ -345,8 +376,10 @@ private:
     HandleTable nodes_;
     Node pending_head_;                                          // circular list of the nodes without storage (lazy expressions)
     void pend_insert(Node* nd) { nd->pend_prev = pending_head_.pend_prev; nd->pend_next = &pending_head_; pending_head_.pend_prev->pend_next = nd; pending_head_.pend_prev = nd; ++n_pending_; }
-    void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr; --n_pending_; }
-    void pend_clear() { pending_head_.pend_prev = pending_head_.pend_next = &pending_head_; n_pending_ = 0; }
+    // (off whichever list it is on: the pending list or — Node::deferred — the deferred list)
+    void pend_erase(Node* nd) { if (!nd->pend_next) return; nd->pend_prev->pend_next = nd->pend_next; nd->pend_next->pend_prev = nd->pend_prev; nd->pend_prev = nd->pend_next = nullptr;
+                                if (nd->deferred) { nd->deferred = false; --n_deferred_; } else --n_pending_; }
+    void pend_clear() { pending_head_.pend_prev = pending_head_.pend_next = &pending_head_; n_pending_ = 0; deferred_head_.pend_prev = deferred_head_.pend_next = &deferred_head_; n_deferred_ = 0; }
     size_t n_pending_ = 0;                      // nodes on the pending list
     std::vector<Node*> node_pool_;                               // recycled Node objects
     std::unordered_map<int64_t, Program*> programs_;
@@ -405,6 +438,7 @@ private:
                      std::vector<SsaOp> ssa; std::vector<int> out_ids; int n_in = 0; Program* prog_red = nullptr; bool no_red = false; };
         std::vector<Seg> segs;
         std::string sig;            // the shape the plan was made for (the cache is keyed by its hash)
+        bool segs_missing = false;  // the shape has only run as ONE launch of its peeled kernel so far: `segs` is cut when that launch is not available (run_plan)
         bool discards_root = false; // the component's root is wanted for its moments only (Node::discard): the peeled kernels of this plan do not store it
         // A periodic stretch of the scheduled order — the same few operations over one component after another, each iteration
         // feeding the next (a running sum) — as ONE launch of a kernel that loops over the iterations (runtime.cpp: rolled loops).
@@ -438,11 +472,52 @@ private:
     };
     bool build_big(const std::vector<Node*>& roots, BigDag& big);
     // build_big: how a shape (the signature of the walk) was scheduled when it was first seen
-    struct ScheduleMemo { std::string walk_sig, sig; std::vector<uint32_t> perm; std::vector<char> escapes; uint64_t hash = 0; };
+    // (signatures here are STRUCTURAL — opcodes and operands, never who holds a handle: the same memo serves a caller that frees its
+    // temporaries at the end of the statement and one whose garbage collector frees them a hundred milliseconds later.)  The flags — which
+    // values are stored — are decided per occurrence (escape policy); the signature and hash that go with the flags seen last are kept.
+    struct ShapePolicy { uint32_t base = 0, size = 0, gen = 0; uint64_t flush = 0; std::vector<uint8_t> decided; };
+    struct ScheduleMemo {
+        std::string walk_sig, sched_sig; std::vector<uint32_t> perm; uint64_t sched_hash = 0; ShapePolicy policy;
+        struct Variant { std::vector<char> flags; std::string sig; uint64_t hash = 0; };       // the same structure with these values stored: signature and hash of the component shape
+        std::vector<Variant> variants; size_t last_variant = 0;
+    };
     std::unordered_map<uint64_t, ScheduleMemo> schedule_cache_;
     size_t schedule_cache_bytes_ = 0;
     std::string walk_sig_;
-    bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag);
+    // ---- escape policy: which values of a fused launch are STORED.
+    // A value somebody outside the component needs (a pending consumer elsewhere, a root of the flush) is stored — that is a fact.  A value
+    // whose only claim to storage is a live HANDLE is a guess about the caller's future: under a garbage-collected caller (the JVM the
+    // reference lives in: RandomVariableCuda.java:96-106, 293-305) the temporary of `x.add(y).mult(z)` still has its handle when the flush
+    // comes, and storing by handles means storing every operation's result.  So the engine LEARNS, per position of a component shape,
+    // from what happens to such handles: stored for observation the first time (a caller that frees temporaries promptly: what it still
+    // holds, it probably wants), found untouched when the shape comes round again → not stored from then on (deferred: Node::deferred),
+    // touched after all → computed from its recipe, stored, and that position is stored for good (each position errs at most once).  A
+    // component in which most internally consumed values still carry handles comes from a caller that does not free temporaries at all:
+    // there the first guess is "not needed".  FMHIP_ESCAPE_POLICY=0: every handle is stored (rounds 1–4).
+    enum : uint8_t { POLICY_NEW = 0, POLICY_OBSERVING = 1, POLICY_STORE = 2, POLICY_DEFER = 3 };
+    std::vector<uint8_t> policy_state_;
+    uint32_t policy_gen_ = 1;
+    uint64_t flush_seq_ = 0;                                      // one number per flush / materialisation: decisions are taken once per position and flush
+    std::unordered_map<std::string, ShapePolicy> dag_policies_;   // single-launch components, by structural signature
+    void policy_bind(ShapePolicy& p, size_t size);                // (re)allocates the slots of a shape for the current generation and flush
+    bool policy_store(ShapePolicy& p, size_t pos, bool optimistic);   // the decision for a handle-only value at that position (once per flush)
+    void policy_reset();                                          // forgets everything learnt (caches dropped: pool_purge, a full schedule cache)
+    // the caller uses this handle again (an operand, a read, an expectation): its position is stored from now on; a value that was left unstored is wanted after all
+    void touch(Node* nd) { if (nd->watch) { if (nd->watch_gen == policy_gen_) policy_state_[nd->watch - 1] = POLICY_STORE; nd->watch = 0; } if (nd->deferred && !nd->buf) ++n_demanded_; }
+    void defer_node(Node* nd, const ShapePolicy* p, size_t pos);  // off the pending list, onto the deferred list; watched
+    void watch_node(Node* nd, const ShapePolicy& p, size_t pos) { nd->watch = p.base + (uint32_t)pos + 1; nd->watch_gen = p.gen; }
+    void demand(Node* nd);                                        // a deferred value is wanted after all: computed from its recipe and stored
+    void materialize_deferred();                                  // every deferred value that still has a handle (fmhip_pool_clean; before a vector is written in place)
+    std::mutex late_mu_;
+    std::vector<fmhip_vec> late_;
+    std::chrono::steady_clock::time_point late_since_{};
+    std::atomic<size_t> late_count_{ 0 };
+    std::atomic<uint64_t> driver_tag_{ 0 }, driver_seq_{ 0 };
+    Node deferred_head_;                                          // circular list of the deferred nodes (Node::pend_prev / pend_next)
+    size_t n_deferred_ = 0;
+    int64_t n_deferred_total_ = 0, n_demanded_ = 0, bytes_written_ = 0, n_interpreter_launches_ = 0;
+    void commit_node(Node* nd, Buffer* b) { nd->buf = b; pend_erase(nd); }       // a launch has stored this value
+    bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag, const std::vector<int32_t>& uses);
     // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
     struct ReduceRequest { double shift; fmhip_moments* host_out; void* dev_out; bool done; };
     // reduce() of a pending expression: the launch that takes the moments leaves its wait to reduce() — the bookkeeping behind the launch
@@ -470,6 +545,8 @@ private:
     void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);
     void red_release(RedLaunch& red);
     void run_big_group(std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
+    void plan_segments(BigPlan& plan, std::vector<BigDag>& group);
+    void plan_loop(BigPlan& plan, const BigDag& g);
     void run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, Program* prog_red = nullptr);
     void run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* rr = nullptr);
     Node* single_root(const BigDag& b, const BigDag& g0);

@@ -662,6 +662,18 @@ int traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches) {
         if (specialised_launches) *specialised_launches = tl;
     });
 }
+int engine_stats(fmhip_engine_stats_t* out) {
+    return fronted([&](Shards& s) {
+        need(out, "out");
+        std::vector<fmhip_engine_stats_t> per((size_t)s.D());
+        s.post([&](Worker& w) { w.ok(fmhip_engine_stats(&per[(size_t)w.shard])); });
+        s.wait();
+        fmhip_engine_stats_t t; std::memset(&t, 0, sizeof t);
+        for (const fmhip_engine_stats_t& p : per) { int64_t* a = &t.size; const int64_t* b = &p.size; for (size_t i = 1; i < sizeof t / sizeof(int64_t); ++i) a[i] += b[i]; }
+        t.size = (int64_t)sizeof t;
+        *out = t;
+    });
+}
 int profile_enable(int enabled) { return fronted([&](Shards& s) { s.post([=](Worker& w) { w.ok(fmhip_profile_enable(enabled)); }); s.wait(); }); }
 int profile_read(double* kernel_ms_total, int64_t* n_launches) {
     return fronted([&](Shards& s) {                            // the shards run side by side: the slowest one's device time, shard 0's launches

@@ -57,6 +57,7 @@ int bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64
 int pool(int what);                                        // 0 clean, 1 purge
 int pool_stats(fmhip_pool_stats_t* out);
 int traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches);
+int engine_stats(fmhip_engine_stats_t* out);
 int profile_enable(int enabled);
 int profile_read(double* kernel_ms_total, int64_t* n_launches);
 int unsupported(const char* what);

@@ -5,6 +5,9 @@
 // (SURVEY.md §8e).  Every rank then takes the same Levenberg–Marquardt step.
 #include <fstream>
 #include <thread>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 #include "lmm_main_common.hpp"
 #include "hip_backend.hpp"
@@ -14,7 +17,19 @@ static void ncclCheck(ncclResult_t r, const char* what) {
     if (r != ncclSuccess) throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
 }
 
+// FMHIP_BACKTRACE=1: the call stack of a fatal signal on stderr (abort() from the allocator's consistency checks, a segmentation fault)
+static void fatalSignal(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "lmm_hip: fatal signal, call stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char** argv) {
+    if (std::getenv("FMHIP_BACKTRACE")) { signal(SIGABRT, fatalSignal); signal(SIGSEGV, fatalSignal); signal(SIGBUS, fatalSignal); }
     const lmm::Options o = lmm::parseOptions(argc, argv);
     try {
         if (!o.devices.empty()) check(fmhip_init_devices(o.devices.data(), (int)o.devices.size()));      // one process, several devices: nothing else in this driver changes
@@ -196,7 +211,13 @@ int main(int argc, char** argv) {
                               o.releaseLagMs, o.releaseLagBytes, ls.queued, ls.released, ls.collections, ls.forcedCollections, ls.peakQueue);
                 lag = lb;
             }
-            return std::string(buf) + prof + lag;
+            fmhip_engine_stats_t es; check(fmhip_engine_stats(&es));
+            char eb[512];
+            std::snprintf(eb, sizeof eb, ", \"engine\": {\"interpreter_launches\": %lld, \"algorithmic_bytes_written\": %lld, \"values_deferred\": %lld, \"values_deferred_now\": %lld, "
+                          "\"values_demanded\": %lld, \"peak_bytes_reserved\": %lld}",
+                          (long long)es.interpreter_launches, (long long)es.algorithmic_bytes_written, (long long)es.values_deferred, (long long)es.values_deferred_now,
+                          (long long)es.values_demanded, (long long)es.peak_bytes_reserved);
+            return std::string(buf) + prof + lag + eb;
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);
         else { lmm::Options quiet = o; quiet.verbose = false; lmm::runAndReport(quiet, be, "hip", extra); }        // every rank reports: the launcher compares the parameter vectors

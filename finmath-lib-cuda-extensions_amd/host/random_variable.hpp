@@ -20,7 +20,6 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
-#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <limits>
@@ -190,49 +189,47 @@ public:
     void start(double collectEveryMs, size_t collectAtBytes) {
         stop();
         if (!(collectEveryMs > 0.0) && collectAtBytes == 0) return;
-        everyMs_ = collectEveryMs; atBytes_ = collectAtBytes; quit_ = false;
+        everyMs_ = collectEveryMs; atBytes_ = collectAtBytes; quit_.store(false);
         on_.store(true);
         collector_ = std::thread([this] { run(); });
     }
     void stop() {                                        // the JVM exits: whatever is queued is released
         if (!on_.load()) return;
-        { std::lock_guard<std::mutex> lock(mu_); quit_ = true; }
-        cv_.notify_all();
+        quit_.store(true);
         if (collector_.joinable()) collector_.join();
         on_.store(false);
         collect(false);
     }
     void died(fmhip_vec h) {                             // a wrapper object has become unreachable
-        bool wake = false;
-        { std::lock_guard<std::mutex> lock(mu_); dead_.push_back(h); ++stats_.queued; stats_.peakQueue = std::max<long long>(stats_.peakQueue, (long long)dead_.size());
-          wake = atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_; }
-        if (wake) cv_.notify_one();
+        std::lock_guard<std::mutex> lock(mu_);
+        dead_.push_back(h); ++stats_.queued;
+        stats_.peakQueue = std::max<long long>(stats_.peakQueue, (long long)dead_.size());
+        if (atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_) full_.store(true, std::memory_order_release);
     }
     void collect(bool forced) {                          // one collection, on the calling thread
         std::vector<fmhip_vec> batch;
-        { std::lock_guard<std::mutex> lock(mu_); batch.swap(dead_); ++stats_.collections; if (forced) ++stats_.forcedCollections; stats_.released += (long long)batch.size(); }
+        { std::lock_guard<std::mutex> lock(mu_); batch.swap(dead_); full_.store(false, std::memory_order_release); ++stats_.collections; if (forced) ++stats_.forcedCollections; stats_.released += (long long)batch.size(); }
         for (fmhip_vec h : batch) fmhip_vec_release(h);
     }
     Stats stats() { std::lock_guard<std::mutex> lock(mu_); return stats_; }
-    ~ReleaseLag() { if (collector_.joinable()) { { std::lock_guard<std::mutex> lock(mu_); quit_ = true; } cv_.notify_all(); collector_.join(); } }
+    ~ReleaseLag() { quit_.store(true); if (collector_.joinable()) collector_.join(); }
 private:
-    void run() {
-        std::unique_lock<std::mutex> lock(mu_);
-        while (!quit_) {
-            if (everyMs_ > 0.0) cv_.wait_for(lock, std::chrono::duration<double, std::milli>(everyMs_), [this] { return quit_ || (atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_); });
-            else cv_.wait(lock, [this] { return quit_ || dead_.size() * BYTES_PER_HANDLE >= atBytes_; });
-            if (quit_) break;
-            lock.unlock();
+    void run() {                                         // (sleeps in slices and looks at two flags: no condition variable — the sanitizer builds' libtsan does not know pthread_cond_clockwait)
+        using clk = std::chrono::steady_clock;
+        auto next = clk::now() + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::milli>(everyMs_ > 0.0 ? everyMs_ : 1e12));
+        while (!quit_.load(std::memory_order_acquire)) {
+            std::this_thread::sleep_for(std::chrono::microseconds(everyMs_ > 0.0 && everyMs_ < 2.0 ? (long long)(everyMs_ * 500) : 1000));
+            const bool due = everyMs_ > 0.0 && clk::now() >= next;
+            if (!due && !full_.load(std::memory_order_acquire)) continue;
             collect(false);
-            lock.lock();
+            if (due) next = clk::now() + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::milli>(everyMs_));
         }
     }
-    std::atomic<bool> on_{ false };
+    std::atomic<bool> on_{ false }, quit_{ false }, full_{ false };
     std::mutex mu_;
-    std::condition_variable cv_;
     std::vector<fmhip_vec> dead_;
     std::thread collector_;
-    double everyMs_ = 0.0; size_t atBytes_ = 0; bool quit_ = false;
+    double everyMs_ = 0.0; size_t atBytes_ = 0;
     Stats stats_;
 };
 

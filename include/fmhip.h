@@ -411,6 +411,21 @@ int fmhip_profile_enable(int enabled);
 /* Algorithmic bytes of all program launches so far (4 B x N x (inputs read + outputs written) per batch row;
  * reductions add nothing) and how many of those launches ran on the specialised tier. */
 int fmhip_traffic_stats(int64_t* algorithmic_bytes, int64_t* specialised_launches);
+/* Counters of the engine's work so far (all engines of the process added up; every field an int64, `size` = bytes filled in).
+ * The reference keeps no such record; the nearest are the log lines of DeviceMemoryPool (RandomVariableCuda.java:287-296).
+ *   values_deferred / _now / values_demanded: results of recorded methods that a fused launch computed for its consumers and did NOT
+ *   store although the caller still held a handle (the engine has learnt that handles at such positions are never used again — a
+ *   garbage-collected caller holds one for EVERY temporary until its next collection), how many of them exist now, and how many were
+ *   wanted after all (computed again from their recipe and stored: each costs a launch, and teaches the engine to store that position). */
+typedef struct fmhip_engine_stats_t {
+    int64_t size;
+    int64_t kernel_launches, specialised_launches, interpreter_launches;
+    int64_t algorithmic_bytes, algorithmic_bytes_written;
+    int64_t values_deferred, values_deferred_now, values_demanded;
+    int64_t pending_operations;
+    int64_t peak_bytes_reserved;
+} fmhip_engine_stats_t;
+int fmhip_engine_stats(fmhip_engine_stats_t* out);
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);
 
 #ifdef __cplusplus

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -351,10 +352,120 @@ static void scenario_speed() {
     rel(a); rel(b);
 }
 
+// A caller whose handles die when a garbage collector says so (the Java binding: a Cleaner action per handle; the reference:
+// RandomVariableCuda.java:293-305): every temporary keeps its handle until a collector THREAD releases it, in bursts, a few milliseconds
+// late.  The engine leaves such values unstored once it has learnt that nobody comes for them (Node::deferred, runtime.hpp: escape policy) —
+// and computes them from their recipes when somebody does: read, reduced, an operand of a later method, the vector they read overwritten
+// in place, fmhip_pool_clean.  Long chains (segments), a little Euler scheme over Brownian increments (time-step grouping, rolled loops).
+static void scenario_lagging() {
+    const int64_t n = 2049;
+    int was_fusion = 0;
+    OK(fmhip_set_fusion(1, &was_fusion));
+    std::mutex mu;
+    std::vector<V> dead;
+    std::atomic<bool> quit{ false };
+    std::thread collector([&] {
+        while (!quit.load()) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            std::vector<V> batch;
+            { std::lock_guard<std::mutex> lock(mu); batch.swap(dead); }
+            for (V h : batch) rel(h);
+        }
+    });
+    auto die = [&](V h) { std::lock_guard<std::mutex> lock(mu); dead.push_back(h); };
+    std::vector<float> host((size_t)n);
+    V x = filled(n, 0.5), y = filled(n, 1.5), z = filled(n, 0.75);
+    for (int round = 0; round < 12; ++round) {
+        std::vector<V> temps;
+        V cur = s1(FMHIP_OP_ADD_S, x, 1.0 + round);
+        for (int k = 0; k < 60; ++k) {
+            const V nx = k % 3 == 0 ? b2(FMHIP_OP_MULT, cur, y) : k % 3 == 1 ? s2(FMHIP_OP_ADDPRODUCT_VS, cur, z, 0.5) : u1(FMHIP_OP_ABS, cur);
+            temps.push_back(cur);
+            cur = nx;
+        }
+        OK(fmhip_flush());
+        fmhip_moments m; OK(fmhip_reduce_moments(cur, 0.0, &m));
+        if (round % 4 == 3) {                                        // values left unstored are used after all
+            OK(fmhip_vec_read_float(temps[17], host.data(), n));
+            const V late = b2(FMHIP_OP_ADD, temps[5], temps[40]);
+            OK(fmhip_vec_read_float(late, host.data(), n));
+            OK(fmhip_reduce_moments(temps[33], 0.0, &m));
+            die(late);
+        }
+        if (round == 7 && !std::getenv("FMNULL_DEVICES")) { void* ptr = nullptr; OK(fmhip_vec_device_ptr(x, &ptr)); }     // may be written in place: whoever reads x is computed first
+        if (round == 9) OK(fmhip_pool_clean());
+        for (V t : temps) die(t);
+        die(cur);
+    }
+    // an Euler scheme: 6 components, 16 time steps, every state and every temporary keeps its handle; expectations of the final state
+    const int steps = 16, comps = 6;
+    std::vector<double> dt((size_t)steps, 0.25);
+    for (int evaluation = 0; evaluation < 5; ++evaluation) {
+        std::vector<V> dW((size_t)steps);
+        OK(fmhip_bm_generate(1234 + evaluation, steps, 1, n, 0, dt.data(), dW.data()));
+        std::vector<V> state((size_t)comps), all;
+        for (int j = 0; j < comps; ++j) { state[(size_t)j] = s1(FMHIP_OP_MULT_S, x, 0.1 * (j + 1)); }
+        for (int i = 0; i < steps; ++i) {
+            V sum = 0;
+            for (int j = 0; j < comps; ++j) {
+                const V t1 = s1(FMHIP_OP_MULT_S, state[(size_t)j], 0.5), t2 = s1(FMHIP_OP_ADD_S, t1, 1.0), tr = s1(FMHIP_OP_VID_S, t2, 0.02);
+                const V ns = sum ? b2(FMHIP_OP_ADD, sum, tr) : tr;
+                const V drift = s1(FMHIP_OP_MULT_S, ns, 0.3), a = s2(FMHIP_OP_ADDPRODUCT_VS, state[(size_t)j], drift, 0.25), nx = s2(FMHIP_OP_ADDPRODUCT_VS, a, dW[(size_t)i], 0.3);
+                all.push_back(t1); all.push_back(t2); if (sum) all.push_back(tr); if (sum) all.push_back(sum);
+                all.push_back(drift); all.push_back(a); all.push_back(state[(size_t)j]);
+                sum = ns; state[(size_t)j] = nx;
+            }
+            all.push_back(sum);
+        }
+        for (int j = 0; j < comps; ++j) { fmhip_moments m; OK(fmhip_reduce_moments(state[(size_t)j], 0.0, &m)); }
+        if (evaluation == 3) { OK(fmhip_vec_read_float(all[all.size() / 2], host.data(), n)); OK(fmhip_vec_read_float(all[7], host.data(), n)); }     // states of the middle of the simulation, wanted after all
+        for (V h : all) die(h);
+        for (V h : state) die(h);
+        for (V h : dW) die(h);
+    }
+    quit.store(true);
+    collector.join();
+    rel(dead);
+    rel(x); rel(y); rel(z);
+    fmhip_engine_stats_t es; OK(fmhip_engine_stats(&es));
+    if (es.values_deferred <= 0 || es.values_demanded <= 0 || es.values_deferred_now != 0) { std::fprintf(stderr, "lagging: deferred %lld, demanded %lld, deferred now %lld\n", (long long)es.values_deferred, (long long)es.values_demanded, (long long)es.values_deferred_now); std::abort(); }
+    OK(fmhip_set_fusion(was_fusion, nullptr));
+}
+
+// A device that is FULL (FMNULL_DEVICE_BYTES: the null device refuses allocations beyond it): the pool's last resort — drop every cached
+// slab, try once more (RandomVariableCuda.java:340) — on the first allocation of a size class it has never seen, with and without success,
+// then the error a garbage-collected caller answers with a collection.  Round 5 found heap corruption here on a real device (a reference
+// into the pool's size-class table held across the purge that erases its entry).
+static void scenario_oom() {
+    if (!std::getenv("FMNULL_DEVICE_BYTES")) { std::printf("oom: FMNULL_DEVICE_BYTES not set, skipped\n"); return; }
+    const int64_t n = 1 << 20;                                   // 4 MiB vectors
+    std::vector<V> small;
+    for (;;) { V h = 0; const int st = fmhip_vec_create_filled(n, 1.0, &h); if (st == FMHIP_ERR_OUT_OF_MEMORY) break; OK(st); small.push_back(h); if (small.size() > 100000) std::abort(); }
+    if (small.size() < 8) std::abort();
+    rel(small);                                                   // all cached in the pool now: the device is full of free blocks
+    V big = 0;
+    OK(fmhip_vec_create_filled(5 * n + 123, 2.0, &big));          // a new size class: hipMalloc fails, the purge makes room
+    V big2 = 0;
+    OK(fmhip_vec_create_filled(3 * n + 77, 2.0, &big2));          // … and another one
+    std::vector<V> more;
+    for (;;) { V h = 0; const int st = fmhip_vec_create_filled(n, 1.0, &h); if (st == FMHIP_ERR_OUT_OF_MEMORY) break; OK(st); more.push_back(h); if (more.size() > 100000) std::abort(); }
+    V huge = 0;
+    EXPECT(fmhip_vec_create_filled(7 * n + 5, 2.0, &huge), FMHIP_ERR_OUT_OF_MEMORY);      // nothing cached to drop: the error, and an engine that carries on
+    int was = 0; OK(fmhip_set_fusion(1, &was));
+    const V t = s1(FMHIP_OP_ADD_S, big, 1.0), u = b2(FMHIP_OP_MULT, t, big);
+    EXPECT(fmhip_flush(), FMHIP_ERR_OUT_OF_MEMORY);               // a fused launch that cannot get its output
+    rel(more);                                                    // the caller's collection
+    OK(fmhip_flush());
+    std::vector<float> host((size_t)(5 * n + 123));
+    OK(fmhip_vec_read_float(u, host.data(), 5 * n + 123));
+    rel(t); rel(u); rel(big); rel(big2);
+    OK(fmhip_set_fusion(was, nullptr));
+}
+
 int main(int argc, char** argv) {
     struct Scenario { const char* name; void (*run)(); };
     const Scenario all[] = { { "basic", scenario_basic }, { "replicas", scenario_replicas }, { "expectations", scenario_expectations },
-                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "shared", scenario_shared }, { "failure", scenario_failure }, { "speed", scenario_speed } };
+                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "shared", scenario_shared }, { "failure", scenario_failure }, { "speed", scenario_speed }, { "lagging", scenario_lagging }, { "oom", scenario_oom } };
     std::vector<std::string> wanted;
     for (int i = 1; i < argc; ++i) wanted.push_back(argv[i]);
     const bool only_failure = wanted.size() == 1 && wanted[0] == "failure";      // (the hook counts the allocations of the whole process: one cycle)
@@ -366,7 +477,7 @@ int main(int argc, char** argv) {
         // FMNULL_THREAD_ENGINES=1: an engine per caller thread (fmhip_set_thread_engines) — the scenarios' threads record side by side
         if (n_devices <= 1 && std::getenv("FMNULL_THREAD_ENGINES")) { int was = -1; OK(fmhip_set_thread_engines(1, &was)); if (was != 0) std::abort(); }
         for (const Scenario& s : all) {
-            bool run = wanted.empty() ? (std::strcmp(s.name, "failure") != 0 && std::strcmp(s.name, "speed") != 0) : false;
+            bool run = wanted.empty() ? (std::strcmp(s.name, "failure") != 0 && std::strcmp(s.name, "speed") != 0 && std::strcmp(s.name, "oom") != 0) : false;
             for (const std::string& w : wanted) run |= w == s.name;
             if (!run) continue;
             s.run();

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <algorithm>
+#include <unordered_map>
 
 #include "../../finmath-lib-cuda-extensions_amd/csrc/kernels.h"
 
@@ -58,6 +60,7 @@ hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_
     for (uint32_t i = 0; i < a.count; ++i) std::memcpy(out + (size_t)i * 4, reinterpret_cast<const void*>((uintptr_t)a.src[i]), 32);
     return hipSuccess;
 }
+hipError_t preload_kernels() { return hipSuccess; }
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t) { ++g_launches; for (int64_t i = 0; i < n_padded; ++i) p[i] = v; return hipSuccess; }
 }
 
@@ -67,9 +70,23 @@ hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "null-device error"; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* p, int) { std::memset(p, 0, sizeof *p); std::strcpy(p->name, "null device (tests)"); std::strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = 256; p->totalGlobalMem = size_t(288) << 30; return hipSuccess; }
-hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = size_t(256) << 30; *tot = size_t(288) << 30; return hipSuccess; }
-hipError_t hipMalloc(void** p, size_t bytes) { ++g_allocs; *p = aligned(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
-hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+// FMNULL_DEVICE_BYTES=N: a device of N bytes — allocations beyond it fail, hipMemGetInfo tells what is left (the engine's behaviour when
+// device memory runs out: purge, FMHIP_ERR_OUT_OF_MEMORY, the caller's collection, the retry)
+static const size_t DEVICE_BYTES = [] { const char* e = std::getenv("FMNULL_DEVICE_BYTES"); return e ? (size_t)std::atoll(e) : (size_t(288) << 30); }();
+static std::mutex g_mem_mu;
+static std::unordered_map<void*, size_t> g_mem;
+static size_t g_mem_used = 0;
+hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { std::lock_guard<std::mutex> lock(g_mem_mu); *fr = DEVICE_BYTES - std::min(DEVICE_BYTES, g_mem_used); *tot = DEVICE_BYTES; return hipSuccess; }
+hipError_t hipMalloc(void** p, size_t bytes) {
+    ++g_allocs;
+    std::lock_guard<std::mutex> lock(g_mem_mu);
+    if (g_mem_used + bytes > DEVICE_BYTES) { *p = nullptr; return hipErrorOutOfMemory; }
+    *p = aligned(bytes);
+    if (!*p) return hipErrorOutOfMemory;
+    g_mem[*p] = bytes; g_mem_used += bytes;
+    return hipSuccess;
+}
+hipError_t hipFree(void* p) { { std::lock_guard<std::mutex> lock(g_mem_mu); auto it = g_mem.find(p); if (it != g_mem.end()) { g_mem_used -= it->second; g_mem.erase(it); } } std::free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = aligned(bytes); if (*p) std::memset(*p, 0, bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }

@@ -4,7 +4,9 @@ pinned arena, plan caches) under AddressSanitizer + UndefinedBehaviorSanitizer a
 pool.  tests/nulldev/drive.cpp replays the graph shapes of the GPU tests (replicas in the ten orders of test_gpu_replicas.py, long
 chains through segments / rolled / peeled plans, expectations taken along, values given up, tickets out of order, the row-table ring
 and the moments arena wrapping at tiny sizes, eight threads, shutdown and re-initialisation) and, in a sweep of its own, a failing
-allocation in the middle of a replicated launch of 1100 members.  The null device is not a back end and never ships."""
+allocation in the middle of a replicated launch of 1100 members; `lagging`: a caller whose handles are released late, in bursts, by a
+collector thread — the lifetime contract of a JVM (values left unstored, computed from their recipes on demand); `oom`: a device that is
+full.  The null device is not a back end and never ships."""
 import os
 import subprocess
 
@@ -31,7 +33,7 @@ def run(binary, tmp_path, *scenarios, **extra_env):
 def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(built, tmp_path):
     r = run(os.path.join(built, "drive_asan"), tmp_path)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 12          # six scenarios, twice (shutdown and re-initialisation in between)
+    assert r.stdout.count("done") == 14          # seven scenarios, twice (shutdown and re-initialisation in between)
     again = run(os.path.join(built, "drive_asan"), tmp_path)      # once more: the code objects of the first run come from the cache directory
     assert again.returncode == 0 and "Sanitizer" not in again.stderr, again.stderr[-6000:]
 
@@ -39,7 +41,7 @@ def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(
 def test_host_runtime_is_clean_under_thread_sanitizer(built, tmp_path):
     r = run(os.path.join(built, "drive_tsan"), tmp_path)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 12
+    assert r.stdout.count("done") == 14
 
 
 def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(built, tmp_path):
@@ -51,16 +53,31 @@ def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(b
         assert "failure done" in r.stdout
 
 
+def test_a_full_device(built, tmp_path):
+    """The pool's last resort (drop every cached slab, try once more) on the first allocation of a new size class, the out-of-memory
+    status, and a fused launch that cannot get its output — on a null device of 800 MB.  Round 5: heap corruption on the real device
+    (a reference into the pool's size-class table held across the purge that erases the entry); the native driver under a lagging
+    collector and a device that fills up within a few evaluations (collections forced by out-of-memory statuses, retries)."""
+    r = run(os.path.join(built, "drive_asan"), tmp_path, "oom", FMNULL_DEVICE_BYTES="800000000", FMHIP_POOL_HEADROOM_BYTES="1000000")
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-500:] + r.stderr[-6000:]
+    assert r.stdout.count("oom done") == 2
+    for policy in ("0", "1"):
+        d = run(os.path.join(built, "lmm_asan"), tmp_path, "--paths", "3000", "--mode", "calibrate", "--max-iterations", "1", "--finmath-like", "--release-lag", "50",
+                FMNULL_DEVICE_BYTES="400000000", FMHIP_POOL_HEADROOM_BYTES="20000000", FMHIP_ESCAPE_POLICY=policy, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
+        assert d.returncode == 0 and "Sanitizer" not in d.stderr and "runtime error" not in d.stderr, (policy, d.stdout[-500:] + d.stderr[-6000:])
+        assert '"collections_forced_by_out_of_memory": 0' not in d.stdout or policy == "1"
+
+
 @pytest.mark.parametrize("shards", [2, 3])
 def test_a_device_list_is_clean_under_both_sanitizer_builds(built, tmp_path, shards):
     """The same scenarios behind fmhip_init_devices (csrc/sharded.cpp: one engine and one worker thread per shard, the caller's calls replayed
     through a single-producer ring per worker, reads and reductions gathered): ASan + UBSan, then ThreadSanitizer."""
     r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 12
+    assert r.stdout.count("done") == 14
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
-    assert t.stdout.count("done") == 12
+    assert t.stdout.count("done") == 14
 
 
 def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_path):
@@ -79,12 +96,16 @@ def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_p
              # an engine per caller thread (fmhip_set_thread_engines): the Jacobian's columns on four threads, the Brownian increments and the
              # initial curve owned by the first engine and imported by the others, results read and released across threads; two iterations,
              # so that the second pool of threads takes over the engines the first one left behind
-             ["--mode", "calibrate", "--max-iterations", "2", "--finmath-like", "--threads", "4"]]
+             ["--mode", "calibrate", "--max-iterations", "2", "--finmath-like", "--threads", "4"],
+             # the caller without hints whose handles die when a collector thread says so (host/random_variable.hpp: ReleaseLag): every 5 ms,
+             # and "never, until 2 MB of dead wrappers have piled up"
+             ["--mode", "calibrate", "--max-iterations", "1", "--finmath-like", "--release-lag", "5"],
+             ["--mode", "evaluate", "--evaluations", "12", "--finmath-like", "--release-lag-bytes", "2000000"]]
     for args in cases:
         r = run(asan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stdout[-500:] + r.stderr[-6000:])
         assert '"evaluations"' in r.stdout
-    for args in (cases[0], cases[2], cases[4]):
+    for args in (cases[0], cases[2], cases[4], cases[5]):
         t = run(tsan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
 
@@ -96,8 +117,8 @@ def test_thread_engines_are_clean_under_both_sanitizer_builds(built, tmp_path):
     on one thread and ended on another, vectors handed over and released across engines; then shutdown (engines retired) and the same again."""
     r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_THREAD_ENGINES="1")
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 12
+    assert r.stdout.count("done") == 14
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_THREAD_ENGINES="1")
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
-    assert t.stdout.count("done") == 12
+    assert t.stdout.count("done") == 14
 
