@@ -329,34 +329,6 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                                    "what": "the same calibration through methods + getAverage() only; the engine groups time steps itself (fmhip_set_step_grouping)"}
         except Exception as e:
             lmm["finmath_like"] = {"error": str(e)[-500:]}
-        # … and the same caller with a garbage collector's idea of lifetime: every handle is released LATE, in bursts, by another thread —
-        # what a JVM does with the reference's / the Java binding's wrappers (RandomVariableCuda.java:293-305; java/…/DeviceVector.java: a
-        # Cleaner action per handle).  lmm_hip --release-lag 100: a collection every 100 ms; --release-lag-bytes: "never, until 256 MB of
-        # dead wrappers".  The engine must not decide what to store by live handles (escape policy, runtime.hpp): bytes written, launches and
-        # the tier they run on are set against the run whose temporaries die at once (RAII, above).
-        try:
-            def gc_block(extra):
-                g, _ = run(base + ["--finmath-like"] + extra)
-                e, e0 = g.get("engine", {}), fl.get("engine", {})
-                return {"seconds": g["seconds"], "seconds_over_raii": round(g["seconds"] / fl["seconds"], 3), "kernel_launches": g["kernel_launches"], "mean_deviation": g["mean_deviation"],
-                        "identical_to_raii": g["mean_deviation"] == fl["mean_deviation"] and g["rms_deviation"] == fl["rms_deviation"],
-                        "algorithmic_bytes_written": e.get("algorithmic_bytes_written"),
-                        "bytes_written_over_raii": round(e.get("algorithmic_bytes_written", 0) / max(1, e0.get("algorithmic_bytes_written", 1)), 3),
-                        "specialised_launches": g.get("specialised_launches"), "interpreter_launches": e.get("interpreter_launches"),
-                        "interpreter_fraction": round(e.get("interpreter_launches", 0) / max(1, g["kernel_launches"]), 4),
-                        "hiprtc_compilations": g.get("specialised_kernels", 0) - g.get("specialisations_from_disk_cache", 0),
-                        "values_deferred": e.get("values_deferred"), "values_demanded": e.get("values_demanded"),
-                        "peak_bytes_reserved": e.get("peak_bytes_reserved"), "release_lag": g.get("release_lag")}
-            gc = {"raii": {"seconds": fl["seconds"], "kernel_launches": fl["kernel_launches"], "algorithmic_bytes_written": fl.get("engine", {}).get("algorithmic_bytes_written"),
-                           "interpreter_launches": fl.get("engine", {}).get("interpreter_launches"), "peak_bytes_reserved": fl.get("engine", {}).get("peak_bytes_reserved")},
-                  "collect_every_100_ms": gc_block(["--release-lag", "100"]),
-                  "collect_every_20_ms": gc_block(["--release-lag", "20"]),
-                  "collect_at_256_MB_of_dead_wrappers": gc_block(["--release-lag-bytes", str(256 << 20)]),
-                  "what": "lmm_hip --finmath-like --release-lag MS | --release-lag-bytes B: the C++ mirror's handle releases are queued and performed by a collector "
-                          "thread, as a JVM's Cleaner would (host/random_variable.hpp: ReleaseLag); a device allocation that fails runs a collection and is retried"}
-            lmm["finmath_like_gc"] = gc
-        except Exception as e:
-            lmm["finmath_like_gc"] = {"error": str(e)[-500:]}
         # … and with the optimiser's thread pool (LIBORMarketModelCalibrationATMTest.java:319: finmath-lib evaluates the columns of a Jacobian on
         # several threads): the same caller on four threads, an engine each (fmhip_set_thread_engines).  At 1 M paths the calibration is bound by
         # the device and the threads gain nothing; where it is bound by the host (100 k paths) they do.
@@ -382,6 +354,35 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                                                     "unmeasured on more than one physical GPU"}
         except Exception as e:
             lmm["device_list_rehearsal"] = {"error": str(e)[-500:]}
+        # … and the same caller with a garbage collector's idea of lifetime: every handle is released LATE, in bursts, by another thread —
+        # what a JVM does with the reference's / the Java binding's wrappers (RandomVariableCuda.java:293-305; java/…/DeviceVector.java: a
+        # Cleaner action per handle).  lmm_hip --release-lag 100: a collection every 100 ms; --release-lag-bytes: "never, until 256 MB of
+        # dead wrappers".  The engine must not decide what to store by live handles (escape policy, runtime.hpp): bytes written, launches and
+        # the tier they run on are set against the run whose temporaries die at once (RAII, above).
+        # (last of the driver runs: a process that held most of the device leaves the next one a device still busy giving the memory back)
+        try:
+            def gc_block(extra):
+                g, _ = run(base + ["--finmath-like"] + extra)
+                e, e0 = g.get("engine", {}), fl.get("engine", {})
+                return {"seconds": g["seconds"], "seconds_over_raii": round(g["seconds"] / fl["seconds"], 3), "kernel_launches": g["kernel_launches"], "mean_deviation": g["mean_deviation"],
+                        "identical_to_raii": g["mean_deviation"] == fl["mean_deviation"] and g["rms_deviation"] == fl["rms_deviation"],
+                        "algorithmic_bytes_written": e.get("algorithmic_bytes_written"),
+                        "bytes_written_over_raii": round(e.get("algorithmic_bytes_written", 0) / max(1, e0.get("algorithmic_bytes_written", 1)), 3),
+                        "specialised_launches": g.get("specialised_launches"), "interpreter_launches": e.get("interpreter_launches"),
+                        "interpreter_fraction": round(e.get("interpreter_launches", 0) / max(1, g["kernel_launches"]), 4),
+                        "hiprtc_compilations": g.get("specialised_kernels", 0) - g.get("specialisations_from_disk_cache", 0),
+                        "values_deferred": e.get("values_deferred"), "values_demanded": e.get("values_demanded"),
+                        "peak_bytes_reserved": e.get("peak_bytes_reserved"), "release_lag": g.get("release_lag")}
+            gc = {"raii": {"seconds": fl["seconds"], "kernel_launches": fl["kernel_launches"], "algorithmic_bytes_written": fl.get("engine", {}).get("algorithmic_bytes_written"),
+                           "interpreter_launches": fl.get("engine", {}).get("interpreter_launches"), "peak_bytes_reserved": fl.get("engine", {}).get("peak_bytes_reserved")},
+                  "collect_every_100_ms": gc_block(["--release-lag", "100"]),
+                  "collect_every_20_ms": gc_block(["--release-lag", "20"]),
+                  "collect_at_256_MB_of_dead_wrappers": gc_block(["--release-lag-bytes", str(256 << 20)]),
+                  "what": "lmm_hip --finmath-like --release-lag MS | --release-lag-bytes B: the C++ mirror's handle releases are queued and performed by a collector "
+                          "thread, as a JVM's Cleaner would (host/random_variable.hpp: ReleaseLag); a device allocation that fails runs a collection and is retried"}
+            lmm["finmath_like_gc"] = gc
+        except Exception as e:
+            lmm["finmath_like_gc"] = {"error": str(e)[-500:]}
         if cpu_base:
             cj, _ = run([LMM_CPU, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "1"])
             per_eval = cj["seconds_simulation_per_evaluation"] + cj["seconds_valuation_per_evaluation"]

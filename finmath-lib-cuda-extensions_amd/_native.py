@@ -22,7 +22,7 @@ SYMBOLS = [
     "fmhip_call_v1s0", "fmhip_call_v1s1", "fmhip_call_v2s0", "fmhip_call_v2s1", "fmhip_call_v3s0",
     "fmhip_set_fusion", "fmhip_flush", "fmhip_fusion_hold", "fmhip_set_step_grouping", "fmhip_graph_clone", "fmhip_graph_scalars", "fmhip_set_math_mode",
     "fmhip_reduce_moments", "fmhip_reduce_moments_batch", "fmhip_reduce_moments_batch_device", "fmhip_reduce_moments_device",
-    "fmhip_reduce_moments_batch_begin", "fmhip_reduce_moments_batch_end",
+    "fmhip_reduce_moments_batch_begin", "fmhip_reduce_moments_batch_end", "fmhip_reduce_moments_batch_devices", "fmhip_get_stream_of", "fmhip_expectation_collective",
     "fmhip_set_expectation_comm", "fmhip_expectation_world", "fmhip_expectation_combine",
     "fmhip_program_create", "fmhip_program_release", "fmhip_program_launch_count", "fmhip_program_shape",
     "fmhip_program_run", "fmhip_program_run_into",
@@ -156,6 +156,7 @@ def lib():
         "fmhip_set_fusion": [i32, C.POINTER(i32)], "fmhip_flush": [], "fmhip_fusion_hold": [i32, C.POINTER(i32)], "fmhip_set_step_grouping": [i32, C.POINTER(i32)], "fmhip_set_math_mode": [i32, C.POINTER(i32)],
         "fmhip_graph_clone": [pv, i32, i32, pv, pv, i32, C.POINTER(dbl), i32, pv], "fmhip_graph_scalars": [pv, i32, C.POINTER(dbl), i32, C.POINTER(i32)],
         "fmhip_reduce_moments": [vec, dbl, C.POINTER(Moments)], "fmhip_reduce_moments_batch": [pv, i32, C.POINTER(dbl), C.POINTER(Moments)], "fmhip_reduce_moments_batch_device": [pv, i32, C.POINTER(dbl), vp], "fmhip_reduce_moments_device": [vec, dbl, vp],
+        "fmhip_reduce_moments_batch_devices": [pv, i32, C.POINTER(dbl), C.POINTER(vp), i32], "fmhip_get_stream_of": [i32, C.POINTER(vp)], "fmhip_expectation_collective": [C.POINTER(i32), C.c_char_p, i32],
         "fmhip_reduce_moments_batch_begin": [pv, i32, C.POINTER(dbl), pv], "fmhip_vec_give_up_values": [pv, i32], "fmhip_reduce_moments_batch_end": [i64, C.POINTER(Moments), i32],
         "fmhip_program_create": [C.POINTER(ProgOp), i32, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), i32, pv],
         "fmhip_program_release": [i64], "fmhip_program_launch_count": [i64, C.POINTER(i32)],

@@ -510,7 +510,11 @@ static void exchange_moments(Engine& e, fmhip_moments* inout, int count) {
     combine_moments(all.data(), e.comm_world, count, inout);
 }
 int fmhip_set_expectation_comm(int world, int rank, fmhip_gather_fn gather, void* context) {
-    if (fm::front_active() && world > 1) return front::unsupported("fmhip_set_expectation_comm");
+    if (fm::front_active()) {                               // a device list combines its shards' moments itself: a communicator of one rank is what it has
+        if (world > 1) return front::unsupported("fmhip_set_expectation_comm");
+        if (world < 1 || rank != 0) { g_last_error = "bad communicator: world " + std::to_string(world) + ", rank " + std::to_string(rank); return FMHIP_ERR_INVALID_ARGUMENT; }
+        return FMHIP_OK;
+    }
     return guarded([&] {
         Engine& e = Engine::get();
         if (world < 1 || rank < 0 || rank >= world) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "bad communicator: world " + std::to_string(world) + ", rank " + std::to_string(rank));
@@ -519,6 +523,7 @@ int fmhip_set_expectation_comm(int world, int rank, fmhip_gather_fn gather, void
     });
 }
 int fmhip_expectation_world(int* world, int* rank) {
+    if (fm::front_active()) { if (world) *world = 1; if (rank) *rank = 0; return FMHIP_OK; }
     return guarded([&] { Engine& e = Engine::get(); if (world) *world = e.comm_world; if (rank) *rank = e.comm_rank; });
 }
 int fmhip_expectation_combine(const fmhip_moments* gathered, int world, int count, fmhip_moments* out) {
@@ -549,8 +554,34 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
     TE_LOCAL(vectors, count, L, fmhip_reduce_moments_batch(L, count, shifts, out));
     return guarded([&] { need(vectors, "vectors"); need(out, "out"); Engine& e = Engine::get(); e.reduce_batch(vectors, count, shifts, out, nullptr); exchange_moments(e, out, count); });
 }
+// With a device list the buffer is on the FIRST listed device: it receives the moments of the whole vectors (all shards, combined by the
+// one exchange between the devices: fm::front::reduce_moments_batch_devices) — "a single reduce for the final expectations".
+static int reduce_to_first_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
+    int shards = 1;
+    const int st = front::device_count(&shards);
+    if (st != FMHIP_OK) return st;
+    std::vector<void*> out((size_t)shards, nullptr);
+    out[0] = device_out;
+    return front::reduce_moments_batch_devices(vectors, count, shifts, out.data(), shards);
+}
+int fmhip_reduce_moments_batch_devices(const fmhip_vec* vectors, int count, const double* shifts, void* const* device_out, int n_devices) {
+    FRONT(reduce_moments_batch_devices(vectors, count, shifts, device_out, n_devices));
+    if (n_devices != 1 || !device_out) { g_last_error = "one device: one output pointer"; return FMHIP_ERR_INVALID_ARGUMENT; }
+    return fmhip_reduce_moments_batch_device(vectors, count, shifts, device_out[0]);
+}
+int fmhip_get_stream_of(int shard, void** stream_out) {
+    FRONT(get_stream_of(shard, stream_out));
+    if (shard != 0) { g_last_error = "no such device shard: " + std::to_string(shard); return FMHIP_ERR_INVALID_ARGUMENT; }
+    return fmhip_get_stream(stream_out);
+}
+int fmhip_expectation_collective(int* kind, char* why, int why_len) {
+    FRONT(expectation_collective(kind, why, why_len));
+    if (kind) *kind = 0;
+    if (why && why_len > 0) why[0] = 0;
+    return FMHIP_OK;
+}
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out) {
-    FRONT(unsupported("fmhip_reduce_moments_batch_device"));
+    if (fm::front_active()) return reduce_to_first_device(vectors, count, shifts, device_out);
     TE_LOCAL(vectors, count, L, fmhip_reduce_moments_batch_device(L, count, shifts, device_out));
     return guarded([&] { need(vectors, "vectors"); need(device_out, "device_out"); Engine::get().reduce_batch_device(vectors, count, shifts, device_out); });
 }
@@ -595,7 +626,7 @@ int fmhip_reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int 
     return rc;
 }
 int fmhip_reduce_moments_device(fmhip_vec v, double shift, void* device_out_4_doubles) {
-    FRONT(unsupported("fmhip_reduce_moments_device"));
+    if (fm::front_active()) { const double sh[1] = { shift }; return reduce_to_first_device(&v, 1, sh, device_out_4_doubles); }
     TE_OWNER(v, fmhip_reduce_moments_device(v, shift, device_out_4_doubles));
     return guarded([&] { need(device_out_4_doubles, "device_out"); Engine::get().reduce(v, shift, nullptr, device_out_4_doubles); });
 }
@@ -673,7 +704,7 @@ int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
 }
 int fmhip_program_release(fmhip_program p) { FRONT(program_release(p)); TE_OWNER(p, fmhip_program_release(p)); return guarded([&] { Engine::get().program_release(p); }); }
 int fmhip_program_launch_count(fmhip_program p, int* n_launches) {
-    if (fm::front_active()) { int a = 0; const int st = front::program_shape(p, &a, nullptr, nullptr); if (st == FMHIP_OK && n_launches) *n_launches = 1; return st; }
+    if (fm::front_active()) { int a = 0, shards = 1; int st = front::program_shape(p, &a, nullptr, nullptr); if (st == FMHIP_OK) st = front::device_count(&shards); if (st == FMHIP_OK && n_launches) *n_launches = shards; return st; }      // one launch per device shard
     TE_OWNER(p, fmhip_program_launch_count(p, n_launches));
     return guarded([&] {
         need(n_launches, "n_launches");

@@ -28,5 +28,7 @@ hipError_t preload_kernels();        // makes the device code of every kernel ab
 constexpr int FM_GATHER_MAX = 384;                 // sources per launch: they travel in the kernel arguments (3 KB of the 4 KB segment)
 struct DevGatherArgs { uint32_t count; uint32_t pad; uint64_t src[FM_GATHER_MAX]; };
 hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t st);
+// gathered[world][count][4] → out[count][4]: the shards' moments combined in shard order by fmhip_expectation_combine's rule (on the device that holds them)
+hipError_t launch_combine_moments(const double* gathered, uint32_t world, uint32_t count, double* out, hipStream_t st);
 
 } // namespace fm

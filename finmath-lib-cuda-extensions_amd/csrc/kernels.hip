@@ -352,6 +352,24 @@ __global__ void __launch_bounds__(64) fm_gather_moments_kernel(const DevGatherAr
     out[(size_t)i * 4 + 0] = v0; out[(size_t)i * 4 + 1] = v1; out[(size_t)i * 4 + 2] = v2; out[(size_t)i * 4 + 3] = v3;
 }
 
+// The moments of `world` path shards of `count` vectors, [shard][vector][Σ, Σ², min, max] (the receive buffer of an all-gather), combined
+// per vector by the rule of fmhip_expectation_combine (abi.cpp: combine_moments): sums added in shard order — the same bits on every
+// device, whatever algorithm the collective used —, java.lang.Math.min / max (NaN-propagating, -0.0 < +0.0).  One lane per vector.
+__global__ void __launch_bounds__(64) fm_combine_moments_kernel(const double* __restrict__ gathered, const uint32_t world, const uint32_t count, double* __restrict__ out)
+{
+    const uint32_t k = blockIdx.x * 64u + threadIdx.x;
+    if (k >= count) return;
+    double sum = gathered[(size_t)k * 4 + 0], sumsq = gathered[(size_t)k * 4 + 1], mn = gathered[(size_t)k * 4 + 2], mx = gathered[(size_t)k * 4 + 3];
+    for (uint32_t r = 1; r < world; ++r) {
+        const double* g = gathered + ((size_t)r * count + k) * 4;
+        sum += g[0]; sumsq += g[1];
+        const double gmin = g[2], gmax = g[3];
+        mn = (mn != mn || gmin != gmin) ? __builtin_nan("") : (gmin < mn || (gmin == mn && __builtin_signbit(gmin))) ? gmin : mn;
+        mx = (mx != mx || gmax != gmax) ? __builtin_nan("") : (gmax > mx || (gmax == mx && !__builtin_signbit(gmax))) ? gmax : mx;
+    }
+    out[(size_t)k * 4 + 0] = sum; out[(size_t)k * 4 + 1] = sumsq; out[(size_t)k * 4 + 2] = mn; out[(size_t)k * 4 + 3] = mx;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers (the only functions the runtime calls)
 // ---------------------------------------------------------------------------------------------
@@ -428,7 +446,15 @@ hipError_t preload_kernels()
     if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_bm_kernel));
     if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_fill_kernel));
     if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_gather_moments_kernel));
+    if (e == hipSuccess) e = hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&fm_combine_moments_kernel));
     return e;
+}
+
+hipError_t launch_combine_moments(const double* gathered, uint32_t world, uint32_t count, double* out, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(fm_combine_moments_kernel, dim3((count + 63u) / 64u), dim3(64), 0, st, gathered, world, count, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_t st)

@@ -83,25 +83,50 @@ void* Pool::alloc(size_t bytes, size_t* cap_out) {
         e = hipMalloc(&base, blocks * cap);
         if (e != hipSuccess && blocks > 1) { (void)hipGetLastError(); blocks = 1; e = hipMalloc(&base, cap); }
     }
-    if (e != hipSuccess) {              // last resort of the reference pool (:340): drop every cached buffer, retry once
+    if (e != hipSuccess) {
+        // The device is full.  (1) Cached slabs go back to the driver — as many as this allocation needs and a little more, not all of
+        // them (the reference's last resort drops every cached buffer, RandomVariableCuda.java:340; here a caller whose collector had
+        // just handed back 290 GB of vectors lost that whole cache to the next 40 KB allocation of an unusual size, and paid for it in
+        // device allocations: 75 s instead of 6 for the calibration of lmm_hip --finmath-like --release-lag-bytes 268435456).
         (void)hipGetLastError();
-        purge();
+        purge(cap + (size_t(256) << 20));
         blocks = 1;
         if (room_for(cap)) e = hipMalloc(&base, cap);
     }
     if (e != hipSuccess) {
+        // (2) Nothing could be given back — slabs are freed whole, and every one of them has a live vector in it — but blocks of a LARGER
+        // size class sit cached: one of them is carved into blocks of this class (a 40 KB buffer for a reduction's partials must not fail
+        // while gigabytes are cached in 4 MB blocks).
         (void)hipGetLastError();
+        if (void* p = borrow(cap)) { misses++; return p; }
         throw Error(FMHIP_ERR_OUT_OF_MEMORY, "device allocation of " + std::to_string(cap) + " bytes failed: " + hipGetErrorString(e) + " (the pool holds " + std::to_string(reserved >> 20) +
                     " MiB, " + std::to_string(in_use >> 20) + " MiB of them in live vectors; " + std::to_string(HEADROOM >> 20) + " MiB of the device are left to the HIP runtime)");
     }
     // (looked up again: purge() above drops the entries of size classes it has emptied — until round 5 a reference taken before the purge
     // was written through here, into a freed map node: heap corruption whenever an allocation of a rarely used size met a full device)
     slab_blocks_[cap] = blocks;
-    slabs_.push_back({ base, cap, blocks });
+    slabs_.push_back({ base, cap, blocks, 0 });
     std::vector<void*>& fl2 = free_[cap];
     for (size_t i = blocks; i-- > 1;) { fl2.push_back((char*)base + i * cap); cached += (int64_t)cap; }
     misses++; reserved += (int64_t)(blocks * cap); in_use += (int64_t)cap;
     peak_reserved = std::max(peak_reserved, reserved);
+    return base;
+}
+
+// A cached block of the smallest larger size class becomes a slab of this one (Slab::parent_cap); purge() hands it back when all its
+// blocks are free again.
+void* Pool::borrow(size_t cap) {
+    size_t best = 0;
+    for (const auto& kv : free_) if (kv.first > cap && !kv.second.empty() && (best == 0 || kv.first < best)) best = kv.first;
+    if (!best) return nullptr;
+    void* base = free_[best].back();
+    free_[best].pop_back();
+    const size_t blocks = best / cap;
+    cached -= (int64_t)best;
+    slabs_.push_back({ base, cap, blocks, best });
+    std::vector<void*>& fl = free_[cap];
+    for (size_t i = blocks; i-- > 1;) { fl.push_back((char*)base + i * cap); cached += (int64_t)cap; }
+    in_use += (int64_t)cap;
     return base;
 }
 
@@ -110,26 +135,45 @@ void Pool::release(void* p, size_t cap) {
     in_use -= (int64_t)cap; cached += (int64_t)cap;
 }
 
-// Frees every slab whose blocks are ALL back in the free list (a slab with one live vector stays).
-void Pool::purge() {
+// Slabs whose blocks are ALL back in the free list go back to the driver (a slab with one live vector stays) — all of them, or as many as
+// it takes to give back `need` bytes.  Slabs that were carved out of a cached block (borrow) return that block to its own free list first.
+void Pool::purge(size_t need) {
     std::unordered_map<size_t, std::unordered_set<void*>> free_set;
     for (auto& kv : free_) free_set[kv.first].insert(kv.second.begin(), kv.second.end());
+    auto all_free = [&](const Slab& sl) {
+        const std::unordered_set<void*>& fs = free_set[sl.cap];
+        for (size_t i = 0; i < sl.blocks; ++i) if (!fs.count((char*)sl.base + i * sl.cap)) return false;
+        return true;
+    };
     std::vector<Slab> kept;
-    for (const Slab& sl : slabs_) {
+    for (const Slab& sl : slabs_) {                          // carved slabs first: their parents' slabs may become free by it
+        if (!sl.parent_cap) { kept.push_back(sl); continue; }
+        if (!all_free(sl)) { kept.push_back(sl); continue; }
         std::unordered_set<void*>& fs = free_set[sl.cap];
-        bool all_free = true;
-        for (size_t i = 0; i < sl.blocks && all_free; ++i) all_free = fs.count((char*)sl.base + i * sl.cap) != 0;
-        if (!all_free) { kept.push_back(sl); continue; }
+        for (size_t i = 0; i < sl.blocks; ++i) fs.erase((char*)sl.base + i * sl.cap);
+        cached -= (int64_t)(sl.blocks * sl.cap);
+        free_set[sl.parent_cap].insert(sl.base);
+        cached += (int64_t)sl.parent_cap;
+    }
+    slabs_.swap(kept);
+    kept.clear();
+    size_t given_back = 0;
+    for (size_t k = slabs_.size(); k-- > 0;) {                // youngest first: the old slabs hold the state a caller keeps
+        const Slab& sl = slabs_[k];
+        if (sl.parent_cap || given_back >= need || !all_free(sl)) { kept.push_back(sl); continue; }
+        std::unordered_set<void*>& fs = free_set[sl.cap];
         for (size_t i = 0; i < sl.blocks; ++i) fs.erase((char*)sl.base + i * sl.cap);
         (void)hipFree(sl.base);
         reserved -= (int64_t)(sl.blocks * sl.cap); cached -= (int64_t)(sl.blocks * sl.cap);
+        given_back += sl.blocks * sl.cap;
     }
+    std::reverse(kept.begin(), kept.end());
     slabs_.swap(kept);
-    for (auto& kv : free_) { kv.second.assign(free_set[kv.first].begin(), free_set[kv.first].end()); }
-    for (auto it = free_.begin(); it != free_.end();) it = it->second.empty() ? free_.erase(it) : std::next(it);
+    free_.clear();
+    for (auto& kv : free_set) if (!kv.second.empty()) free_[kv.first].assign(kv.second.begin(), kv.second.end());
     for (auto it = slab_blocks_.begin(); it != slab_blocks_.end();) {       // size classes without slabs start small again
         bool any = false;
-        for (const Slab& sl : slabs_) any |= sl.cap == it->first;
+        for (const Slab& sl : slabs_) any |= sl.cap == it->first && !sl.parent_cap;
         it = any ? std::next(it) : slab_blocks_.erase(it);
     }
 }
@@ -417,7 +461,8 @@ void Engine::node_maybe_free(Node* nd) {
     if (nd->refs_ext > 0 || nd->refs_int > 0) return;
     if (nd->buf) buffer_unref(nd->buf);
     else { pend_erase(nd); drop_expression(nd); }
-    if (node_pool_.size() < 65536) node_pool_.push_back(nd); else delete nd;
+    static const size_t NODE_POOL_CAP = [] { const char* e = std::getenv("FMHIP_NODE_POOL_CAP"); return e ? (size_t)std::atoll(e) : (size_t)65536; }();      // (measured under a lagging collector: recycling ALL the nodes a burst of releases frees — random addresses — is no faster than fresh, consecutive ones)
+    if (node_pool_.size() < NODE_POOL_CAP) node_pool_.push_back(nd); else delete nd;      // (a collector's burst frees hundreds of thousands at once: they are the next ones handed out, most recently touched first)
 }
 
 void Engine::retain(fmhip_vec h) { require_init(); node(h)->refs_ext++; }
@@ -433,9 +478,15 @@ void Engine::drain_late() {
     std::vector<fmhip_vec> batch;
     { std::lock_guard<std::mutex> lock(late_mu_); batch.swap(late_); late_count_.store(0, std::memory_order_release); }
     if (!initialized_) return;
-    for (fmhip_vec h : batch) {
-        Node* nd = owner_of(h) == index_ ? nodes_.get(h) : nullptr;     // (a handle that is not one: nobody is left to tell)
-        if (nd && --nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
+    // (the nodes of handles that died a while ago are cold: their addresses are looked up a few ahead and fetched while the ones before are dealt with)
+    static const size_t AHEAD = [] { const char* e = std::getenv("FMHIP_DRAIN_PREFETCH"); return e ? (size_t)std::atoll(e) : (size_t)8; }();
+    std::vector<Node*> nds(batch.size());
+    for (size_t i = 0; i < batch.size(); ++i) nds[i] = owner_of(batch[i]) == index_ ? nodes_.get(batch[i]) : nullptr;     // (a handle that is not one: nobody is left to tell)
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (AHEAD && i + AHEAD < batch.size() && nds[i + AHEAD]) __builtin_prefetch(nds[i + AHEAD], 1, 1);
+        Node* nd = nds[i];
+        if (!nd || nodes_.get(batch[i]) != nd) continue;             // (released twice in one batch: the second is not a handle any more)
+        if (--nd->refs_ext == 0) { nodes_.erase(batch[i]); node_maybe_free(nd); }
     }
 }
 
@@ -1024,6 +1075,8 @@ static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is
 
 void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
 static const size_t SPECULATE_PENDING = [] { const char* e = std::getenv("FMHIP_SPECULATE_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)5000; }();   // operations recorded since the last time step; 0 = off
+static const size_t SPECULATE_IDLE_MIN = [] { const char* e = std::getenv("FMHIP_SPECULATE_IDLE_MIN"); return e ? (size_t)std::atoll(e) : (size_t)0; }();   // 0 (default) = the device's idleness is not looked at.  Measured, lmm_hip --finmath-like at 1 M paths on one box: off 4.68 s; 512 / 1024 / 2048 / 4096: 5.26 / 4.89 / 4.96 / 4.90 s —
+                                                         // chains cut wherever the device happens to run dry are shapes that never repeat (70 kernels compiled instead of 38, 4–12 k launches on the interpreter)
 static const size_t FUSION_SOFT_CAP = 32768;     // pending operations at which a SOFT hold (fmhip_fusion_hold(2)) executes everything
 // Experiment knob (off): execute everything once this many operations are pending anywhere, instead of the per-handle weight rule.
 // On the hint-free LMM calibration (lmm_hip --finmath-like) 1000 … 16000 gave 15-18 ms per evaluation against 22.8 with the
@@ -1065,7 +1118,12 @@ fmhip_vec Engine::call(int opcode, int n_in, const fmhip_vec* in, double scalar,
     if (!fusion || (w > FUSION_MAX_WEIGHT && !held)) {
         try { materialize({nd}); }
         catch (...) { nd->refs_ext = 0; nodes_.erase(nd->id); node_maybe_free(nd); throw; }
-    } else if (SPECULATE_PENDING && group_hold_ && fusion_hold == 0 && ops_since_boundary_ > SPECULATE_PENDING) {
+    } else if (SPECULATE_PENDING && group_hold_ && fusion_hold == 0 &&
+               (ops_since_boundary_ > SPECULATE_PENDING ||
+                // … or much sooner when the device has NOTHING to do (asked every 128 methods, from SPECULATE_IDLE_MIN pending ones on): the
+                // caller records the payoffs behind a simulation whose launches have drained — whatever is complete enough to run keeps the
+                // device busy while the recording goes on.  The count above is the cut for a device that is still busy: larger launches.
+                (SPECULATE_IDLE_MIN && ops_since_boundary_ >= SPECULATE_IDLE_MIN && (ops_since_boundary_ & 127) == 0 && hipStreamQuery(stream_) == hipSuccess))) {
         // The engine's own hold (time steps being grouped), no new time step for thousands of operations, and a caller that keeps
         // recording without asking for anything (the payoffs of its products, behind the simulation): what is pending runs now, without
         // waiting for it, and the launches take the moments of their roots along — when the caller comes to ask for expectations

@@ -41,10 +41,11 @@ class Pool {
 public:
     void* alloc(size_t bytes, size_t* cap_out);       // throws Error(OOM)
     void  release(void* p, size_t cap);               // back to the free list (stream-ordered reuse)
-    void  purge();                                    // hipFree everything cached
+    void  purge(size_t need = ~size_t(0));            // hipFree what is cached: everything, or slabs until `need` bytes have gone back to the driver
     int64_t reserved = 0, in_use = 0, cached = 0, hits = 0, misses = 0, peak_reserved = 0;
 private:
-    struct Slab { void* base; size_t cap; size_t blocks; };
+    struct Slab { void* base; size_t cap; size_t blocks; size_t parent_cap; };       // parent_cap != 0: carved out of a cached block of that size class (borrow)
+    void* borrow(size_t cap);
     std::unordered_map<size_t, std::vector<void*>> free_;
     std::vector<Slab> slabs_;
     std::unordered_map<size_t, size_t> slab_blocks_;       // blocks of the last slab per size class (geometric growth)

@@ -1,6 +1,10 @@
 // sharded.cpp — see sharded.hpp: one engine and one worker thread per device of a device list, the caller's C-ABI calls replayed on all.
 #include "sharded.hpp"
 #include "runtime.hpp"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <atomic>
 #include <chrono>
@@ -70,37 +74,29 @@ private:
     size_t size_ = 0;
 };
 
-// A queued call.  The calls a Monte-Carlo caller makes by the million — a method, a release — travel as plain data; everything else as a closure.
+// A queued call: plain data.  The calls a Monte-Carlo caller makes by the million — a method, a release — carry their operands; everything
+// else names a closure kept beside the ring (Shards::fns).  `target`: the shard the command is for, or -1 for all of them.
 struct Cmd {
     enum Kind : uint8_t { FN, CALL, RELEASE, RETAIN } kind = FN;
     bool has_scalar = false, last = false;
+    int8_t target = -1;
     int32_t opcode = 0, n_in = 0;
     fmhip_vec a0 = 0, a1 = 0, a2 = 0, id = 0;
     double scalar = 0.0;
-    Command fn;
 };
+
+struct Shards;
 
 struct Worker {
     int shard = 0, shards = 1, device = 0;
     Engine* engine = nullptr;
+    Shards* front = nullptr;
     std::thread thread;
-    // The command queue: a single-producer (the front, one caller at a time under its mutex) single-consumer ring.  A recorded method is
-    // ≈ 50 ns of work for an engine, so the hand-over must not cost much more: plain-data commands, no lock and no system call while the
-    // worker is awake, and the producer makes its commands visible (one store to a cache line the consumer polls) every eighth command
-    // and whenever somebody is about to wait — a mutex + condition variable per command was 5 µs per method (the futex wake of a worker
-    // that had just gone back to sleep: 20 s instead of 2.3 for the calibration on 2 shards), a published tail per command 0.45 µs per
-    // method and shard (the line bounces between the two cores with every command).  A worker that finds nothing spins for a while, then
-    // sleeps with a timeout: a tail the producer has not announced to a sleeper is found within a millisecond.
-    static constexpr size_t RING = size_t(1) << 15;
-    std::vector<Cmd> ring = std::vector<Cmd>(RING);
-    alignas(64) std::atomic<uint64_t> head{ 0 };        // next slot the worker takes
-    alignas(64) std::atomic<uint64_t> tail{ 0 };        // slots below this one are filled (published)
-    alignas(64) uint64_t tail_local = 0;                // producer's own count (ahead of `tail` by at most 7)
-    uint64_t head_seen = 0;                             // producer's last look at `head`
-    std::mutex mu;
-    std::condition_variable cv;
-    std::atomic<bool> sleeping{ false };
-    std::atomic<bool> quit{ false };
+    alignas(64) std::atomic<uint64_t> head{ 0 };        // next slot of the front's ring this worker takes (its own line: the producer reads it when the ring looks full)
+    alignas(64) std::atomic<bool> quit{ false };
+    // the expectation collective (front::reduce_moments_batch_devices): this shard's device buffer [shard][vector][Σ, Σ², min, max] — its own
+    // block filled by its launches, the others' by the all-gather — and the stream everything of this shard is ordered on
+    fmhip_vec gather_vec = 0; double* gather_ptr = nullptr; size_t gather_doubles = 0; void* stream = nullptr;
     // worker-side tables: the front's numbers → this engine's handles
     PagedTable<fmhip_vec> local;
     std::unordered_map<int64_t, fmhip_program> programs;
@@ -110,74 +106,16 @@ struct Worker {
     int error_code = FMHIP_OK;
     std::string error_message;
 
-    fmhip_vec at(fmhip_vec front) { const fmhip_vec* h = local.get(front); return h ? *h : 0; }
-    void bind(fmhip_vec front, fmhip_vec mine) { local.put(front, mine); }
+    fmhip_vec at(fmhip_vec front_handle) { const fmhip_vec* h = local.get(front_handle); return h ? *h : 0; }
+    void bind(fmhip_vec front_handle, fmhip_vec mine) { local.put(front_handle, mine); }
     bool ok(int status) {
         if (status == FMHIP_OK) return true;
         std::lock_guard<std::mutex> lk(error_mu);
         if (error_code == FMHIP_OK) { error_code = status; error_message = "device shard " + std::to_string(shard) + ": " + fmhip_last_error(); }
         return false;
     }
-    Cmd& slot() {                                       // the next slot to fill (producer)
-        if (tail_local - head_seen >= RING) {           // looks full: look again, wait if it is
-            publish();
-            while (tail_local - (head_seen = head.load(std::memory_order_acquire)) >= RING) std::this_thread::yield();
-        }
-        return ring[(size_t)(tail_local & (RING - 1))];
-    }
-    void pushed() { if ((++tail_local & 7u) == 0) publish(); }
-    void publish() {
-        if (tail.load(std::memory_order_relaxed) == tail_local) return;
-        tail.store(tail_local, std::memory_order_seq_cst);
-        if (sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(mu); cv.notify_one(); }
-    }
-    void post(Command c) { Cmd& x = slot(); x.kind = Cmd::FN; x.fn = std::move(c); pushed(); publish(); }      // (closures are the rare calls: visible at once)
-    void stop() { publish(); quit.store(true, std::memory_order_seq_cst); std::lock_guard<std::mutex> lk(mu); cv.notify_one(); }
-    void execute(Cmd& x) {
-        switch (x.kind) {
-        case Cmd::CALL: {
-            fmhip_vec h = 0;
-            int st;
-            if (x.n_in == 1) st = x.has_scalar ? fmhip_call_v1s1(x.opcode, at(x.a0), x.scalar, &h) : fmhip_call_v1s0(x.opcode, at(x.a0), &h);
-            else if (x.n_in == 2) st = x.has_scalar ? fmhip_call_v2s1(x.opcode, at(x.a0), at(x.a1), x.scalar, &h) : fmhip_call_v2s0(x.opcode, at(x.a0), at(x.a1), &h);
-            else st = fmhip_call_v3s0(x.opcode, at(x.a0), at(x.a1), at(x.a2), &h);
-            if (ok(st)) bind(x.id, h);
-            break; }
-        case Cmd::RELEASE: ok(fmhip_vec_release(at(x.a0))); if (x.last) local.erase(x.a0); break;
-        case Cmd::RETAIN: ok(fmhip_vec_retain(at(x.a0))); break;
-        case Cmd::FN: { Command f = std::move(x.fn); x.fn = nullptr; f(*this); break; }
-        }
-    }
-    void run() {
-        Engine::bind_thread(engine);
-        for (;;) {
-            const uint64_t h = head.load(std::memory_order_relaxed);
-            if (tail.load(std::memory_order_acquire) == h) {
-                bool found = false;
-                for (int spin = 0; spin < 4000 && !found; ++spin) {
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                    found = tail.load(std::memory_order_acquire) != h;
-                }
-                if (!found) {
-                    std::unique_lock<std::mutex> lk(mu);
-                    sleeping.store(true, std::memory_order_seq_cst);
-                    // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be pthread_cond_clockwait, which this toolchain's ThreadSanitizer does not model)
-                    cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(1), [&] { return tail.load(std::memory_order_seq_cst) != h || quit.load(std::memory_order_seq_cst); });
-                    sleeping.store(false, std::memory_order_seq_cst);
-                    if (tail.load(std::memory_order_seq_cst) == h && quit.load()) break;
-                }
-                continue;
-            }
-            Cmd& x = ring[(size_t)(h & (RING - 1))];
-            try { execute(x); }
-            catch (const Error& e) { std::lock_guard<std::mutex> lk(error_mu); if (error_code == FMHIP_OK) { error_code = e.code; error_message = "device shard " + std::to_string(shard) + ": " + e.what(); } }
-            catch (const std::exception& e) { std::lock_guard<std::mutex> lk(error_mu); if (error_code == FMHIP_OK) { error_code = FMHIP_ERR_HIP; error_message = "device shard " + std::to_string(shard) + ": " + e.what(); } }
-            head.store(h + 1, std::memory_order_release);
-        }
-        Engine::bind_thread(nullptr);
-    }
+    void execute(const Cmd& x, uint64_t position);
+    void run();
 };
 
 struct Meta { int64_t n = 0; int refs = 0; };
@@ -192,9 +130,70 @@ struct Shards {
     std::unordered_map<int64_t, int> tickets;          // front ticket → count
     int64_t next_other = 1;                            // program and ticket numbers
     int fusion = 0, hold = 0, group_steps = 4, math_mode = FMHIP_MATH_EXACT, jit_mode = FMHIP_JIT_AUTO;
+    // The one exchange between devices ("single-process ncclCommInitAll … inside ncclGroupStart/End"): a communicator per
+    // listed device when the devices are DISTINCT and RCCL is there (looked up at run time: the library does not link it — a process with
+    // one device never needs it); otherwise (an index repeats: shards of one device, the one-GPU test rig) expectations wanted on the
+    // devices are combined on the host and copied back.  collective: 1 = RCCL, 2 = host combine.
+    std::vector<ncclComm_t> comms;
+    int collective = 2;
+    std::string collective_why;
+    struct Rccl {
+        void* lib = nullptr;
+        decltype(&ncclCommInitAll) CommInitAll = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclGroupStart) GroupStart = nullptr;
+        decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclAllGather) AllGather = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+        bool load() {
+            auto sym = [&](const char* name) -> void* { void* p = dlsym(RTLD_DEFAULT, name); if (!p && lib) p = dlsym(lib, name); return p; };
+            if (!dlsym(RTLD_DEFAULT, "ncclCommInitAll")) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); }
+            CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy"); GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+            GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd"); AllGather = (decltype(AllGather))sym("ncclAllGather"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+            return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && GetErrorString;
+        }
+    } rccl;
+
+    // The command queue: ONE ring for all shards — the producer (the front, one caller at a time under its mutex) writes a command once,
+    // every worker reads it with a head of its own; a slot is written again when the slowest head has passed it.  A recorded method is
+    // ≈ 50 ns of work for an engine, so the hand-over must not cost much more, and must not grow with the number of shards (until round 5:
+    // one ring per worker and one copy of every command per shard — the caller's thread was the bound from a handful of shards on): plain
+    // data, no lock and no system call while the workers are awake; the producer makes its commands visible (one store to a line the
+    // consumers poll) every eighth command and whenever somebody is about to wait.  A worker that finds nothing spins for ≈ 50 µs, then
+    // sleeps with a timeout: a tail the producer has not announced to a sleeper is found within a millisecond.
+    static constexpr size_t RING = size_t(1) << 15;
+    std::vector<Cmd> ring = std::vector<Cmd>(RING);
+    std::vector<Command> fns = std::vector<Command>(RING);                  // the closure of slot i (Cmd::FN), dropped by the last worker that has run it
+    std::unique_ptr<std::atomic<int>[]> fn_left{ new std::atomic<int>[RING]() };
+    alignas(64) std::atomic<uint64_t> tail{ 0 };        // slots below this one are filled (published)
+    alignas(64) uint64_t tail_local = 0;                // producer's own count (ahead of `tail` by at most 7)
+    uint64_t head_seen = 0;                             // producer's last look at the slowest head
+    std::mutex sleep_mu;
+    std::condition_variable sleep_cv;
+    std::atomic<int> sleeping{ 0 };
 
     int D() const { return (int)workers.size(); }
-    void post(const Command& c) { for (auto& w : workers) w->post(c); }
+    uint64_t slowest_head() const { uint64_t h = ~uint64_t(0); for (const auto& w : workers) h = std::min(h, w->head.load(std::memory_order_acquire)); return h; }
+    size_t next_slot() {                                // the index of the next slot to fill (producer)
+        if (tail_local - head_seen >= RING) {           // looks full: look again, wait if it is
+            publish();
+            while (tail_local - (head_seen = slowest_head()) >= RING) std::this_thread::yield();
+        }
+        return (size_t)(tail_local & (RING - 1));
+    }
+    Cmd& slot() { return ring[next_slot()]; }
+    void pushed() { if ((++tail_local & 7u) == 0) publish(); }
+    void publish() {
+        if (tail.load(std::memory_order_relaxed) == tail_local) return;
+        tail.store(tail_local, std::memory_order_seq_cst);
+        if (sleeping.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(sleep_mu); sleep_cv.notify_all(); }
+    }
+    // a closure for one shard (target >= 0) or for all: stored once, visible at once (closures are the rare calls)
+    void post(Command c, int target = -1) {
+        const size_t i = next_slot();
+        Cmd& x = ring[i];
+        x = Cmd(); x.kind = Cmd::FN; x.target = (int8_t)target;
+        fns[i] = std::move(c);
+        fn_left[i].store(D(), std::memory_order_release);
+        pushed(); publish();
+    }
+    void stop_workers() { publish(); for (auto& w : workers) w->quit.store(true, std::memory_order_seq_cst); std::lock_guard<std::mutex> lk(sleep_mu); sleep_cv.notify_all(); }
     // waits until every worker has run everything posted so far; then the first error any shard has met (shard order) is thrown
     void wait() {
         std::mutex m; std::condition_variable cv; int left = D();
@@ -218,6 +217,58 @@ struct Shards {
     }
     fmhip_vec fresh(int64_t n) { const fmhip_vec id = next_vec++; meta.put(id, Meta{ n, 1 }); return id; }
 };
+
+void Worker::execute(const Cmd& x, uint64_t position) {
+    switch (x.kind) {
+    case Cmd::CALL: {
+        fmhip_vec h = 0;
+        int st;
+        if (x.n_in == 1) st = x.has_scalar ? fmhip_call_v1s1(x.opcode, at(x.a0), x.scalar, &h) : fmhip_call_v1s0(x.opcode, at(x.a0), &h);
+        else if (x.n_in == 2) st = x.has_scalar ? fmhip_call_v2s1(x.opcode, at(x.a0), at(x.a1), x.scalar, &h) : fmhip_call_v2s0(x.opcode, at(x.a0), at(x.a1), &h);
+        else st = fmhip_call_v3s0(x.opcode, at(x.a0), at(x.a1), at(x.a2), &h);
+        if (ok(st)) bind(x.id, h);
+        break; }
+    case Cmd::RELEASE: ok(fmhip_vec_release(at(x.a0))); if (x.last) local.erase(x.a0); break;
+    case Cmd::RETAIN: ok(fmhip_vec_retain(at(x.a0))); break;
+    case Cmd::FN: {
+        const size_t i = (size_t)(position & (Shards::RING - 1));
+        struct Last { Shards* f; size_t i; ~Last() { if (f->fn_left[i].fetch_sub(1, std::memory_order_acq_rel) == 1) f->fns[i] = nullptr; } } last{ front, i };      // (whoever runs it last lets the closure go)
+        if (x.target < 0 || x.target == shard) front->fns[i](*this);
+        break; }
+    }
+}
+
+void Worker::run() {
+    Engine::bind_thread(engine);
+    Shards& f = *front;
+    for (;;) {
+        const uint64_t h = head.load(std::memory_order_relaxed);
+        if (f.tail.load(std::memory_order_acquire) == h) {
+            bool found = false;
+            for (int spin = 0; spin < 2000 && !found; ++spin) {           // ≈ 50 µs
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                found = f.tail.load(std::memory_order_acquire) != h;
+            }
+            if (!found) {
+                std::unique_lock<std::mutex> lk(f.sleep_mu);
+                f.sleeping.fetch_add(1, std::memory_order_seq_cst);
+                // (wait_until on the system clock = pthread_cond_timedwait; wait_for would be pthread_cond_clockwait, which this toolchain's ThreadSanitizer does not model)
+                f.sleep_cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::milliseconds(1), [&] { return f.tail.load(std::memory_order_seq_cst) != h || quit.load(std::memory_order_seq_cst); });
+                f.sleeping.fetch_sub(1, std::memory_order_seq_cst);
+                if (f.tail.load(std::memory_order_seq_cst) == h && quit.load()) break;
+            }
+            continue;
+        }
+        const Cmd x = f.ring[(size_t)(h & (Shards::RING - 1))];
+        try { execute(x, h); }
+        catch (const Error& e) { std::lock_guard<std::mutex> lk(error_mu); if (error_code == FMHIP_OK) { error_code = e.code; error_message = "device shard " + std::to_string(shard) + ": " + e.what(); } }
+        catch (const std::exception& e) { std::lock_guard<std::mutex> lk(error_mu); if (error_code == FMHIP_OK) { error_code = FMHIP_ERR_HIP; error_message = "device shard " + std::to_string(shard) + ": " + e.what(); } }
+        head.store(h + 1, std::memory_order_release);
+    }
+    Engine::bind_thread(nullptr);
+}
 
 Shards* g_shards = nullptr;                            // non-null while a device list is active
 std::mutex g_shards_mu;
@@ -273,18 +324,34 @@ int init_devices(const int* devices, int count) {
             std::unique_ptr<Worker> w(new Worker());
             w->shard = d; w->shards = count; w->device = devices[d];
             w->engine = Engine::create();
+            w->front = s.get();
             s->workers.push_back(std::move(w));
         }
         for (auto& w : s->workers) { Worker* p = w.get(); p->thread = std::thread([p] { p->run(); }); }
-        for (auto& w : s->workers) { const int device = w->device; w->post([device](Worker& me) { me.ok(fmhip_init(device)); }); }
+        s->post([](Worker& me) { me.ok(fmhip_init(me.device)); });
         auto tear_down = [&]() {
-            for (auto& w : s->workers) { w->post([](Worker&) { (void)fmhip_shutdown(); }); w->stop(); }
+            s->post([](Worker&) { (void)fmhip_shutdown(); });
+            s->stop_workers();
             for (auto& w : s->workers) { if (w->thread.joinable()) w->thread.join(); delete w->engine; w->engine = nullptr; }
         };
         try { s->wait(); } catch (...) { tear_down(); throw; }
         // what the engines read from the environment at initialisation
-        s->workers[0]->post([&s](Worker&) { Engine& e = Engine::get(); s->group_steps = e.group_steps; s->jit_mode = e.jit_mode; });
+        s->post([&s](Worker&) { Engine& e = Engine::get(); s->group_steps = e.group_steps; s->jit_mode = e.jit_mode; }, 0);
         s->wait();
+        {   // the expectation collective: RCCL over the listed devices when they are distinct
+            bool distinct = true;
+            for (int d = 0; d < count; ++d) for (int e = 0; e < d; ++e) distinct &= devices[d] != devices[e];
+            static const bool WANT = [] { const char* e = std::getenv("FMHIP_DEVICE_LIST_RCCL"); return !(e && e[0] == '0'); }();
+            if (!distinct) s->collective_why = "a device index repeats (shards of one device): expectations wanted on the devices are combined on the host";
+            else if (!WANT) s->collective_why = "FMHIP_DEVICE_LIST_RCCL=0";
+            else if (!s->rccl.load()) s->collective_why = "librccl.so not found";
+            else {
+                s->comms.assign((size_t)count, nullptr);
+                const ncclResult_t r = s->rccl.CommInitAll(s->comms.data(), count, devices);
+                if (r != ncclSuccess) { s->comms.clear(); s->collective_why = std::string("ncclCommInitAll: ") + s->rccl.GetErrorString(r); }
+                else s->collective = 1;
+            }
+        }
         g_shards = s.release();
         return FMHIP_OK;
     } catch (const Error& e) { set_last_error(e.what()); return e.code; }
@@ -297,7 +364,12 @@ int shutdown() {
     if (!s) return FMHIP_OK;
     {
         std::lock_guard<std::mutex> lk2(s->mu);
-        for (auto& w : s->workers) { w->post([](Worker&) { (void)fmhip_shutdown(); }); w->stop(); }
+        s->post([](Worker& w) { (void)fmhip_synchronize(); if (w.gather_vec) { (void)fmhip_vec_release(w.gather_vec); w.gather_vec = 0; } });
+        try { s->wait(); } catch (...) {}
+        for (ncclComm_t c : s->comms) if (c) (void)s->rccl.CommDestroy(c);
+        s->comms.clear();
+        s->post([](Worker&) { (void)fmhip_shutdown(); });
+        s->stop_workers();
         for (auto& w : s->workers) { if (w->thread.joinable()) w->thread.join(); delete w->engine; w->engine = nullptr; }
         g_shards = nullptr;
     }
@@ -307,15 +379,11 @@ int shutdown() {
 
 int device_info(char* name_buf, int name_buf_len, int* n_compute_units, int64_t* hbm_bytes) {
     return fronted([&](Shards& s) {
-        int64_t total = 0;
         std::vector<int64_t> hbm((size_t)s.D(), 0);
-        for (auto& w : s.workers) {
-            int64_t* mine = &hbm[(size_t)w->shard];
-            const bool first = w->shard == 0;
-            w->post([=](Worker& me) { me.ok(fmhip_device_info(first ? name_buf : nullptr, first ? name_buf_len : 0, first ? n_compute_units : nullptr, mine)); });
-        }
+        s.post([=, &hbm](Worker& me) { const bool first = me.shard == 0; me.ok(fmhip_device_info(first ? name_buf : nullptr, first ? name_buf_len : 0, first ? n_compute_units : nullptr, &hbm[(size_t)me.shard])); });
         s.wait();
-        for (int64_t b : hbm) total += b;
+        int64_t total = 0;                                     // the memory of every DISTINCT device of the list (an index may repeat: shards of one device)
+        for (int d = 0; d < s.D(); ++d) { bool seen = false; for (int e = 0; e < d; ++e) seen |= s.workers[(size_t)e]->device == s.workers[(size_t)d]->device; if (!seen) total += hbm[(size_t)d]; }
         if (hbm_bytes) *hbm_bytes = total;
     });
 }
@@ -335,7 +403,8 @@ int vec_create_from_host(const void* host, bool is_double, int64_t n, fmhip_vec*
             const int st = is_double ? fmhip_vec_create_from_double((const double*)host + off, cnt, &h) : fmhip_vec_create_from_float((const float*)host + off, cnt, &h);
             if (w.ok(st)) w.bind(id, h);
         });
-        try { s.wait(); } catch (...) { s.meta.erase(id); throw; }
+        // (a shard that failed leaves the others with a block bound under this number: they give it back)
+        try { s.wait(); } catch (...) { s.post([=](Worker& w) { if (const fmhip_vec h = w.at(id)) { (void)fmhip_vec_release(h); w.local.erase(id); } }); s.meta.erase(id); throw; }
         *out = id;
     });
 }
@@ -357,14 +426,14 @@ int vec_create_filled(int64_t n, double value, bool initialised, fmhip_vec* out)
 int vec_retain(fmhip_vec v) {
     return fronted([&](Shards& s) {
         s.vec(v).refs++;
-        for (auto& w : s.workers) { Cmd& x = w->slot(); x.kind = Cmd::RETAIN; x.a0 = v; w->pushed(); }
+        Cmd& x = s.slot(); x = Cmd(); x.kind = Cmd::RETAIN; x.a0 = v; s.pushed();
     });
 }
 int vec_release(fmhip_vec v) {
     return fronted([&](Shards& s) {
         const bool last = --s.vec(v).refs == 0;
         if (last) s.meta.erase(v);
-        for (auto& w : s.workers) { Cmd& x = w->slot(); x.kind = Cmd::RELEASE; x.a0 = v; x.last = last; w->pushed(); }
+        Cmd& x = s.slot(); x = Cmd(); x.kind = Cmd::RELEASE; x.a0 = v; x.last = last; s.pushed();
     });
 }
 int vec_size(fmhip_vec v, int64_t* n_out) { return fronted([&](Shards& s) { need(n_out, "n_out"); *n_out = s.vec(v).n; }); }
@@ -397,12 +466,10 @@ int call(int opcode, int n_in, const fmhip_vec* in, double scalar, bool has_scal
             a[i] = in[i];
         }
         const fmhip_vec id = s.fresh(n);
-        for (auto& w : s.workers) {
-            Cmd& x = w->slot();
-            x.kind = Cmd::CALL; x.opcode = opcode; x.n_in = n_in; x.has_scalar = has_scalar; x.scalar = scalar;
-            x.a0 = a[0]; x.a1 = a[1]; x.a2 = a[2]; x.id = id;
-            w->pushed();
-        }
+        Cmd& x = s.slot();                                     // written ONCE, whatever the number of shards
+        x.kind = Cmd::CALL; x.has_scalar = has_scalar; x.last = false; x.target = -1; x.opcode = opcode; x.n_in = n_in; x.scalar = scalar;
+        x.a0 = a[0]; x.a1 = a[1]; x.a2 = a[2]; x.id = id;
+        s.pushed();
         *out = id;
     });
 }
@@ -459,10 +526,10 @@ int graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int 
         if (n_roots <= 0 || !roots) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "no roots");
         for (int r = 0; r < n_roots; ++r) (void)s.vec(roots[r]);
         std::vector<fmhip_vec> r(roots, roots + n_roots);
-        s.workers[0]->post([&](Worker& w) {                   // every shard holds the same graph: shard 0 answers
+        s.post([&](Worker& w) {                                // every shard holds the same graph: shard 0 answers
             std::vector<fmhip_vec> lr; for (fmhip_vec h : r) lr.push_back(w.at(h));
             w.ok(fmhip_graph_scalars(lr.data(), n_roots, scalars_out, capacity, n_scalars));
-        });
+        }, 0);
         s.wait();
     });
 }
@@ -522,6 +589,86 @@ int reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count)
     });
 }
 
+// The expectations of `count` vectors ON THE DEVICES: device_out[d] (a buffer of count x 32 bytes on the d-th listed device; nullptr: not
+// wanted there) receives the moments of the WHOLE vectors — all shards combined in shard order, the same bits on every device.
+// Every shard's launches leave its moments in its block of its own gather buffer; ONE all-gather, issued for all devices from this thread
+// inside ncclGroupStart / ncclGroupEnd on the shards' streams, makes every device hold all blocks; fm_combine_moments_kernel combines
+// them per device.  Nothing waits for the devices here: the results are ordered on the shards' streams (fmhip_get_stream_of).  With a
+// repeated device index (or without RCCL) the shards' blocks are read back, combined on the host and copied to the devices.
+int reduce_moments_batch_devices(const fmhip_vec* vectors, int count, const double* shifts, void* const* device_out, int n_devices) {
+    return fronted([&](Shards& s) {
+        need(vectors, "vectors"); need(device_out, "device_out");
+        if (count <= 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "count must be positive");
+        const int D = s.D();
+        if (n_devices != D) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "one output pointer per listed device: " + std::to_string(D) + " expected, " + std::to_string(n_devices) + " given");
+        for (int i = 0; i < count; ++i) if (s.vec(vectors[i]).n != s.vec(vectors[0]).n) throw Error(FMHIP_ERR_SIZE_MISMATCH, "batched reduction over vectors of different size");
+        const size_t block = (size_t)count * 4;                // doubles per shard
+        s.post([&](Worker& w) {
+            if (w.gather_doubles < block * (size_t)w.shards) {
+                if (w.gather_vec) { w.ok(fmhip_vec_release(w.gather_vec)); w.gather_vec = 0; w.gather_ptr = nullptr; w.gather_doubles = 0; }
+                const size_t want = std::max(block * (size_t)w.shards, (size_t)4096);
+                fmhip_vec h = 0; void* p = nullptr;
+                if (!w.ok(fmhip_vec_create_uninitialized((int64_t)want * 2, &h)) || !w.ok(fmhip_vec_device_ptr(h, &p))) { if (h) (void)fmhip_vec_release(h); return; }
+                w.gather_vec = h; w.gather_ptr = (double*)p; w.gather_doubles = want;
+            }
+            std::vector<fmhip_vec> l; for (int i = 0; i < count; ++i) l.push_back(w.at(vectors[i]));
+            w.ok(fmhip_reduce_moments_batch_device(l.data(), count, shifts, w.gather_ptr + block * (size_t)w.shard));
+            w.ok(fmhip_get_stream(&w.stream));
+        });
+        s.wait();
+        if (s.collective == 1) {
+            auto nccl = [&](ncclResult_t r, const char* what) { if (r != ncclSuccess) throw Error(FMHIP_ERR_HIP, std::string(what) + ": " + s.rccl.GetErrorString(r)); };
+            nccl(s.rccl.GroupStart(), "ncclGroupStart");
+            ncclResult_t first = ncclSuccess;
+            for (int d = 0; d < D; ++d) {
+                Worker& w = *s.workers[(size_t)d];
+                const ncclResult_t r = s.rccl.AllGather(w.gather_ptr + block * (size_t)d, w.gather_ptr, block, ncclDouble, s.comms[(size_t)d], (hipStream_t)w.stream);
+                if (first == ncclSuccess) first = r;
+            }
+            nccl(s.rccl.GroupEnd(), "ncclGroupEnd");
+            nccl(first, "ncclAllGather");
+            for (int d = 0; d < D; ++d) {
+                if (!device_out[d]) continue;
+                Worker& w = *s.workers[(size_t)d];
+                hip_check(hipSetDevice(w.device), "hipSetDevice");
+                hip_check(launch_combine_moments(w.gather_ptr, (uint32_t)D, (uint32_t)count, (double*)device_out[d], (hipStream_t)w.stream), "launch fm_combine_moments_kernel");
+            }
+            return;
+        }
+        // host combine: every shard's block read back, combined, handed to the devices that want it
+        std::vector<std::vector<fmhip_moments>> per((size_t)D, std::vector<fmhip_moments>((size_t)count));
+        s.post([&](Worker& w) {
+            hipError_t e = hipMemcpyAsync(per[(size_t)w.shard].data(), w.gather_ptr + block * (size_t)w.shard, block * 8, hipMemcpyDeviceToHost, (hipStream_t)w.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)w.stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); w.ok(FMHIP_ERR_HIP); }
+        });
+        s.wait();
+        std::vector<fmhip_moments> all((size_t)count);
+        combine(per, count, all.data());
+        s.post([&](Worker& w) {
+            if (!device_out[w.shard]) return;
+            hipError_t e = hipMemcpyAsync(device_out[w.shard], all.data(), block * 8, hipMemcpyHostToDevice, (hipStream_t)w.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)w.stream);      // (`all` is this call's)
+            if (e != hipSuccess) { (void)hipGetLastError(); w.ok(FMHIP_ERR_HIP); }
+        });
+        s.wait();
+    });
+}
+int get_stream_of(int shard, void** stream_out) {
+    return fronted([&](Shards& s) {
+        need(stream_out, "stream_out");
+        if (shard < 0 || shard >= s.D()) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "no such device shard: " + std::to_string(shard));
+        s.post([=](Worker& w) { w.ok(fmhip_get_stream(stream_out)); }, shard);
+        s.wait();
+    });
+}
+int expectation_collective(int* kind, char* why, int why_len) {
+    return fronted([&](Shards& s) {
+        if (kind) *kind = s.collective;
+        if (why && why_len > 0) { std::strncpy(why, s.collective_why.c_str(), (size_t)why_len - 1); why[why_len - 1] = 0; }
+    });
+}
+
 int vec_give_up_values(const fmhip_vec* vectors, int count) {
     return fronted([&](Shards& s) {
         need(vectors, "vectors");
@@ -560,7 +707,7 @@ int program_shape(fmhip_program p, int* n_inputs, int* n_outputs, int* n_reduce)
 int program_tier(fmhip_program p, int* tier, int* vgprs) {
     return fronted([&](Shards& s) {
         if (!s.programs.count(p)) throw Error(FMHIP_ERR_INVALID_HANDLE, "invalid program handle " + std::to_string(p));
-        s.workers[0]->post([=](Worker& w) { w.ok(fmhip_program_tier(w.programs[p], tier, vgprs)); });
+        s.post([=](Worker& w) { w.ok(fmhip_program_tier(w.programs[p], tier, vgprs)); }, 0);
         s.wait();
     });
 }

@@ -11,8 +11,10 @@
 // that return data wait for all shards: a read gathers the blocks by one device-to-host copy per shard, straight into the caller's
 // buffer; host-side moments need NO collective — every shard's launch leaves its 32 bytes in pinned memory, the front adds them in
 // shard order by the rule fmhip_expectation_combine implements (sums in shard order, java.lang.Math.min / max).  Nothing is exchanged
-// between devices.  The *_device variants of the reductions, raw device pointers and the expectation communicator are not available
-// with a device list (they name ONE device).
+// between devices for those.  Expectations wanted ON the devices (fmhip_reduce_moments_batch_devices; the *_device variants deliver to
+// the first listed device) are the one exchange: a grouped RCCL all-gather of the shards' moments over the listed devices and a combine
+// kernel per device — or, where a device index repeats, a host combine.  Raw device pointers of vectors and the expectation communicator
+// are not available with a device list (they name ONE device).
 //
 // The reference has one device index (RandomVariableCuda.java:161,177).  UNMEASURED on more than one physical GPU: the boxes this was
 // built on have one; tests use the device lists {0, 0} and {0, 0, 0} — shards on separate streams of one device.
@@ -45,6 +47,9 @@ int graph_scalars(const fmhip_vec* roots, int n_roots, double* scalars_out, int 
 int reduce_moments_batch(const fmhip_vec* vectors, int count, const double* shifts, fmhip_moments* out);
 int reduce_moments_batch_begin(const fmhip_vec* vectors, int count, const double* shifts, fmhip_ticket* ticket_out);
 int reduce_moments_batch_end(fmhip_ticket ticket, fmhip_moments* out, int count);
+int reduce_moments_batch_devices(const fmhip_vec* vectors, int count, const double* shifts, void* const* device_out, int n_devices);
+int get_stream_of(int shard, void** stream_out);
+int expectation_collective(int* kind, char* why, int why_len);
 int vec_give_up_values(const fmhip_vec* vectors, int count);
 int program_create(const fmhip_prog_op* ops, int n_ops, int n_inputs, const int32_t* out_values, int n_outputs, const int32_t* reduce_values, int n_reduce, fmhip_program* out);
 int program_release(fmhip_program p);

@@ -200,13 +200,16 @@ public:
         on_.store(false);
         collect(false);
     }
-    void died(fmhip_vec h) {                             // a wrapper object has become unreachable
-        std::lock_guard<std::mutex> lock(mu_);
-        dead_.push_back(h); ++stats_.queued;
-        stats_.peakQueue = std::max<long long>(stats_.peakQueue, (long long)dead_.size());
-        if (atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_) full_.store(true, std::memory_order_release);
+    // A wrapper object has become unreachable.  (A JVM pays nothing for this moment; the model pays a push into a buffer of the thread's
+    // own, handed to the shared list 256 at a time — the collector does not see the last few of a thread that has gone quiet, as it would
+    // not see objects that still sit in a register.)
+    void died(fmhip_vec h) {
+        std::vector<fmhip_vec>& mine = local();
+        mine.push_back(h);
+        if (mine.size() >= 256) publish(mine);
     }
     void collect(bool forced) {                          // one collection, on the calling thread
+        publish(local());
         std::vector<fmhip_vec> batch;
         { std::lock_guard<std::mutex> lock(mu_); batch.swap(dead_); full_.store(false, std::memory_order_release); ++stats_.collections; if (forced) ++stats_.forcedCollections; stats_.released += (long long)batch.size(); }
         for (fmhip_vec h : batch) fmhip_vec_release(h);
@@ -214,6 +217,16 @@ public:
     Stats stats() { std::lock_guard<std::mutex> lock(mu_); return stats_; }
     ~ReleaseLag() { quit_.store(true); if (collector_.joinable()) collector_.join(); }
 private:
+    static std::vector<fmhip_vec>& local() { static thread_local std::vector<fmhip_vec> v; return v; }
+    void publish(std::vector<fmhip_vec>& mine) {
+        if (mine.empty()) return;
+        std::lock_guard<std::mutex> lock(mu_);
+        dead_.insert(dead_.end(), mine.begin(), mine.end());
+        stats_.queued += (long long)mine.size();
+        mine.clear();
+        stats_.peakQueue = std::max<long long>(stats_.peakQueue, (long long)dead_.size());
+        if (atBytes_ > 0 && dead_.size() * BYTES_PER_HANDLE >= atBytes_) full_.store(true, std::memory_order_release);
+    }
     void run() {                                         // (sleeps in slices and looks at two flags: no condition variable — the sanitizer builds' libtsan does not know pthread_cond_clockwait)
         using clk = std::chrono::steady_clock;
         auto next = clk::now() + std::chrono::duration_cast<clk::duration>(std::chrono::duration<double, std::milli>(everyMs_ > 0.0 ? everyMs_ : 1e12));

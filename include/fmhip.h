@@ -27,9 +27,13 @@
  *     the boundary as double or float.
  *   - scalars are passed as double and narrowed with (float) before use, as the reference does
  *     (RandomVariableCuda.java:521,533).
- *   - all entry points are thread-safe; device work is enqueued on one in-order stream per process,
- *     only the read/reduce entry points block.
- *   - one process drives one GPU (one rank per GPU under torch.distributed / RCCL).
+ *   - all entry points are thread-safe; device work is enqueued on one in-order stream per engine — one engine per process
+ *     (fmhip_init), per listed device (fmhip_init_devices) or per caller thread (fmhip_set_thread_engines); only the read /
+ *     reduce entry points block.
+ *   - a process drives one GPU (fmhip_init: one rank per GPU under torch.distributed / RCCL) or several (fmhip_init_devices).
+ *   - a handle may be released late and from another thread (a garbage collector's cleaner: what the reference's WeakReference /
+ *     ReferenceQueue pool and the Java binding's Cleaner do): the engine does not decide what to store by live handles, see
+ *     fmhip_engine_stats.
  */
 #ifndef FMHIP_H
 #define FMHIP_H
@@ -140,9 +144,14 @@ int fmhip_init(int device_index);
  * this header works unchanged on the caller's side; handles are the library's own numbers.  An index may repeat (shards on separate
  * streams of one device: how this is tested on a one-GPU box).  Calls that only return handles are queued to one worker thread per
  * device and return at once: an error a device meets later (an allocation that fails) is returned by the next call that waits (a read,
- * a reduction, fmhip_synchronize).  Not available with a device list: fmhip_get_stream, fmhip_vec_device_ptr, the *_device variants
- * of the reductions, device_moments of fmhip_program_run, fmhip_set_expectation_comm.  count == 1 is fmhip_init(devices[0]).
- * UNMEASURED on more than one physical GPU. */
+ * a reduction, fmhip_synchronize).  Expectations wanted ON the devices — fmhip_reduce_moments_batch_devices: a buffer per listed
+ * device; the *_device variants: a buffer on the first listed device — are the ONE exchange between the devices: every shard's launches
+ * leave its moments in a device buffer of its own, one RCCL all-gather issued for all listed devices inside ncclGroupStart /
+ * ncclGroupEnd makes every device hold all of them, a kernel per device combines them in device order (fmhip_expectation_combine's
+ * rule: the same bits everywhere); with a repeated index — or without librccl.so, which is looked up at run time — they are combined
+ * on the host instead (fmhip_expectation_collective tells which).  Not available with a device list: fmhip_get_stream (use
+ * fmhip_get_stream_of), fmhip_vec_device_ptr, device_moments of fmhip_program_run, fmhip_set_expectation_comm with more than one
+ * rank.  count == 1 is fmhip_init(devices[0]).  UNMEASURED on more than one physical GPU. */
 int fmhip_init_devices(const int* devices, int count);
 int fmhip_device_count(int* count);           /* devices (shards) behind the handles: 1 after fmhip_init */
 /* An ENGINE PER CALLER THREAD on the one device of fmhip_init: every thread that calls into the library gets a pending graph, a stream,
@@ -277,6 +286,17 @@ int fmhip_reduce_moments_batch(const fmhip_vec* vectors, int count, const double
 /* Same, results (count x 4 doubles) left in caller-owned DEVICE memory, asynchronous on the runtime stream — the send buffer
  * of the one RCCL all-reduce per objective evaluation when paths are sharded over GPUs. */
 int fmhip_reduce_moments_batch_device(const fmhip_vec* vectors, int count, const double* shifts, void* device_out);
+/* The same ON EVERY DEVICE of a device list (fmhip_init_devices): device_out[d] — a buffer of count x 32 bytes on the d-th listed device,
+ * the caller's own allocation; NULL: not wanted there — receives the moments of the WHOLE vectors, all path shards combined in device
+ * order (bit-identical on every device).  Nothing is waited for: the result is ordered on the shards' streams (fmhip_get_stream_of).
+ * n_devices = fmhip_device_count (with one device: 1, and this is fmhip_reduce_moments_batch_device).  The reference has no counterpart
+ * (one device index: RandomVariableCuda.java:161,177); SURVEY.md §8e. */
+int fmhip_reduce_moments_batch_devices(const fmhip_vec* vectors, int count, const double* shifts, void* const* device_out, int n_devices);
+/* The stream the work of device shard `shard` is ordered on (shard 0 of one device: fmhip_get_stream). */
+int fmhip_get_stream_of(int shard, void** stream_out);
+/* How expectations wanted on the devices of a device list travel: kind 0 = one device, nothing to exchange; 1 = a grouped RCCL all-gather
+ * over the listed devices; 2 = combined on the host (`why`, if given, says why: a repeated device index, librccl.so not found …). */
+int fmhip_expectation_collective(int* kind, char* why, int why_len);
 /* The same reduction in two halves: _begin enqueues it and returns a ticket at once; _end waits for THAT reduction — not for work
  * enqueued after it — writes the `count` moments (the expectation communicator applied, as in fmhip_reduce_moments_batch) and
  * retires the ticket.  A caller that evaluates one parameter set after the other records and enqueues set k+1 between the two
@@ -377,8 +397,9 @@ int fmhip_program_source(const fmhip_prog_op* ops, int n_ops, int n_inputs, cons
 
 /* Fill n_steps*n_factors new vectors of n_paths N(0, dt_step) increments:
  *   out[step*n_factors + factor][p] = (float)sqrt(dt[step]) * Z(seed, step, factor, path_offset + p)
- * Z is a counter-based Philox4x32-10 + Box–Muller normal: a pure function of (seed, step, factor,
- * global path index), hence independent of launch geometry and of how paths are sharded over GPUs.
+ * Z is a counter-based normal — Philox4x32-10 (counter = (global path index / 4, step * n_factors + factor), key = seed), each 32-bit
+ * word mapped through the inverse normal CDF (a segment table in LDS and a cubic per segment: csrc/fm_normal_table.hpp) — a pure
+ * function of (seed, step, factor, global path index), hence independent of launch geometry and of how paths are sharded over GPUs.
  * Replaces curandGenerateNormal per (step,factor) (BrownianMotionCudaWithRandomVariableCuda.java:168-178). */
 int fmhip_bm_generate(int64_t seed, int n_steps, int n_factors, int64_t n_paths, int64_t path_offset,
                       const double* dt, fmhip_vec* out);

@@ -31,11 +31,11 @@ final class DeviceVector {
 	}
 
 	static DeviceVector fromHost(final double[] values) {			// (float)values[i], RandomVariableCuda.java:768-774 — narrowed in the engine
-		return new DeviceVector(Native.vecCreateFromDouble(values), values.length);
+		return new DeviceVector(afterCollection(Native.vecCreateFromDouble(values), () -> Native.vecCreateFromDouble(values)), values.length);
 	}
 
 	static DeviceVector filled(final long size, final double value) {
-		return new DeviceVector(Native.vecCreateFilled(size, value), size);
+		return new DeviceVector(afterCollection(Native.vecCreateFilled(size, value), () -> Native.vecCreateFilled(size, value)), size);
 	}
 
 	double[] toDoubleArray() {
@@ -56,24 +56,39 @@ final class DeviceVector {
 	// The operands stay reachable until the native call has returned (the engine then holds its own references to them):
 	// without the fences the JIT may treat `this` / `b` as dead once their handle field has been read, and the Cleaner could
 	// release a handle that the call is about to use.
+	/*
+	 * A device allocation that fails while dead wrappers wait for the collector: the collector is asked to run, the cleaner given a moment,
+	 * the call tried once more — what the reference's pool does when device memory runs short (System.gc() and a wait on the reference
+	 * queue, RandomVariableCuda.java:311-335).  Only on the failure path: the hot path allocates nothing for it.  (The C++ mirror models
+	 * this caller: host/random_variable.hpp, ReleaseLag.)
+	 */
+	private static long afterCollection(final long handle, final java.util.function.LongSupplier again) {
+		if(handle != 0 || !Native.lastError().startsWith("device allocation")) {
+			return handle;
+		}
+		System.gc();
+		try { Thread.sleep(50); } catch(final InterruptedException e) { Thread.currentThread().interrupt(); }
+		return again.getAsLong();
+	}
+
 	DeviceVector v1s0(final int opcode) {
-		try { return new DeviceVector(Native.callV1s0(opcode, handle), size); }
+		try { return new DeviceVector(afterCollection(Native.callV1s0(opcode, handle), () -> Native.callV1s0(opcode, handle)), size); }
 		finally { Reference.reachabilityFence(this); }
 	}
 	DeviceVector v1s1(final int opcode, final double s) {
-		try { return new DeviceVector(Native.callV1s1(opcode, handle, s), size); }
+		try { return new DeviceVector(afterCollection(Native.callV1s1(opcode, handle, s), () -> Native.callV1s1(opcode, handle, s)), size); }
 		finally { Reference.reachabilityFence(this); }
 	}
 	DeviceVector v2s0(final int opcode, final DeviceVector b) {
-		try { return new DeviceVector(Native.callV2s0(opcode, handle, b.handle), size); }
+		try { return new DeviceVector(afterCollection(Native.callV2s0(opcode, handle, b.handle), () -> Native.callV2s0(opcode, handle, b.handle)), size); }
 		finally { Reference.reachabilityFence(this); Reference.reachabilityFence(b); }
 	}
 	DeviceVector v2s1(final int opcode, final DeviceVector b, final double s) {
-		try { return new DeviceVector(Native.callV2s1(opcode, handle, b.handle, s), size); }
+		try { return new DeviceVector(afterCollection(Native.callV2s1(opcode, handle, b.handle, s), () -> Native.callV2s1(opcode, handle, b.handle, s)), size); }
 		finally { Reference.reachabilityFence(this); Reference.reachabilityFence(b); }
 	}
 	DeviceVector v3s0(final int opcode, final DeviceVector b, final DeviceVector c) {
-		try { return new DeviceVector(Native.callV3s0(opcode, handle, b.handle, c.handle), size); }
+		try { return new DeviceVector(afterCollection(Native.callV3s0(opcode, handle, b.handle, c.handle), () -> Native.callV3s0(opcode, handle, b.handle, c.handle)), size); }
 		finally { Reference.reachabilityFence(this); Reference.reachabilityFence(b); Reference.reachabilityFence(c); }
 	}
 }

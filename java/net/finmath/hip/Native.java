@@ -69,6 +69,11 @@ final class Native {
 	static native int reduceMomentsDevice(long vector, double shift, long deviceOut4Doubles);
 	static native int reduceMomentsBatch(long[] vectors, double[] shiftsOrNull, double[] moments4PerVector);
 	static native int reduceMomentsBatchDevice(long[] vectors, double[] shiftsOrNull, long deviceOut);
+	/** With a device list: one device buffer per listed device (0 = not wanted there), each receives the moments of the whole vectors. */
+	static native int reduceMomentsBatchDevices(long[] vectors, double[] shiftsOrNull, long[] deviceOutPerDevice);
+	static native int getStreamOf(int shard, long[] stream);
+	/** kind[0]: 0 = one device, 1 = grouped RCCL all-gather over the listed devices, 2 = combined on the host. */
+	static native int expectationCollective(int[] kind);
 	// the same reduction in two halves: begin enqueues and returns a ticket (ticket[0]); end waits for that reduction only and retires the ticket
 	static native int reduceMomentsBatchBegin(long[] vectors, double[] shiftsOrNull, long[] ticket);
 	static native int vecGiveUpValues(long[] vectors);

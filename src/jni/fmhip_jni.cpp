@@ -172,6 +172,25 @@ FMJ(jint, reduceMomentsBatchDevice)(JNIEnv* env, jclass, jlongArray vectors, jdo
     if (!pv.p || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
     return fmhip_reduce_moments_batch_device((const fmhip_vec*)pv.p, pv.length(), ps.p, (void*)(intptr_t)deviceOut);
 }
+FMJ(jint, reduceMomentsBatchDevices)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jlongArray deviceOutPerDevice) {
+    Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT); Pin<jlong> po(env, deviceOutPerDevice, JNI_ABORT);
+    if (!pv.p || !po.p || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;
+    std::vector<void*> out((size_t)po.length());
+    for (int d = 0; d < po.length(); ++d) out[(size_t)d] = (void*)(intptr_t)po.p[d];
+    return fmhip_reduce_moments_batch_devices((const fmhip_vec*)pv.p, pv.length(), ps.p, out.data(), po.length());
+}
+FMJ(jint, getStreamOf)(JNIEnv* env, jclass, jint shard, jlongArray stream) {
+    void* s = nullptr;
+    const int st = fmhip_get_stream_of(shard, &s);
+    if (st == FMHIP_OK) set1(env, stream, (jlong)(intptr_t)s);
+    return st;
+}
+FMJ(jint, expectationCollective)(JNIEnv* env, jclass, jintArray kind) {
+    int k = 0;
+    const int st = fmhip_expectation_collective(&k, nullptr, 0);
+    if (st == FMHIP_OK && kind && env->GetArrayLength(kind) >= 1) { const jint v = k; env->SetIntArrayRegion(kind, 0, 1, &v); }
+    return st;
+}
 FMJ(jint, reduceMomentsBatchBegin)(JNIEnv* env, jclass, jlongArray vectors, jdoubleArray shifts, jlongArray ticket) {
     Pin<jlong> pv(env, vectors, JNI_ABORT); Pin<jdouble> ps(env, shifts, JNI_ABORT);
     if (!pv.p || !ticket || env->GetArrayLength(ticket) < 1 || (ps.p && ps.length() < pv.length())) return FMHIP_ERR_INVALID_ARGUMENT;

@@ -348,6 +348,27 @@ static void scenario_speed() {
     std::printf("speed: %.0f ns per recorded method + release on the caller's thread, %.0f ns including the shards' replay\n",
                 std::chrono::duration<double>(t1 - t0).count() / reps * 1e9, std::chrono::duration<double>(t2 - t0).count() / reps * 1e9);
     if (cur != a) rel(cur);
+    // … and the FRONT's own cost (a device list: what the caller's thread pays to hand a method and a release to the shards): bursts that
+    // fit the command ring, so that the caller never waits for a slot; the shards' replay (waited for between the bursts) is not timed
+    {
+        const int burst = 12000, bursts = 40;
+        double seconds = 0.0;
+        for (int r = 0; r < bursts; ++r) {
+            OK(fmhip_synchronize());
+            const auto b0 = std::chrono::steady_clock::now();
+            V c2 = a;
+            for (int k = 0; k < burst; ++k) {
+                V nx = 0;
+                OK(fmhip_call_v2s1(FMHIP_OP_DISCOUNT, c2, b, 0.5, &nx));
+                if (c2 != a) OK(fmhip_vec_release(c2));
+                c2 = nx;
+                if (k % 200 == 199) { rel(c2); c2 = a; }
+            }
+            seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - b0).count();
+            if (c2 != a) rel(c2);
+        }
+        std::printf("speed: %.0f ns per recorded method + release in bursts of %d (the caller never waits for the command ring)\n", seconds / (burst * bursts) * 1e9, burst);
+    }
     OK(fmhip_fusion_hold(0, nullptr));
     rel(a); rel(b);
 }
@@ -449,6 +470,15 @@ static void scenario_oom() {
     OK(fmhip_vec_create_filled(3 * n + 77, 2.0, &big2));          // … and another one
     std::vector<V> more;
     for (;;) { V h = 0; const int st = fmhip_vec_create_filled(n, 1.0, &h); if (st == FMHIP_ERR_OUT_OF_MEMORY) break; OK(st); more.push_back(h); if (more.size() > 100000) std::abort(); }
+    // every second vector released: cached blocks, but no slab is free as a whole — a small allocation is carved out of a cached block
+    std::vector<V> odd;
+    for (size_t i = 0; i < more.size(); ++i) if (i % 2) rel(more[i]); else odd.push_back(more[i]);
+    more.swap(odd);
+    std::vector<V> tiny;
+    for (int i = 0; i < 300; ++i) tiny.push_back(filled(1000 + 7 * i, 0.5));            // 300 size classes, none seen before
+    fmhip_moments mm; OK(fmhip_reduce_moments(tiny[5], 0.0, &mm));
+    rel(tiny);
+    for (;;) { V h = 0; const int st = fmhip_vec_create_filled(n, 1.0, &h); if (st == FMHIP_ERR_OUT_OF_MEMORY) break; OK(st); more.push_back(h); if (more.size() > 200000) std::abort(); }
     V huge = 0;
     EXPECT(fmhip_vec_create_filled(7 * n + 5, 2.0, &huge), FMHIP_ERR_OUT_OF_MEMORY);      // nothing cached to drop: the error, and an engine that carries on
     int was = 0; OK(fmhip_set_fusion(1, &was));
@@ -462,17 +492,67 @@ static void scenario_oom() {
     OK(fmhip_set_fusion(was, nullptr));
 }
 
+// Expectations wanted ON the devices of a device list (fmhip_reduce_moments_batch_devices; the *_device variants: the first listed device):
+// the one exchange between devices — a grouped all-gather over the listed devices and a combine kernel per device when the devices are
+// distinct (FMNULL_DISTINCT=1: the list {0, 1, 2 …}; RCCL = the stand-ins of null_rccl.cpp), a host combine when an index repeats.  Every
+// device must end up with the bits fmhip_reduce_moments_batch returns on the host.
+static void scenario_collective() {
+    int shards = 1, kind = -1;
+    OK(fmhip_device_count(&shards));
+    char why[256];
+    OK(fmhip_expectation_collective(&kind, why, sizeof why));
+    const bool distinct = std::getenv("FMNULL_DISTINCT") != nullptr;
+    if (kind != (shards == 1 ? 0 : distinct ? 1 : 2)) { std::fprintf(stderr, "collective: kind %d with %d shards (%s)\n", kind, shards, why); std::abort(); }
+    int was = 0; OK(fmhip_set_fusion(1, &was));
+    const int64_t n = 40003;
+    V x = filled(n, 0.5), y = filled(n, 1.5);
+    for (int round = 0; round < 3; ++round) {
+        const int count = 5 + 60 * round;
+        std::vector<V> vs;
+        for (int k = 0; k < count; ++k) { const V t = s1(FMHIP_OP_MULT_S, x, 1.0 + k), u = b2(FMHIP_OP_ADD, t, y); rel(t); vs.push_back(u); }
+        std::vector<std::vector<double>> dev((size_t)shards, std::vector<double>((size_t)count * 4, -1.0));       // ("device" memory of the null device is host memory)
+        std::vector<void*> out;
+        for (int d = 0; d < shards; ++d) out.push_back(d == 1 && shards > 2 ? nullptr : dev[(size_t)d].data());     // (one device that does not want them)
+        OK(fmhip_reduce_moments_batch_devices(vs.data(), count, nullptr, out.data(), shards));
+        OK(fmhip_synchronize());
+        std::vector<fmhip_moments> host((size_t)count);
+        OK(fmhip_reduce_moments_batch(vs.data(), count, nullptr, host.data()));
+        for (int d = 0; d < shards; ++d) {
+            if (!out[(size_t)d]) continue;
+            if (std::memcmp(dev[(size_t)d].data(), host.data(), (size_t)count * 32) != 0) { std::fprintf(stderr, "collective: device %d of %d disagrees with the host-side moments (round %d)\n", d, shards, round); std::abort(); }
+        }
+        std::vector<double> first((size_t)count * 4, -1.0);
+        OK(fmhip_reduce_moments_batch_device(vs.data(), count, nullptr, first.data()));                          // the first listed device
+        OK(fmhip_synchronize());
+        if (std::memcmp(first.data(), host.data(), (size_t)count * 32) != 0) std::abort();
+        double one[4] = { -1, -1, -1, -1 };
+        OK(fmhip_reduce_moments_device(vs[0], 0.0, one));
+        OK(fmhip_synchronize());
+        if (std::memcmp(one, &host[0], 32) != 0) std::abort();
+        void* stream = nullptr;
+        OK(fmhip_get_stream_of(shards - 1, &stream));
+        EXPECT(fmhip_get_stream_of(shards, &stream), FMHIP_ERR_INVALID_ARGUMENT);
+        rel(vs);
+    }
+    rel(x); rel(y);
+    OK(fmhip_set_fusion(was, nullptr));
+}
+
 int main(int argc, char** argv) {
     struct Scenario { const char* name; void (*run)(); };
     const Scenario all[] = { { "basic", scenario_basic }, { "replicas", scenario_replicas }, { "expectations", scenario_expectations },
-                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "shared", scenario_shared }, { "failure", scenario_failure }, { "speed", scenario_speed }, { "lagging", scenario_lagging }, { "oom", scenario_oom } };
+                             { "programs", scenario_programs_and_steps }, { "threads", scenario_threads }, { "shared", scenario_shared }, { "failure", scenario_failure }, { "speed", scenario_speed }, { "lagging", scenario_lagging }, { "oom", scenario_oom }, { "collective", scenario_collective } };
     std::vector<std::string> wanted;
     for (int i = 1; i < argc; ++i) wanted.push_back(argv[i]);
     const bool only_failure = wanted.size() == 1 && wanted[0] == "failure";      // (the hook counts the allocations of the whole process: one cycle)
     for (int cycle = 0; cycle < (only_failure ? 1 : 2); ++cycle) {                  // twice: shutdown and re-initialisation in between
         // FMNULL_DEVICES=N: the same scenarios behind a device list of N shards (sharded.cpp: one engine and one worker thread per shard)
         const int n_devices = std::getenv("FMNULL_DEVICES") ? std::atoi(std::getenv("FMNULL_DEVICES")) : 1;
-        if (n_devices > 1) { std::vector<int> devices((size_t)n_devices, 0); OK(fmhip_init_devices(devices.data(), n_devices)); int c = 0; OK(fmhip_device_count(&c)); if (c != n_devices) std::abort(); }
+        // (FMHIP_WORKER_THREAD=1 with one device: the front with ONE shard)
+        if (n_devices > 1 || (n_devices == 1 && std::getenv("FMHIP_WORKER_THREAD"))) { std::vector<int> devices((size_t)n_devices, 0);
+            // (FMNULL_DISTINCT=1: distinct indices — the front asks RCCL, i.e. null_rccl.cpp, for a communicator per device)
+            if (std::getenv("FMNULL_DISTINCT")) for (int k = 0; k < n_devices; ++k) devices[(size_t)k] = k;
+            OK(fmhip_init_devices(devices.data(), n_devices)); int c = 0; OK(fmhip_device_count(&c)); if (c != n_devices) std::abort(); }
         else OK(fmhip_init(0));
         // FMNULL_THREAD_ENGINES=1: an engine per caller thread (fmhip_set_thread_engines) — the scenarios' threads record side by side
         if (n_devices <= 1 && std::getenv("FMNULL_THREAD_ENGINES")) { int was = -1; OK(fmhip_set_thread_engines(1, &was)); if (was != 0) std::abort(); }

@@ -61,6 +61,20 @@ hipError_t launch_gather_moments(const DevGatherArgs& a, double* out, hipStream_
     return hipSuccess;
 }
 hipError_t preload_kernels() { return hipSuccess; }
+hipError_t launch_combine_moments(const double* gathered, uint32_t world, uint32_t count, double* out, hipStream_t) {       // (computed: the rule is small enough to state twice)
+    ++g_launches;
+    for (uint32_t k = 0; k < count; ++k) {
+        double m[4]; std::memcpy(m, gathered + (size_t)k * 4, 32);
+        for (uint32_t r = 1; r < world; ++r) {
+            const double* g = gathered + ((size_t)r * count + k) * 4;
+            m[0] += g[0]; m[1] += g[1];
+            m[2] = (m[2] != m[2] || g[2] != g[2]) ? __builtin_nan("") : (g[2] < m[2] || (g[2] == m[2] && __builtin_signbit(g[2]))) ? g[2] : m[2];
+            m[3] = (m[3] != m[3] || g[3] != g[3]) ? __builtin_nan("") : (g[3] > m[3] || (g[3] == m[3] && !__builtin_signbit(g[3]))) ? g[3] : m[3];
+        }
+        std::memcpy(out + (size_t)k * 4, m, 32);
+    }
+    return hipSuccess;
+}
 hipError_t launch_fill(float* p, float v, int64_t n_padded, hipStream_t) { ++g_launches; for (int64_t i = 0; i < n_padded; ++i) p[i] = v; return hipSuccess; }
 }
 

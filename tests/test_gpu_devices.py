@@ -156,3 +156,67 @@ def test_lmm_objective_evaluation_on_a_device_list():
         many = run("--devices", devices)
         a, b = np.array(one["model_volatility"]), np.array(many["model_volatility"])
         assert a.shape == b.shape and np.all(np.abs(a - b) <= 1e-12 * np.abs(a)), (devices, float(np.max(np.abs(a - b) / np.abs(a))))
+
+
+def test_expectations_on_the_devices_of_a_device_list(tmp_path):
+    """fmhip_reduce_moments_batch_devices / _batch_device / _device behind a device list.  The box has one GPU: the lists [0, 0] and
+    [0, 0, 0] repeat a device index, so the shards' moments are combined on the HOST and copied back (fmhip_expectation_collective says 2,
+    and why); with distinct devices the same call is one grouped RCCL all-gather and a combine kernel per device (rehearsed on the null
+    device: tests/test_sanitizers_cpu.py).  Every device buffer must hold the bits fmhip_reduce_moments_batch returns on the host."""
+    script = tmp_path / "collective.py"
+    script.write_text(r'''
+import ctypes as C, importlib, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+fm = importlib.import_module("finmath-lib-cuda-extensions_amd")
+N = fm._native
+for dev in ([0, 0], [0, 0, 0]):
+    fm.init_devices(dev)
+    D = len(dev)
+    kind = C.c_int32(-1); why = C.create_string_buffer(256)
+    N.check(fm.lib().fmhip_expectation_collective(C.byref(kind), why, 256))
+    assert kind.value == 2 and b"repeats" in why.value, (kind.value, why.value)
+    rng = np.random.default_rng(7)
+    n = 100_003
+    xs = [fm.DeviceVector.from_host(rng.normal(0.1 * k, 1.0, n).astype(np.float32)) for k in range(9)]
+    prev = fm.set_fusion(True)
+    vs = [x.v1s1("MULT_S", 1.5).v2s0("ADD", xs[0]).v1s0("ABS") for x in xs]             # pending: the launches that compute them take the moments along
+    count = len(vs)
+    handles = (C.c_int64 * count)(*[v.handle for v in vs])
+    bufs = [torch.full((count * 4,), -1.0, dtype=torch.float64, device="cuda:0") for _ in range(D)]
+    outs = (C.c_void_p * D)(*[b.data_ptr() for b in bufs])
+    if D == 3: outs[1] = None                                                            # one device that does not want them
+    N.check(fm.lib().fmhip_reduce_moments_batch_devices(handles, count, None, outs, D))
+    fm.synchronize()
+    host = (N.Moments * count)()
+    N.check(fm.lib().fmhip_reduce_moments_batch(handles, count, None, host))
+    want = np.frombuffer(host, dtype=np.float64)
+    for d in range(D):
+        got = bufs[d].cpu().numpy()
+        if D == 3 and d == 1: assert (got == -1.0).all()
+        else: assert got.tobytes() == want.tobytes(), (dev, d)
+    first = torch.full((count * 4,), -1.0, dtype=torch.float64, device="cuda:0")
+    N.check(fm.lib().fmhip_reduce_moments_batch_device(handles, count, None, C.c_void_p(first.data_ptr())))
+    one = torch.full((4,), -1.0, dtype=torch.float64, device="cuda:0")
+    N.check(fm.lib().fmhip_reduce_moments_device(C.c_int64(vs[3].handle), C.c_double(0.0), C.c_void_p(one.data_ptr())))
+    fm.synchronize()
+    assert first.cpu().numpy().tobytes() == want.tobytes() and one.cpu().numpy().tobytes() == want[12:16].tobytes()
+    s = C.c_void_p(0)
+    N.check(fm.lib().fmhip_get_stream_of(D - 1, C.byref(s))); assert s.value
+    assert fm.lib().fmhip_get_stream_of(D, C.byref(s)) == N.ERR_INVALID_ARGUMENT
+    assert fm.lib().fmhip_reduce_moments_batch_devices(handles, count, None, outs, D + 1) == N.ERR_INVALID_ARGUMENT
+    fm.set_fusion(prev)
+    del vs, xs
+    fm.shutdown()
+fm.init(0)                                                                               # one device: kind 0, the same entry points
+kind = C.c_int32(-1)
+N.check(fm.lib().fmhip_expectation_collective(C.byref(kind), None, 0)); assert kind.value == 0
+x = fm.DeviceVector.from_host(np.arange(1000, dtype=np.float32))
+buf = torch.zeros(4, dtype=torch.float64, device="cuda:0")
+h = (C.c_int64 * 1)(x.handle); o = (C.c_void_p * 1)(buf.data_ptr())
+N.check(fm.lib().fmhip_reduce_moments_batch_devices(h, 1, None, o, 1)); fm.synchronize()
+assert buf.cpu().numpy()[0] == 499500.0
+print("ok")
+''' % {"root": ROOT})
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1000:] + r.stderr[-3000:]

@@ -33,7 +33,7 @@ def run(binary, tmp_path, *scenarios, **extra_env):
 def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(built, tmp_path):
     r = run(os.path.join(built, "drive_asan"), tmp_path)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 14          # seven scenarios, twice (shutdown and re-initialisation in between)
+    assert r.stdout.count("done") == 16          # eight scenarios, twice (shutdown and re-initialisation in between)
     again = run(os.path.join(built, "drive_asan"), tmp_path)      # once more: the code objects of the first run come from the cache directory
     assert again.returncode == 0 and "Sanitizer" not in again.stderr, again.stderr[-6000:]
 
@@ -41,7 +41,7 @@ def test_host_runtime_is_clean_under_address_and_undefined_behaviour_sanitizers(
 def test_host_runtime_is_clean_under_thread_sanitizer(built, tmp_path):
     r = run(os.path.join(built, "drive_tsan"), tmp_path)
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 14
+    assert r.stdout.count("done") == 16
 
 
 def test_a_failing_allocation_inside_a_replicated_launch_leaves_nothing_behind(built, tmp_path):
@@ -74,10 +74,23 @@ def test_a_device_list_is_clean_under_both_sanitizer_builds(built, tmp_path, sha
     through a single-producer ring per worker, reads and reductions gathered): ASan + UBSan, then ThreadSanitizer."""
     r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 14
+    assert r.stdout.count("done") == 16
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_DEVICES=str(shards))
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
-    assert t.stdout.count("done") == 14
+    assert t.stdout.count("done") == 16
+
+
+def test_the_expectation_collective_of_a_device_list(built, tmp_path):
+    """Expectations wanted ON the devices of a device list: with distinct device indices the front asks RCCL (here: the stand-ins of
+    tests/nulldev/null_rccl.cpp, found by dlsym as librccl.so's would be) for a communicator per device and issues ONE all-gather for
+    all of them inside ncclGroupStart / ncclGroupEnd, a combine kernel per device follows; with a repeated index the host combines.
+    Every device must hold the bits the host-side reduction returns (scenario `collective`), under ASan and TSan, 4 and 8 devices."""
+    for env in ({"FMNULL_DEVICES": "4", "FMNULL_DISTINCT": "1"}, {"FMNULL_DEVICES": "8", "FMNULL_DISTINCT": "1"}, {"FMNULL_DEVICES": "3"}):
+        r = run(os.path.join(built, "drive_asan"), tmp_path, "collective", "lagging", **env)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (env, r.stdout[-500:] + r.stderr[-6000:])
+        assert r.stdout.count("done") == 4
+    t = run(os.path.join(built, "drive_tsan"), tmp_path, "collective", "lagging", "basic", FMNULL_DEVICES="4", FMNULL_DISTINCT="1")
+    assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-500:] + t.stderr[-6000:]
 
 
 def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_path):
@@ -117,8 +130,8 @@ def test_thread_engines_are_clean_under_both_sanitizer_builds(built, tmp_path):
     on one thread and ended on another, vectors handed over and released across engines; then shutdown (engines retired) and the same again."""
     r = run(os.path.join(built, "drive_asan"), tmp_path, FMNULL_THREAD_ENGINES="1")
     assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-6000:]
-    assert r.stdout.count("done") == 14
+    assert r.stdout.count("done") == 16
     t = run(os.path.join(built, "drive_tsan"), tmp_path, FMNULL_THREAD_ENGINES="1")
     assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-1500:] + t.stderr[-6000:]
-    assert t.stdout.count("done") == 14
+    assert t.stdout.count("done") == 16
 
