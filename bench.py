@@ -356,8 +356,9 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
             lmm["device_list_rehearsal"] = {"error": str(e)[-500:]}
         # … and the same caller with a garbage collector's idea of lifetime: every handle is released LATE, in bursts, by another thread —
         # what a JVM does with the reference's / the Java binding's wrappers (RandomVariableCuda.java:293-305; java/…/DeviceVector.java: a
-        # Cleaner action per handle).  lmm_hip --release-lag 100: a collection every 100 ms; --release-lag-bytes: "never, until 256 MB of
-        # dead wrappers".  The engine must not decide what to store by live handles (escape policy, runtime.hpp): bytes written, launches and
+        # Cleaner action per handle).  lmm_hip --release-lag 100: a collection every 100 ms ("never, until 256 MB of dead wrappers" —
+        # --release-lag-bytes — fills the device and is measured by benchmarks/round5/release_lag.sh, not here: the process after it meets a device
+        # still busy giving 300 GB back).  The engine must not decide what to store by live handles (escape policy, runtime.hpp): bytes written, launches and
         # the tier they run on are set against the run whose temporaries die at once (RAII, above).
         # (last of the driver runs: a process that held most of the device leaves the next one a device still busy giving the memory back)
         try:
@@ -377,7 +378,6 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                            "interpreter_launches": fl.get("engine", {}).get("interpreter_launches"), "peak_bytes_reserved": fl.get("engine", {}).get("peak_bytes_reserved")},
                   "collect_every_100_ms": gc_block(["--release-lag", "100"]),
                   "collect_every_20_ms": gc_block(["--release-lag", "20"]),
-                  "collect_at_256_MB_of_dead_wrappers": gc_block(["--release-lag-bytes", str(256 << 20)]),
                   "what": "lmm_hip --finmath-like --release-lag MS | --release-lag-bytes B: the C++ mirror's handle releases are queued and performed by a collector "
                           "thread, as a JVM's Cleaner would (host/random_variable.hpp: ReleaseLag); a device allocation that fails runs a collection and is retried"}
             lmm["finmath_like_gc"] = gc
@@ -779,7 +779,7 @@ def main():
     # correction applied): NOT measured in this run — counters need a profiler pass of their own — but OFFLINE on this exact
     # workload, committed under profiles/ (newest round first); null for other shapes.
     traffic, traffic_source = None, None
-    for name in ("round04_hbm_traffic.json", "round03_hbm_traffic.json", "round02_hbm_traffic.json", "round01_hbm_traffic.json"):
+    for name in ("round05_hbm_traffic.json", "round04_hbm_traffic.json", "round03_hbm_traffic.json", "round02_hbm_traffic.json", "round01_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 prof = json.load(fh)

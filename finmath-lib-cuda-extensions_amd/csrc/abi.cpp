@@ -6,6 +6,7 @@
 #include "sharded.hpp"
 #include <cmath>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -343,16 +344,37 @@ int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
     return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
 }
 int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); TE_OWNER(v, fmhip_vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
-// A release by the thread that drives the engine is performed at once; one by another thread — a collector's cleaner — is queued and
-// performed by whoever enters the engine next (runtime.hpp: release_later).  Queued releases cannot report an invalid handle.
+// A release by the thread that drives the engine is performed at once; one by another thread — a collector's cleaner, which hands back
+// hundreds of thousands of handles in a burst — is queued and performed by whoever enters the engine next (runtime.hpp: release_later).
+// The releasing thread collects them 256 at a time before it touches the engine's queue: one by one, its pushes and the driving thread's
+// look at the queue met on the queue's lock for as long as the burst lasted (tens of milliseconds per burst; lmm_hip --finmath-like
+// --release-lag 100 between 6 and 11 s from run to run).  What a thread has collected goes to the engine when 256 wait, at its next
+// release after a millisecond, and when the thread ends.  Queued releases cannot report an invalid handle.
+namespace {
+struct LateBuffer {
+    Engine* engine = nullptr;
+    std::vector<fmhip_vec> handles;
+    std::chrono::steady_clock::time_point since{};
+    void flush() {
+        if (handles.empty() || !engine) { handles.clear(); return; }
+        Engine& e = *engine;
+        const bool perform = e.release_later(handles.data(), handles.size());
+        handles.clear();
+        if (perform) { std::lock_guard<std::recursive_mutex> lock(e.mu); e.drain_late(); }
+    }
+    ~LateBuffer() { try { flush(); } catch (...) {} }
+};
+}
 static int release_vector(fmhip_vec v) {
     try {
         Engine& e = Engine::get();
         static const bool LATE = [] { const char* s = std::getenv("FMHIP_LATE_RELEASES"); return !(s && s[0] == '0'); }();      // =0: every release takes the engine lock (rounds 1–4; A/B measurement)
         if (LATE && !e.driven_by(thread_tag())) {
-            if (!e.release_later(v)) return FMHIP_OK;
-            std::lock_guard<std::recursive_mutex> lock(e.mu);
-            e.drain_late();
+            static thread_local LateBuffer mine;
+            if (mine.engine != &e) { mine.flush(); mine.engine = &e; }
+            if (mine.handles.empty()) mine.since = std::chrono::steady_clock::now();
+            mine.handles.push_back(v);
+            if (mine.handles.size() >= 256 || ((mine.handles.size() & 15u) == 0 && std::chrono::steady_clock::now() - mine.since > std::chrono::milliseconds(1))) mine.flush();
             return FMHIP_OK;
         }
         std::lock_guard<std::recursive_mutex> lock(e.mu);

@@ -239,11 +239,11 @@ public:
     bool driven_by(uint64_t thread_tag) const { return driver_tag_.load(std::memory_order_relaxed) == thread_tag; }
     uint64_t driver_seq() const { return driver_seq_.load(std::memory_order_relaxed); }
     // (returns true when the caller should perform the queue itself: LATE_BATCH releases wait, or the oldest has waited 10 ms — the driving thread has gone quiet)
-    bool release_later(fmhip_vec h) {
+    bool release_later(const fmhip_vec* hs, size_t count) {
         const auto now = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> lock(late_mu_);
         if (late_.empty()) late_since_ = now;
-        late_.push_back(h);
+        late_.insert(late_.end(), hs, hs + count);
         late_count_.store(late_.size(), std::memory_order_release);
         return late_.size() >= LATE_BATCH || now - late_since_ > std::chrono::milliseconds(10);
     }
