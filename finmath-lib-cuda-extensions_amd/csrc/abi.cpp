@@ -150,7 +150,9 @@ struct Localized {
 };
 }
 
-static uint64_t thread_tag() { static std::atomic<uint64_t> next{ 1 }; static thread_local const uint64_t tag = next.fetch_add(1); return tag; }
+// Has this thread ever ENTERED an engine for anything but a release?  A thread that has not — a garbage collector's cleaner thread — is a
+// releasing thread: its releases are queued (release_vector).  Thread-local: the driving thread and the releasing thread share nothing here.
+static thread_local bool tl_drives = false;
 
 template <typename F>
 static int guarded(F&& f) {
@@ -160,8 +162,9 @@ static int guarded(F&& f) {
         Engine& e = Engine::get();
         {
             std::lock_guard<std::recursive_mutex> lock(e.mu);
-            e.note_driver(thread_tag());
-            if (e.late_count() >= Engine::LATE_DRAIN) e.drain_late();      // releases other threads have left (Engine::release_later): in batches — and at every flush
+            tl_drives = true;
+            e.note_driver();
+            if (e.late_count() >= Engine::late_eager()) e.drain_late();      // releases other threads have left (Engine::release_later): preferably performed while the device is waited for
             f();
         }
         if (thread_engines) te::drain(e);
@@ -344,7 +347,7 @@ int fmhip_vec_create_uninitialized(int64_t n, fmhip_vec* out) {
     return guarded([&] { need(out, "out"); *out = Engine::get().create_uninitialized(n); });
 }
 int fmhip_vec_retain(fmhip_vec v) { FRONT(vec_retain(v)); TE_OWNER(v, fmhip_vec_retain(v)); return guarded([&] { Engine::get().retain(v); }); }
-// A release by the thread that drives the engine is performed at once; one by another thread — a collector's cleaner, which hands back
+// A release by a thread that drives the engine is performed at once; one by a thread that only ever releases — a collector's cleaner, which hands back
 // hundreds of thousands of handles in a burst — is queued and performed by whoever enters the engine next (runtime.hpp: release_later).
 // The releasing thread collects them 256 at a time before it touches the engine's queue: one by one, its pushes and the driving thread's
 // look at the queue met on the queue's lock for as long as the burst lasted (tens of milliseconds per burst; lmm_hip --finmath-like
@@ -355,12 +358,22 @@ struct LateBuffer {
     Engine* engine = nullptr;
     std::vector<fmhip_vec> handles;
     std::chrono::steady_clock::time_point since{};
+    uint64_t seq_seen = ~uint64_t(0);
+    std::chrono::steady_clock::time_point seq_since{};
     void flush() {
         if (handles.empty() || !engine) { handles.clear(); return; }
         Engine& e = *engine;
-        const bool perform = e.release_later(handles.data(), handles.size());
+        e.release_later(handles.data(), handles.size());
         handles.clear();
-        if (perform) { std::lock_guard<std::recursive_mutex> lock(e.mu); e.drain_late(); }
+        // nobody has entered the engine for 10 ms (this thread has looked twice and found the same count of entries): the caller has gone
+        // quiet, nobody will perform the queue — this thread does
+        const uint64_t seq = e.driver_seq();
+        const auto now = std::chrono::steady_clock::now();
+        if (seq != seq_seen) { seq_seen = seq; seq_since = now; return; }
+        if (now - seq_since < std::chrono::milliseconds(10)) return;
+        std::lock_guard<std::recursive_mutex> lock(e.mu);
+        e.drain_late();
+        seq_since = now;
     }
     ~LateBuffer() { try { flush(); } catch (...) {} }
 };
@@ -369,7 +382,7 @@ static int release_vector(fmhip_vec v) {
     try {
         Engine& e = Engine::get();
         static const bool LATE = [] { const char* s = std::getenv("FMHIP_LATE_RELEASES"); return !(s && s[0] == '0'); }();      // =0: every release takes the engine lock (rounds 1–4; A/B measurement)
-        if (LATE && !e.driven_by(thread_tag())) {
+        if (LATE && !tl_drives) {
             static thread_local LateBuffer mine;
             if (mine.engine != &e) { mine.flush(); mine.engine = &e; }
             if (mine.handles.empty()) mine.since = std::chrono::steady_clock::now();

@@ -243,7 +243,7 @@ void Engine::init(int device_index) {
     arena_off_ = 0; arena_outstanding_.clear();
     free_slots_.clear();
     for (int i = RESULT_SLOTS; i-- > 0;) free_slots_.push_back(i);
-    { const char* e = std::getenv("FMHIP_UNIT_WORKGROUPS"); unit_workgroups_ = e ? std::atoll(e) : 128; }
+    { const char* e = std::getenv("FMHIP_UNIT_WORKGROUPS"); unit_workgroups_ = e ? std::atoll(e) : 512; }
     hip_check(hipMalloc((void**)&counters_dev_, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t)), "hipMalloc(counters)");
     hip_check(hipMemsetAsync(counters_dev_, 0, FM_COUNTER_PLANES * FM_COUNTER_PLANE * sizeof(uint32_t), stream_), "hipMemset(counters)");
     hip_check(hipStreamSynchronize(stream_), "init sync");
@@ -342,7 +342,7 @@ size_t Engine::ring_reserve(size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes > ring_cap_) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "batch too large for the row-table ring");
     if (ring_off_ + bytes > ring_cap_) {        // wrap: earlier tables may still be read by queued kernels
-        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(ring wrap)");
+        wait_for_stream("hipStreamSynchronize(ring wrap)");
         ring_off_ = 0;
         ++ring_generation_;                     // device copies of earlier tables are about to be overwritten: nobody may reuse them
     }
@@ -357,6 +357,11 @@ Buffer* Engine::new_buffer(int64_t n_floats) {
     Buffer* b = new Buffer();
     size_t cap = 0;
     try { b->ptr = (float*)pool_.alloc((size_t)n_floats * 4, &cap); }
+    catch (const Error& e) {
+        // (out of memory with releases still queued: they are performed — their vectors go back to the pool — and the allocation is tried again)
+        if (e.code != FMHIP_ERR_OUT_OF_MEMORY || !has_late()) { delete b; throw; }
+        try { drain_late(); b->ptr = (float*)pool_.alloc((size_t)n_floats * 4, &cap); } catch (...) { delete b; throw; }
+    }
     catch (...) { delete b; throw; }
     b->cap = cap; b->refs = 1;
     return b;
@@ -474,16 +479,37 @@ void Engine::release(fmhip_vec h) {
     if (--nd->refs_ext == 0) { nodes_.erase(h); node_maybe_free(nd); }
 }
 
-void Engine::drain_late() {
+void Engine::drain_late(size_t at_most) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct Spent { Engine* e; std::chrono::steady_clock::time_point t0; ~Spent() { e->late_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } spent{ this, t_begin };
     std::vector<fmhip_vec> batch;
-    { std::lock_guard<std::mutex> lock(late_mu_); batch.swap(late_); late_count_.store(0, std::memory_order_release); }
+    {
+        std::lock_guard<std::mutex> lock(late_mu_);
+        const size_t waiting = late_.size() - late_pos_;
+        if (at_most >= waiting) { if (late_pos_ == 0) batch.swap(late_); else { batch.assign(late_.begin() + (std::ptrdiff_t)late_pos_, late_.end()); late_.clear(); } late_pos_ = 0; }
+        else { batch.assign(late_.begin() + (std::ptrdiff_t)late_pos_, late_.begin() + (std::ptrdiff_t)(late_pos_ + at_most)); late_pos_ += at_most; }
+        late_count_.store(late_.size() - late_pos_, std::memory_order_release);
+    }
     if (!initialized_) return;
-    // (the nodes of handles that died a while ago are cold: their addresses are looked up a few ahead and fetched while the ones before are dealt with)
+    (at_most == ~size_t(0) ? n_late_at_once_ : n_late_waiting_) += (int64_t)batch.size();
+    // The nodes of handles that died a while ago are COLD, and performing a release touches several lines of several nodes: the node's
+    // own three, its neighbours on the deferred list (unlinked), its operands (their counts drop; whatever only the recipe kept alive goes
+    // with it).  Two stages of prefetching ahead of the work: the node itself 16 handles ahead, what it points to 8 ahead (by then it is there).
     static const size_t AHEAD = [] { const char* e = std::getenv("FMHIP_DRAIN_PREFETCH"); return e ? (size_t)std::atoll(e) : (size_t)8; }();
     std::vector<Node*> nds(batch.size());
     for (size_t i = 0; i < batch.size(); ++i) nds[i] = owner_of(batch[i]) == index_ ? nodes_.get(batch[i]) : nullptr;     // (a handle that is not one: nobody is left to tell)
+    auto fetch = [](const void* p) { __builtin_prefetch(p, 1, 1); };
     for (size_t i = 0; i < batch.size(); ++i) {
-        if (AHEAD && i + AHEAD < batch.size() && nds[i + AHEAD]) __builtin_prefetch(nds[i + AHEAD], 1, 1);
+        if (AHEAD) {
+            if (i + 2 * AHEAD < batch.size()) if (const Node* far = nds[i + 2 * AHEAD]) { fetch(far); fetch((const char*)far + 64); fetch((const char*)far + 128); }
+            if (i + AHEAD < batch.size()) if (const Node* near = nds[i + AHEAD]) {
+                if (nodes_.get(batch[i + AHEAD]) == near && near->refs_ext == 1) {      // (still the handle's node: a handle released twice in one batch has lost it by now)                            // about to go: what its going touches
+                    if (near->pend_prev) fetch(&near->pend_prev->pend_next);
+                    if (near->pend_next) fetch(&near->pend_next->pend_prev);
+                    if (!near->buf) for (int k = 0; k < near->n_in; ++k) if (near->in[k]) fetch(near->in[k]);
+                }
+            }
+        }
         Node* nd = nds[i];
         if (!nd || nodes_.get(batch[i]) != nd) continue;             // (released twice in one batch: the second is not a handle any more)
         if (--nd->refs_ext == 0) { nodes_.erase(batch[i]); node_maybe_free(nd); }
@@ -550,7 +576,7 @@ void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
         const int64_t m = std::min(chunk, n - off);
         float* st = (float*)ensure_stage((size_t)m * 4);
         hip_check(hipMemcpyAsync(st, nd->buf->ptr + off, (size_t)m * 4, hipMemcpyDeviceToHost, stream_), "D2H");
-        hip_check(hipStreamSynchronize(stream_), "D2H sync");
+        wait_for_stream("D2H sync");
         if (as_double) { double* d = (double*)dst + off; for (int64_t i = 0; i < m; ++i) d[i] = st[i]; }
         else std::memcpy((float*)dst + off, st, (size_t)m * 4);
     }
@@ -930,7 +956,7 @@ double* Engine::arena_alloc(size_t count)
     const size_t need = count * 32;
     if (need > ARENA_BYTES) return nullptr;
     if (arena_off_ + need > ARENA_BYTES) {                     // full: everything written so far is collected, then it starts again
-        hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize(moments arena)");
+        wait_for_stream("hipStreamSynchronize(moments arena)");
         arena_collect();
         arena_off_ = 0;
     }
@@ -966,6 +992,23 @@ void Engine::arena_collect()
     }
 }
 
+// Waits for everything queued on the stream — and, while it waits, performs releases that other threads have queued (drain_late): the
+// device is asked whether it is done between portions instead of being slept on.
+void Engine::wait_for_stream(const char* what)
+{
+    if (has_late()) {
+        for (;;) {
+            const hipError_t q = hipStreamQuery(stream_);
+            if (q == hipSuccess) return;
+            if (q != hipErrorNotReady) hip_check(q, what);
+            (void)hipGetLastError();
+            if (!has_late()) break;
+            drain_late(late_portion());
+        }
+    }
+    hip_check(hipStreamSynchronize(stream_), what);
+}
+
 bool Engine::slot_wait(Node* nd)
 {
     volatile uint64_t* slot = nd->moments_slot;
@@ -974,13 +1017,16 @@ bool Engine::slot_wait(Node* nd)
     const auto t0 = std::chrono::steady_clock::now();
     bool arrived = complete();
     for (uint32_t spins = 1; !arrived; ++spins) {
+        if (has_late()) drain_late(late_portion());           // the device is being waited for: queued releases are performed meanwhile, a few per look
+        else {
 #if defined(__x86_64__)
-        _mm_pause();
+            _mm_pause();
 #endif
+        }
         arrived = complete();
         if (!arrived && (spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
-    if (!arrived) { hip_check(hipStreamSynchronize(stream_), "moments sync"); arrived = complete(); }
+    if (!arrived) { wait_for_stream("moments sync"); arrived = complete(); }
     std::atomic_thread_fence(std::memory_order_acquire);
     nd->moments_slot = nullptr;
     if (!arrived) return false;                                  // (the launch never took them: a failed launch)
@@ -1042,7 +1088,7 @@ void Engine::red_complete(RedLaunch& red, bool arrived)
     if (!red.pending) return;
     red.pending = false;
     try {
-        if (!arrived) hip_check(hipStreamSynchronize(stream_), "moments sync");
+        if (!arrived) wait_for_stream("moments sync");
         std::memcpy(red.host, red.results, (size_t)red.batch * red.n_red * 32);
     } catch (...) { red_release(red); throw; }
     red_release(red);
@@ -1054,7 +1100,16 @@ void Engine::red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_
     const size_t bytes = (size_t)batch * n_red * 32;
     void* src = red.results;
     if (!red.on_host) { src = ensure_stage(bytes); hip_check(hipMemcpyAsync(src, red.results, bytes, hipMemcpyDeviceToHost, stream_), "moments D2H"); }
-    if (!red_poll(red)) hip_check(hipStreamSynchronize(stream_), "moments sync");
+    bool arrived = false;
+    if (red.poll_flag && has_late()) {                      // (as red_poll, with queued releases performed between the looks)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 1; !(arrived = *red.poll_flag == red.done_value); ++spins) {
+            if (has_late()) drain_late(late_portion());
+            if ((spins & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!arrived && !red_poll(red)) wait_for_stream("moments sync");
     std::memcpy(host_moments, src, bytes);
 }
 
@@ -2813,7 +2868,7 @@ void Engine::materialize(const std::vector<Node*>& targets) {
 void Engine::flush_all() {
     HostTimer timer(HostProfile::FLUSH);
     require_init();
-    if (has_late()) drain_late();
+    if (late_count() >= late_eager()) drain_late();
     ++flush_seq_;
     for (int round = 0; round < 1000000; ++round) {
         std::unique_ptr<HostTimer> t_components(new HostTimer(HostProfile::FLUSH_COMPONENTS));
@@ -3242,9 +3297,12 @@ Engine::MomentsTicket Engine::ticket_take(int64_t id) {
         const auto t0 = std::chrono::steady_clock::now();
         bool arrived = complete();
         for (uint32_t spins = 1; !arrived; ++spins) {
+            if (has_late()) drain_late(late_portion());
+            else {
 #if defined(__x86_64__)
-            _mm_pause();
+                _mm_pause();
 #endif
+            }
             arrived = complete();
             if (!arrived && (spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
         }
@@ -3468,7 +3526,6 @@ void Engine::pool_purge() {
 void Engine::engine_stats(fmhip_engine_stats_t* out) {
     require_init();
     if (!out) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "null stats pointer");
-    if (has_late()) drain_late();
     std::memset(out, 0, sizeof *out);
     out->size = (int64_t)sizeof *out;
     out->kernel_launches = n_launches_; out->specialised_launches = n_jit_launches_; out->interpreter_launches = n_interpreter_launches_;
@@ -3476,6 +3533,7 @@ void Engine::engine_stats(fmhip_engine_stats_t* out) {
     out->values_deferred = n_deferred_total_; out->values_deferred_now = (int64_t)n_deferred_; out->values_demanded = n_demanded_;
     out->pending_operations = (int64_t)n_pending_;
     out->peak_bytes_reserved = pool_.peak_reserved;
+    out->late_releases_while_waiting = n_late_waiting_; out->late_releases_at_once = n_late_at_once_; out->late_release_nanoseconds = late_ns_;
 }
 
 void Engine::pool_stats(fmhip_pool_stats_t* out) {

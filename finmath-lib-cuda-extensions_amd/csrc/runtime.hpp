@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -232,25 +233,27 @@ public:
     // objects that died a while ago (java/net/finmath/hip/DeviceVector.java; the reference's ReferenceQueue, RandomVariableCuda.java:293-305)
     // — never take the engine lock one by one: a caller thread that records two million methods a second would meet the releaser on the
     // lock at every other call and sleep on it (measured, lmm_hip --finmath-like --release-lag 100, 1 M paths: 14.1 s against 4.3 s with
-    // the same launches).  They are queued (a tiny lock of their own) and performed by whoever enters the engine next; the releasing thread
-    // performs them itself, all at once, when LATE_BATCH have piled up or the oldest has waited 10 ms (the driving thread has gone quiet).
-    static constexpr size_t LATE_BATCH = 4096;
-    void note_driver(uint64_t thread_tag) { driver_tag_.store(thread_tag, std::memory_order_relaxed); driver_seq_.store(driver_seq_.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed); }
-    bool driven_by(uint64_t thread_tag) const { return driver_tag_.load(std::memory_order_relaxed) == thread_tag; }
+    // the same launches).  They are queued (a tiny lock of their own; abi.cpp collects 256 per releasing thread first) and PERFORMED by the
+    // driving thread — preferably while it has nothing else to do: in small portions while it waits for the device (the spin loops of
+    // slot_wait / ticket_take / red_wait), all of them before a flush looks for memory in vain (new_buffer), at the latest when LATE_EAGER
+    // wait.  A node that was released 100 ms after its creation is cold: performing 21 M of them between the recorded methods cost the
+    // hint-free calibration 1.5 s; the device gives that time away for nothing while it is waited for.  The releasing thread performs the
+    // queue itself only when no thread has entered the engine for 10 ms (the caller has gone quiet).
+    static size_t late_eager() { static const size_t v = [] { const char* e = std::getenv("FMHIP_LATE_EAGER"); return e ? (size_t)std::atoll(e) : (size_t(1) << 17); }(); return v; }      // queued releases at which the driving thread performs them at once
+    static size_t late_portion() { static const size_t v = [] { const char* e = std::getenv("FMHIP_LATE_PORTION"); return e ? (size_t)std::atoll(e) : (size_t)48; }(); return v; }       // … and how many it performs per look while it waits for the device
+    // (a count of entries, on a cache line of its own, written by the driving threads and read by a releasing thread once per 256 releases:
+    // until it was — and while every release read the driving thread's tag, which every entry wrote — the line went back and forth between the
+    // two cores with every recorded method: 0.10 → 0.25 µs per method for as long as a collector's burst lasted)
+    void note_driver() { driver_seq_.store(driver_seq_.load(std::memory_order_relaxed) + 1, std::memory_order_relaxed); }
     uint64_t driver_seq() const { return driver_seq_.load(std::memory_order_relaxed); }
-    // (returns true when the caller should perform the queue itself: LATE_BATCH releases wait, or the oldest has waited 10 ms — the driving thread has gone quiet)
-    bool release_later(const fmhip_vec* hs, size_t count) {
-        const auto now = std::chrono::steady_clock::now();
+    void release_later(const fmhip_vec* hs, size_t count) {
         std::lock_guard<std::mutex> lock(late_mu_);
-        if (late_.empty()) late_since_ = now;
         late_.insert(late_.end(), hs, hs + count);
-        late_count_.store(late_.size(), std::memory_order_release);
-        return late_.size() >= LATE_BATCH || now - late_since_ > std::chrono::milliseconds(10);
+        late_count_.store(late_.size() - late_pos_, std::memory_order_release);
     }
     bool has_late() const { return late_count_.load(std::memory_order_acquire) != 0; }
     size_t late_count() const { return late_count_.load(std::memory_order_relaxed); }
-    static constexpr size_t LATE_DRAIN = 512;                  // a driving thread performs queued releases when this many wait (a releaser that feeds them one by one must not make it take the queue's lock at every call)
-    void drain_late();                                         // under `mu`
+    void drain_late(size_t at_most = ~size_t(0));              // under `mu`
     // Callers that wait for moments WITHOUT the engine lock (abi.cpp: fmhip_reduce_moments, fmhip_reduce_moments_batch_end) hold slots,
     // pinned blocks and events of this engine meanwhile: counted here (under the lock, before it is dropped); fmhip_shutdown waits for zero.
     std::atomic<int> waits_in_flight{ 0 };
@@ -292,7 +295,9 @@ public:
     int group_steps = 4;
     // Launches with a fused reduction of at most this many spans in all give every workgroup one UNIT of the reduction tree instead of a
     // span (runtime.cpp: launch); FMHIP_UNIT_WORKGROUPS.
-    int64_t unit_workgroups_ = 128;
+    // (512 since round 5: two or three rows of 1 M paths — 246 / 369 spans — used to fall between "one row: a unit per workgroup" and "four rows and
+    // more: enough spans", took no moments along and cost a reduction launch each: 6 210 of the hint-free calibration's 43 471 launches)
+    int64_t unit_workgroups_ = 512;
     bool unit_launch(int64_t n, int64_t batch) const;
     void end_step_group() { group_hold_ = false; group_steps_pending_ = 0; }      // a value is read, or the caller flushes: whatever was being grouped has run
     void flush_all();
@@ -511,12 +516,14 @@ private:
     void materialize_deferred();                                  // every deferred value that still has a handle (fmhip_pool_clean; before a vector is written in place)
     std::mutex late_mu_;
     std::vector<fmhip_vec> late_;
-    std::chrono::steady_clock::time_point late_since_{};
+    size_t late_pos_ = 0;                                      // late_[late_pos_ …) wait
     std::atomic<size_t> late_count_{ 0 };
-    std::atomic<uint64_t> driver_tag_{ 0 }, driver_seq_{ 0 };
+    alignas(64) std::atomic<uint64_t> driver_seq_{ 0 };
+    alignas(64) std::atomic<uint64_t> after_driver_seq_{ 0 };      // (keeps what follows off that line)
     Node deferred_head_;                                          // circular list of the deferred nodes (Node::pend_prev / pend_next)
     size_t n_deferred_ = 0;
     int64_t n_deferred_total_ = 0, n_demanded_ = 0, bytes_written_ = 0, n_interpreter_launches_ = 0;
+    int64_t n_late_waiting_ = 0, n_late_at_once_ = 0, late_ns_ = 0;
     void commit_node(Node* nd, Buffer* b) { nd->buf = b; pend_erase(nd); }       // a launch has stored this value
     bool segment_dag(const BigDag& big, size_t s, size_t e, Dag& dag, const std::vector<int32_t>& uses);
     // An expectation asked of a large pending expression: taken by the launch that computes its root (the last segment of its plan)
@@ -541,6 +548,7 @@ private:
     double* arena_alloc(size_t count);                           // count slots, preset; may synchronise the stream (arena full)
     void arena_collect();                                        // stream synchronised: every outstanding slot goes to its node (if it still exists)
     void arena_assign(Node* nd, double* slot);
+    void wait_for_stream(const char* what);                      // hipStreamSynchronize, with queued releases performed meanwhile
     bool slot_wait(Node* nd);                                    // the node's slot has arrived (or the stream is waited for): moments into the node
     void red_begin(RedLaunch& red, int batch, int n_red, size_t blocks_per_row, fmhip_moments* host_moments, void* dev_moments);
     void red_wait(RedLaunch& red, int batch, int n_red, fmhip_moments* host_moments);

@@ -63,7 +63,7 @@ inline lmm::Backend makeHipBackend(const RandomVariableFactory* factory, const B
             for (const RV& x : v) { auto p = dynamic_cast<const RandomVariableHip*>(x.get()); if (p && !p->isDeterministic()) h.push_back(p->deviceVector().handle()); }
             if (!h.empty()) check(fmhip_vec_give_up_values(h.data(), (int)h.size()));
         };
-    be.launches = [] { fmhip_pool_stats_t s; check(fmhip_pool_stats(&s)); return (long long)s.n_kernel_launches; };
+    be.launches = [] { fmhip_engine_stats_t s; check(fmhip_engine_stats(&s)); return (long long)s.kernel_launches; };      // (counters only: fmhip_pool_stats counts live vectors, i.e. performs queued releases first)
     be.averages = [](const std::vector<RV>& v) { return getAverages(v); };
     if (!(std::getenv("FMHIP_LMM_ASYNC") && std::getenv("FMHIP_LMM_ASYNC")[0] == '0'))    // =0: every batch's expectations read before the next batch is recorded (A/B)
         be.expectationsRunPending = true;

@@ -445,6 +445,9 @@ typedef struct fmhip_engine_stats_t {
     int64_t values_deferred, values_deferred_now, values_demanded;
     int64_t pending_operations;
     int64_t peak_bytes_reserved;
+    /* releases that arrived from a thread which only ever releases (a collector's cleaner): queued, and performed by a driving thread
+     * while it waited for the device / at once because too many waited; the time the driving threads spent on them */
+    int64_t late_releases_while_waiting, late_releases_at_once, late_release_nanoseconds;
 } fmhip_engine_stats_t;
 int fmhip_engine_stats(fmhip_engine_stats_t* out);
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);

@@ -113,8 +113,9 @@ final class Native {
 	// ---- measurement
 	static native int profileEnable(int enabled);
 	static native int trafficStats(long[] algorithmicBytesAndSpecialisedLaunches);
-	/** {size, kernelLaunches, specialisedLaunches, interpreterLaunches, algorithmicBytes, algorithmicBytesWritten, valuesDeferred, valuesDeferredNow, valuesDemanded, pendingOperations, peakBytesReserved} */
-	static native int engineStats(long[] stats11);
+	/** {size, kernelLaunches, specialisedLaunches, interpreterLaunches, algorithmicBytes, algorithmicBytesWritten, valuesDeferred, valuesDeferredNow, valuesDemanded, pendingOperations, peakBytesReserved,
+	 *  lateReleasesWhileWaiting, lateReleasesAtOnce, lateReleaseNanoseconds} */
+	static native int engineStats(long[] stats14);
 	static native int profileRead(double[] kernelMsTotal, long[] launches);
 
 	// ---- helpers (plain Java)
