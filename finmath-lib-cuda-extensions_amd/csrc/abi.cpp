@@ -82,7 +82,7 @@ static void ensure() {
     e->set_index(i);
     // Its lock is taken BEFORE it can be found: whoever finds it in the registry — a setter or fmhip_synchronize walking all engines —
     // waits until it is initialised (until round 5 the engine was published first, and such a caller could lock it uninitialised).
-    std::unique_lock<std::recursive_mutex> l(e->mu);
+    std::unique_lock<fm::EngineMutex> l(e->mu);
     engines[i].store(e, std::memory_order_release);
     count.store(i + 1, std::memory_order_release);
     lock.unlock();                                            // the other threads' engines start side by side (an engine's start is ≈ 60 ms of allocations)
@@ -93,7 +93,7 @@ static void ensure() {
     // the registration, a concurrent fmhip_set_math_mode left one thread on EXACT and the others on FAST).  Lock order e → first: nobody
     // holds the first engine's lock while waiting for another engine's.
     int fusion = 0, math_mode = 0, group_steps = 0, jit_mode = 0; bool profiling = false;
-    { std::lock_guard<std::recursive_mutex> l0(first->mu); profiling = first->profiling(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
+    { std::lock_guard<fm::EngineMutex> l0(first->mu); profiling = first->profiling(); fusion = first->fusion ? 1 : 0; math_mode = first->math_mode; group_steps = first->group_steps; jit_mode = first->jit_mode; }
     e->fusion = fusion != 0; e->math_mode = math_mode; e->group_steps = group_steps; e->jit_mode = jit_mode;
     if (profiling) e->profile_enable(true);
     l.unlock();
@@ -103,10 +103,10 @@ static void ensure() {
 // the references owners hold for imports that have died in e go back (e's lock is NOT held here)
 static void drain(Engine& e) {
     std::vector<Engine::ForeignDone> done;
-    { std::lock_guard<std::recursive_mutex> l(e.mu); if (!e.has_foreign_done()) return; done = e.take_foreign_done(); }
+    { std::lock_guard<fm::EngineMutex> l(e.mu); if (!e.has_foreign_done()) return; done = e.take_foreign_done(); }
     for (const Engine::ForeignDone& d : done) {
         Engine* o = engines[d.owner].load(std::memory_order_acquire);
-        if (o) { std::lock_guard<std::recursive_mutex> l(o->mu); try { if (o->initialized()) o->release_exported(d.handle, d.done); } catch (...) {} }
+        if (o) { std::lock_guard<fm::EngineMutex> l(o->mu); try { if (o->initialized()) o->release_exported(d.handle, d.done); } catch (...) {} }
         if (d.done) (void)hipEventDestroy(d.done);
     }
 }
@@ -120,7 +120,7 @@ struct Localized {
     void give_back() {
         if (taken.empty()) return;
         Engine& mine = Engine::get();
-        { std::lock_guard<std::recursive_mutex> l(mine.mu); for (fmhip_vec v : taken) { try { mine.release(v); } catch (...) {} } }
+        { std::lock_guard<fm::EngineMutex> l(mine.mu); for (fmhip_vec v : taken) { try { mine.release(v); } catch (...) {} } }
         taken.clear();
     }
     void import_all() {
@@ -128,16 +128,16 @@ struct Localized {
         for (fmhip_vec& v : local) {
             if (!(v > 0 && Engine::owner_of(v) != mine.index())) continue;
             fmhip_vec loc = 0;
-            { std::lock_guard<std::recursive_mutex> l(mine.mu); loc = mine.find_import(v); }
+            { std::lock_guard<fm::EngineMutex> l(mine.mu); loc = mine.find_import(v); }
             if (!loc) {
                 Engine* o = owner(v);
                 hipEvent_t ready = nullptr;
                 if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) throw Error(FMHIP_ERR_HIP, "hipEventCreate(import)");
                 try {
                     Engine::Exported x;
-                    { std::lock_guard<std::recursive_mutex> l(o->mu); x = o->export_vector(v, ready); }
-                    try { std::lock_guard<std::recursive_mutex> l(mine.mu); loc = mine.import_vector(o->index(), v, x, ready); }
-                    catch (...) { std::lock_guard<std::recursive_mutex> l(o->mu); try { o->release(v); } catch (...) {} throw; }
+                    { std::lock_guard<fm::EngineMutex> l(o->mu); x = o->export_vector(v, ready); }
+                    try { std::lock_guard<fm::EngineMutex> l(mine.mu); loc = mine.import_vector(o->index(), v, x, ready); }
+                    catch (...) { std::lock_guard<fm::EngineMutex> l(o->mu); try { o->release(v); } catch (...) {} throw; }
                 } catch (...) { (void)hipEventDestroy(ready); throw; }
                 (void)hipEventDestroy(ready);                  // (destroyed when the waits on it have been served)
             }
@@ -161,7 +161,7 @@ static int guarded(F&& f) {
         if (thread_engines) te::ensure();
         Engine& e = Engine::get();
         {
-            std::lock_guard<std::recursive_mutex> lock(e.mu);
+            std::lock_guard<fm::EngineMutex> lock(e.mu);
             tl_drives = true;
             e.note_driver();
             if (e.late_count() >= Engine::late_eager()) e.drain_late();      // releases other threads have left (Engine::release_later): preferably performed while the device is waited for
@@ -269,7 +269,7 @@ int fmhip_set_thread_engines(int enabled, int* previous) {
     return te::status_of([&]() -> int {
         std::lock_guard<std::mutex> lock(te::registry_mu);
         Engine& first = Engine::get();
-        { std::lock_guard<std::recursive_mutex> l(first.mu); first.require_init(); }
+        { std::lock_guard<fm::EngineMutex> l(first.mu); first.require_init(); }
         if (first.index() != 0) throw Error(FMHIP_ERR_INVALID_ARGUMENT, "thread engines are switched on from the thread that initialised the library");
         te::engines[0].store(&first, std::memory_order_release);
         te::count.store(1, std::memory_order_release);
@@ -290,7 +290,7 @@ static int shutdown_thread_engines() {
         if (!e) continue;
         Engine::bind_thread(e);
         for (;;) {
-            { std::lock_guard<std::recursive_mutex> l(e->mu); if (e->waits_in_flight.load(std::memory_order_acquire) == 0) { const int st = te::status_of([&]() -> int { if (e->initialized()) e->shutdown(); return FMHIP_OK; }); if (rc == FMHIP_OK) rc = st; break; } }
+            { std::lock_guard<fm::EngineMutex> l(e->mu); if (e->waits_in_flight.load(std::memory_order_acquire) == 0) { const int st = te::status_of([&]() -> int { if (e->initialized()) e->shutdown(); return FMHIP_OK; }); if (rc == FMHIP_OK) rc = st; break; } }
             std::this_thread::yield();
         }
         te::engines[i].store(nullptr, std::memory_order_release);
@@ -310,7 +310,7 @@ int fmhip_shutdown(void) {
     // teardown starts when the last such wait is over (they end by themselves: the device finishes what was launched)
     for (;;) {
         {
-            std::lock_guard<std::recursive_mutex> lock(Engine::get().mu);
+            std::lock_guard<fm::EngineMutex> lock(Engine::get().mu);
             if (Engine::get().waits_in_flight.load(std::memory_order_acquire) == 0) return guarded([&] { Engine::get().shutdown(); });
         }
         std::this_thread::yield();
@@ -371,7 +371,7 @@ struct LateBuffer {
         const auto now = std::chrono::steady_clock::now();
         if (seq != seq_seen) { seq_seen = seq; seq_since = now; return; }
         if (now - seq_since < std::chrono::milliseconds(10)) return;
-        std::lock_guard<std::recursive_mutex> lock(e.mu);
+        std::lock_guard<fm::EngineMutex> lock(e.mu);
         e.drain_late();
         seq_since = now;
     }
@@ -390,7 +390,7 @@ static int release_vector(fmhip_vec v) {
             if (mine.handles.size() >= 256 || ((mine.handles.size() & 15u) == 0 && std::chrono::steady_clock::now() - mine.since > std::chrono::milliseconds(1))) mine.flush();
             return FMHIP_OK;
         }
-        std::lock_guard<std::recursive_mutex> lock(e.mu);
+        std::lock_guard<fm::EngineMutex> lock(e.mu);
         if (e.has_late()) e.drain_late();
         e.release(v);
         return FMHIP_OK;

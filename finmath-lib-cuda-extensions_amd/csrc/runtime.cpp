@@ -22,6 +22,19 @@
 namespace fm {
 static std::atomic<uint64_t> g_te_malloc_ns{ 0 }, g_te_malloc_calls{ 0 }, g_te_init_ns{ 0 };     // FMHIP_TE_TRACE: where an engine's start goes
 
+void EngineMutex::lock_slow(uint64_t me) {
+    for (unsigned spins = 0;; ++spins) {
+        uint64_t expected = 0;
+        if (owner_.load(std::memory_order_relaxed) == 0 && owner_.compare_exchange_weak(expected, me, std::memory_order_acquire, std::memory_order_relaxed)) return;
+        if (spins < 256) {
+#if defined(__x86_64__)
+            _mm_pause();
+#endif
+        } else if (spins < 320) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+}
+
 void hip_check(hipError_t e, const char* what) {
     if (e == hipSuccess) return;
     (void)hipGetLastError();

@@ -206,6 +206,38 @@ private:
     size_t size_ = 0;
 };
 
+// The engine's lock: recursive, and taken and released once per recorded method and once per release — forty million times per calibration of a
+// caller without hints, practically never contended (waits for the device happen outside it).  An owner tag and a depth instead of a pthread
+// recursive mutex; a thread that finds it taken spins briefly, then yields, then naps (a holder keeps it for microseconds, a flush for up to a
+// millisecond).  FMHIP_ENGINE_MUTEX=pthread builds nothing else: the type is chosen at compile time below.
+class EngineMutex {
+public:
+    void lock() {
+        const uint64_t me = self();
+        if (owner_.load(std::memory_order_relaxed) == me) { ++depth_; return; }
+        uint64_t expected = 0;
+        if (!owner_.compare_exchange_strong(expected, me, std::memory_order_acquire, std::memory_order_relaxed)) lock_slow(me);
+        depth_ = 1;
+    }
+    bool try_lock() {
+        const uint64_t me = self();
+        if (owner_.load(std::memory_order_relaxed) == me) { ++depth_; return true; }
+        uint64_t expected = 0;
+        if (!owner_.compare_exchange_strong(expected, me, std::memory_order_acquire, std::memory_order_relaxed)) return false;
+        depth_ = 1;
+        return true;
+    }
+    void unlock() { if (--depth_ == 0) owner_.store(0, std::memory_order_release); }
+private:
+    static uint64_t self() { static std::atomic<uint64_t> next{ 1 }; static thread_local const uint64_t id = next.fetch_add(1); return id; }
+    void lock_slow(uint64_t me);
+    alignas(64) std::atomic<uint64_t> owner_{ 0 };
+    int depth_ = 0;                              // (the owner's)
+    alignas(64) char pad_[8] = { 0 };
+public:
+    EngineMutex() { (void)pad_; }
+};
+
 class Engine {
 public:
     static Engine& get();
@@ -228,7 +260,7 @@ public:
     void release_exported(fmhip_vec h, hipEvent_t done);       // owner side: this stream waits for `done`, then the reference goes
     static void bind_thread(Engine* e);      // Engine::get() of THIS thread returns e from now on (nullptr: the process-wide engine again)
     static bool thread_is_bound();
-    std::recursive_mutex mu;
+    EngineMutex mu;
     // Releases from a thread that is NOT driving the engine — a garbage collector's cleaner thread handing back, in bursts, the handles of
     // objects that died a while ago (java/net/finmath/hip/DeviceVector.java; the reference's ReferenceQueue, RandomVariableCuda.java:293-305)
     // — never take the engine lock one by one: a caller thread that records two million methods a second would meet the releaser on the
