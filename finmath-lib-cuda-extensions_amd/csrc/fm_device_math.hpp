@@ -468,6 +468,52 @@ __device__ __forceinline__ void ueval_div_all(float (&out)[E], const float (&acc
     }
 }
 
+// discount(a, r, s) = a / (1 + r·s) for SEVERAL numerators over the same (r, s) — the chains of a merged loop kernel (jit.cpp:
+// jit_generate_merged_source) all discount by the rate the step has just loaded.  The denominator, its reciprocal, the Newton step and the
+// denominator's share of the range test are taken once (div_prepare_discount); each numerator then costs its quotient, the residual, the
+// one correction and its own share of the range test (ueval_div_prepared).  The same chain on the same numbers as
+// ueval_div_all<U_DISCOUNT_A>: div_pair_in_range(num, den) is a function of its two arguments, the range covers the same operands, and the
+// wave-uniform fallback is div_pair(num, den) — bit-identical by construction.
+template <int E> struct DivPrepared { f32x2 den[E / 2], nd[E / 2], y1[E / 2]; DivRange range; };
+template <int E>
+__device__ __forceinline__ void div_prepare_discount(DivPrepared<E>& P, const float (&r1)[E], const float s) {
+    static_assert(E % 2 == 0, "pairs of elements");
+    const f32x2 sv = { s, s }, one = { 1.0f, 1.0f };
+#pragma unroll
+    for (int p = 0; p < E / 2; ++p) {
+        const f32x2 x = { r1[2 * p], r1[2 * p + 1] };
+        const f32x2 pr = x * sv;
+        P.den[p] = one + pr;
+        f32x2 y;
+        y.x = __builtin_amdgcn_rcpf(P.den[p].x);
+        y.y = __builtin_amdgcn_rcpf(P.den[p].y);
+        P.nd[p] = -P.den[p];
+        const f32x2 e = __builtin_elementwise_fma(P.nd[p], y, one);
+        P.y1[p] = __builtin_elementwise_fma(e, y, y);
+        P.range.take(P.den[p]);
+    }
+}
+template <int E>
+__device__ __forceinline__ void ueval_div_prepared(float (&out)[E], const float (&acc)[E], const DivPrepared<E>& P) {
+    f32x2 num[E / 2], q[E / 2];
+    DivRange range = P.range;
+#pragma unroll
+    for (int p = 0; p < E / 2; ++p) {
+        num[p] = f32x2{ acc[2 * p], acc[2 * p + 1] };
+        const f32x2 q0 = num[p] * P.y1[p];
+        const f32x2 r0 = __builtin_elementwise_fma(P.nd[p], q0, num[p]);
+        q[p] = __builtin_elementwise_fma(r0, P.y1[p], q0);
+        range.take(num[p]);
+    }
+    if (__builtin_amdgcn_ballot_w64(range.outside()) != 0ull) {
+        asm volatile("; division: IEEE expansion with scaling and fix-up for operands outside [2^-48, 2^48)");
+#pragma unroll
+        for (int p = 0; p < E / 2; ++p) q[p] = div_pair(num[p], P.den[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < E / 2; ++p) { out[2 * p] = q[p].x; out[2 * p + 1] = q[p].y; }
+}
+
 // pow with a WAVE-UNIFORM exponent (a scalar operand of the row block), all E elements of a lane: the exponents Monte-Carlo code
 // actually writes take code of their own, chosen ONCE per micro-op by a scalar comparison — the out-of-line fp64 library path (pow_f:
 // ≈ 75 fp64 instructions and a call per element, 2.2-2.35 TB/s for the opcode alone) is left for everything else.  Each special form

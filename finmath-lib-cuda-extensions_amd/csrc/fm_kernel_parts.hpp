@@ -290,15 +290,17 @@ __device__ __forceinline__ void wave_sum_span_partials(const double* __restrict_
 // of a group adds the group's span partials in a fixed order (wave_sum_partials) and, if G > 1, stores the group partial behind
 // the row's workgroup partials and moves the second-level counter; the last of those adds the G group partials.  The final
 // moments are a deterministic function of the data and of the number of spans: no float atomics, no second launch.
+// (block_combine_values: the same with the workgroup's values handed in — wg_sums / wg_ext in LDS, written by lane 0 of the keeper wave; the
+// merged loop kernels reduce their chains one after the other through RedShared<1> and keep the values in a ChainValues<K>)
 template <int NRED>
-__device__ __forceinline__ void block_combine(double* __restrict__ partials, const uint32_t row,
-                                              double* __restrict__ results, uint32_t* __restrict__ counter,       // counter: this row's arrival counter
-                                              uint64_t* done_flag, const uint64_t done_value,                       // see DevProgramArgs::done_flag
-                                              const uint32_t Q)
+__device__ __forceinline__ void block_combine_values(const f64x2* wg_sums, const f32x2* wg_ext,
+                                                     double* __restrict__ partials, const uint32_t row,
+                                                     double* __restrict__ results, uint32_t* __restrict__ counter,       // counter: this row's arrival counter
+                                                     uint64_t* done_flag, const uint64_t done_value,                       // see DevProgramArgs::done_flag
+                                                     const uint32_t Q)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (wave != red_keeper_wave()) return;
-    RedShared<NRED>& S = red_shared<NRED>();
 
     const uint32_t slots = gridDim.x + FM_COMBINE_GROUP_SLOTS;             // per (row, reduction)
     const uint32_t spans = (gridDim.x + Q - 1u) / Q;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
     if (lane == 0u) {
 #pragma unroll
         for (int r = 0; r < NRED; ++r) {
-            const f64x2 w = S.wg_sums[r]; const f32x2 e = S.wg_ext[r];      // (written by this very lane: red_span_fold)
+            const f64x2 w = wg_sums[r]; const f32x2 e = wg_ext[r];          // (written by this very lane: red_span_fold)
             const double s1 = w.x, s2 = w.y;
             const float mn = e.x, mx = e.y;
             double* out = partials + (((size_t)row * NRED + r) * slots + blockIdx.x) * 4;
@@ -400,6 +402,37 @@ __device__ __forceinline__ void block_combine(double* __restrict__ partials, con
         }
     }
     if (done_flag && lane == 63u) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <int NRED>
+__device__ __forceinline__ void block_combine(double* __restrict__ partials, const uint32_t row,
+                                              double* __restrict__ results, uint32_t* __restrict__ counter,
+                                              uint64_t* done_flag, const uint64_t done_value, const uint32_t Q)
+{
+    RedShared<NRED>& S = red_shared<NRED>();
+    block_combine_values<NRED>(S.wg_sums, S.wg_ext, partials, row, results, counter, done_flag, done_value, Q);
+}
+
+// ---- Several reductions of ONE tile taken one after the other (merged loop kernels: K chains, K up to 16).  RedShared<K> would hold K lane
+// transpositions at once (24 bytes per lane and reduction: 86 KB for 14); here every chain goes through the one slot of RedShared<1> — its
+// tile is one unit of the tree, folded at once — and leaves its value in ChainValues<K>.  Same order of additions per chain as a kernel
+// that reduces that chain alone with one tile per workgroup (red_tile_end<1, 8> with rel = 0, last = true).
+template <int K> struct ChainValues { f64x2 wg_sums[K]; f32x2 wg_ext[K]; };
+template <int K> __device__ __forceinline__ ChainValues<K>& chain_values() { __shared__ ChainValues<K> v; return v; }
+template <int K, int E>
+__device__ __forceinline__ void red_chain_unit(const int k, const float (&x)[E], const double shift_value, const bool pass_full,
+                                               const uint32_t (&i4)[E / FM_VEC], const int64_t n)
+{
+    static_assert(FM_BLOCK * E == FM_UNIT_ELEMS, "the workgroup's tile is one unit of the reduction tree");
+    double acc_sum[1] = { 0.0 }, acc_sq[1] = { 0.0 }, shift[1] = { shift_value }; unsigned long long nan_mask[1] = { 0ull };
+    float acc_min[1] = { __builtin_huge_valf() }, acc_max[1] = { -__builtin_huge_valf() };
+    red_accumulate<E>(x, shift[0], pass_full, i4, n, acc_sum[0], acc_sq[0], acc_min[0], acc_max[0], nan_mask[0]);
+    red_unit_end<1>(acc_sum, acc_sq, acc_min, acc_max, nan_mask, shift, 0u);
+    red_span_fold<1>(1u, true);
+    if ((threadIdx.x >> 6) == red_keeper_wave() && (threadIdx.x & 63u) == 0u) {
+        RedShared<1>& S = red_shared<1>();
+        ChainValues<K>& V = chain_values<K>();
+        V.wg_sums[k] = S.wg_sums[0]; V.wg_ext[k] = S.wg_ext[0];
+    }
 }
 
 } // namespace fm

@@ -125,7 +125,7 @@ struct DevRolledArgs {
     uint32_t tiles_per_row;              // passes of FM_BLOCK*E elements
     uint32_t row_words;                  // row stride in 8-byte words
     uint32_t iterations;
-    uint32_t pad;
+    uint32_t pad;                        // merged launches: chains per row (results: [rows][chains][4]); else 0
     uint64_t dump;                       // FM_DUMP_BYTES of device memory nobody reads: where lanes past the end of a vector put their stores
     // kernels with a fused reduction of one of their values (one unit of the reduction tree per workgroup: fm_kernel_parts.hpp), else unused
     double    shift;                     // subtracted from every element before it is added (getVariance's second pass)

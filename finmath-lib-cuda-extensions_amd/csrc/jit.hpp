@@ -85,7 +85,20 @@ struct RolledBody {
         // tree (fm_kernel_parts.hpp), so the moments are those of the stand-alone reduction to the last bit.
         std::string reduce;
     } peel;
+    // MERGED form (chains >= 2; runtime.cpp: merge_families): ONE launch serves `chains` components of this very shape whose inputs —
+    // the head's own vectors, then the loop's, one per step — are the same vectors, the shorter components reading a SUFFIX of the longest
+    // one's sequence (the swaptions of one exercise date, tenor by tenor: each reads the forward rates from its last period back to the
+    // exercise date).  A step loads its vector once and every chain that has started takes its turn on it: the head's operations in the
+    // chain's first steps (one stage per head input), the loop body afterwards; the tail and the moments of every chain behind the loop.
+    // Preconditions (the host checks them, the generator returns an empty string otherwise): peeled with a reduction, 8 elements per
+    // lane, no loop-invariant inputs, one input and no output per iteration, nothing stored by the head, final values = carried values.
+    // shared_den: every `discount(·, <the step's vector>, s)` of head and body carries the same scalar in all chains (the host compares
+    // them launch by launch): denominator, reciprocal and Newton step are computed once per step (fm_device_math.hpp: DivPrepared).
+    uint32_t chains = 0;
+    bool shared_den = false;
 };
+// Where the scalars that shared_den needs to be equal sit: indices into the head's scalar list and into one iteration's.
+void jit_merged_shared_scalars(const RolledBody& body, std::vector<uint32_t>& pre_slots, std::vector<uint32_t>& body_slots);
 std::string jit_generate_rolled_source(const RolledBody& body);
 std::string jit_describe(const RolledBody& body);
 bool jit_parse_description(const std::string& line, RolledBody& body);

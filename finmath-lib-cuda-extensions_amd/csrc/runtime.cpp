@@ -2394,7 +2394,7 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     if (body.elems == 8) {
         if (n > end) pl.reduce = "q" + std::to_string(n - 1 - end);
         else if (final_of[(n - 1 - begin) % P] >= 0) pl.reduce = "F" + std::to_string(final_of[(n - 1 - begin) % P]);
-        if (!pl.reduce.empty()) { jit().record(jit_describe(body)); pe.source_red = jit_generate_rolled_source(body); }
+        if (!pl.reduce.empty()) { pe.desc_red = jit_describe(body); jit().record(pe.desc_red); pe.source_red = jit_generate_rolled_source(body); }
     }
     ro.peeled = std::move(pe);
     return true;
@@ -2819,6 +2819,297 @@ void Engine::plan_loop(BigPlan& plan, const BigDag& g) {
     if (jit_mode != FMHIP_JIT_OFF) plan.rolled.jit = jit().request_source(std::move(source), elems, jit_mode == FMHIP_JIT_SYNC);
 }
 
+// ---------------------------------------------------------------- merged chains (runtime.hpp: merge_families; jit.hpp: RolledBody::chains)
+//
+// The 14 swaptions of one exercise date are 14 components of the same loop shape and different length — 14 launches by shape (each with the
+// other exercise dates' swaptions of that tenor as its rows), every one of which reads the forward rates of its tenor: L_e[e] 14 times,
+// L_e[e + 19] five times, 304 vector reads per exercise date where 61 vectors exist.  A FAMILY is a set of such components, found by
+// their vectors: same shape of head, body and tail, the same tail inputs, and the head + loop inputs of each a suffix of the longest
+// one's.  One launch per (shape, family size): a row per family, a step per vector of the longest chain, every chain joining at its own
+// first step; per chain the same operations on the same operands in the same order as in its own launch, and its moments by the same
+// tree — bit-identical results, a fifth of the bytes.  Nothing is assumed about the caller: the family is read off the pending graph.
+static const bool MERGE_CHAINS = [] { const char* e = std::getenv("FMHIP_MERGE_CHAINS"); return !(e && e[0] == '0'); }();
+
+void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
+{
+    if (!MERGE_CHAINS || !want_root_moments_ || jit_mode == FMHIP_JIT_OFF || groups.size() < 2) return;
+    struct Chain { size_t group, member; BigPlan* plan; Node* root; uint32_t steps; const float* last; };
+    std::vector<Chain> chains;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        std::vector<BigDag>& g = groups[gi];
+        if (g.empty() || g[0].described() || g[0].n <= 0) continue;
+        auto planned = plan_cache_.find(g[0].hash);
+        if (planned == plan_cache_.end() || planned->second.sig != g[0].sig) continue;
+        BigPlan& plan = planned->second;
+        BigPlan::Rolled& ro = plan.rolled;
+        BigPlan::Rolled::Peeled& pe = ro.peeled;
+        if (!ro.present || !pe.present || pe.desc_red.empty() || pe.elems != 8) continue;
+        if (pe.mergeable < 0) {
+            RolledBody body;
+            pe.mergeable = 0;
+            if (jit_parse_description(pe.desc_red, body)) { body.chains = 2; body.shared_den = true; pe.mergeable = jit_generate_rolled_source(body).empty() ? 0 : 1; }
+        }
+        if (!pe.mergeable) continue;
+        const size_t tiles = (size_t)((g[0].n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS);
+        if (tiles > (size_t)FM_SPAN_UNITS * 65536) continue;
+        const size_t NXa = pe.extra_leaf.size() - 0;      // (split into head / tail inputs below)
+        (void)NXa;
+        for (size_t mi = 0; mi < g.size(); ++mi) {
+            const BigDag& b = g[mi];
+            Node* r = single_root(b, g[0]);
+            if (!r || r->moments_blocked || (plan.discards_root && !r->discard) || r->buf) continue;
+            const int32_t last_leaf = ro.iter_leaf[(size_t)(ro.iterations - 1) * ro.leaf_in.size()];
+            const Buffer* lb = b.leaves[(size_t)last_leaf]->buf;
+            if (!lb) continue;
+            chains.push_back({ gi, mi, &plan, r, 0u, lb->ptr });
+        }
+    }
+    if (chains.size() < 2) return;
+    // head inputs per description (the generator's numbers): parsed once per plan
+    struct Shape { RolledBody body; size_t NXa = 0, NXP = 0, NS0 = 0, NS2 = 0, LS = 0, NXO = 0; std::vector<uint32_t> shared_pre, shared_body; };
+    std::unordered_map<const BigPlan*, Shape> shapes;
+    auto shape_of = [&](BigPlan* plan) -> Shape& {
+        auto it = shapes.find(plan);
+        if (it != shapes.end()) return it->second;
+        Shape& sh = shapes[plan];
+        jit_parse_description(plan->rolled.peeled.desc_red, sh.body);
+        sh.NXa = sh.body.peel.extra_pre; sh.NXP = sh.body.peel.extra_post;
+        sh.NS0 = plan->rolled.peeled.n_pre_scal; sh.NS2 = plan->rolled.peeled.n_post_scal; sh.LS = plan->rolled.scal_pos.size(); sh.NXO = plan->rolled.peeled.post_out.size();
+        jit_merged_shared_scalars(sh.body, sh.shared_pre, sh.shared_body);
+        return sh;
+    };
+    auto leaf_ptr = [](const BigDag& b, int32_t leaf) -> const float* { const Buffer* x = b.leaves[(size_t)leaf]->buf; return x ? x->ptr : nullptr; };
+    // the vector a chain reads at step i of its own sequence (head inputs first, then one per iteration)
+    auto seq_ptr = [&](const Chain& c, const Shape& sh, size_t i) -> const float* {
+        const BigDag& b = groups[c.group][c.member];
+        const BigPlan::Rolled& ro = c.plan->rolled;
+        return i < sh.NXa ? leaf_ptr(b, ro.peeled.extra_leaf[i]) : leaf_ptr(b, ro.iter_leaf[(i - sh.NXa) * ro.leaf_in.size()]);
+    };
+    for (Chain& c : chains) c.steps = (uint32_t)(shape_of(c.plan).NXa + c.plan->rolled.iterations);
+    // candidates by (description, last vector, tail inputs, length of the vectors): longest first
+    std::sort(chains.begin(), chains.end(), [&](const Chain& a, const Chain& b) {
+        const std::string& da = a.plan->rolled.peeled.desc_red; const std::string& db = b.plan->rolled.peeled.desc_red;
+        if (da != db) return da < db;
+        if (a.last != b.last) return a.last < b.last;
+        if (a.steps != b.steps) return a.steps > b.steps;
+        if (a.group != b.group) return a.group < b.group;
+        return a.member < b.member;
+    });
+    struct Family { std::vector<size_t> chain; };          // indices into `chains`, longest first
+    std::vector<Family> families;
+    for (size_t i = 0; i < chains.size();) {
+        size_t j = i + 1;
+        while (j < chains.size() && chains[j].last == chains[i].last && chains[j].plan->rolled.peeled.desc_red == chains[i].plan->rolled.peeled.desc_red) ++j;
+        // [i, j): same description, same last vector.  Those whose whole sequence is a suffix of the longest one's and whose tail inputs
+        // and shared scalars agree with it form families of at most 16.
+        const Chain& lead = chains[i];
+        const Shape& sh = shape_of(lead.plan);
+        const BigDag& lb = groups[lead.group][lead.member];
+        auto first_shared = [&](const Chain& c, bool* any) -> float {
+            const BigDag& b = groups[c.group][c.member];
+            const BigPlan::Rolled& ro = c.plan->rolled;
+            *any = !(sh.shared_pre.empty() && sh.shared_body.empty());
+            if (!sh.shared_pre.empty()) return b.scalar_at(ro.peeled.pre_scal[sh.shared_pre[0]]);
+            if (!sh.shared_body.empty()) return b.scalar_at(ro.begin + ro.scal_pos[sh.shared_body[0]]);
+            return 0.f;
+        };
+        bool any_shared = false;
+        const float s_star = first_shared(lead, &any_shared);
+        Family fam;
+        for (size_t q = i; q < j; ++q) {
+            const Chain& c = chains[q];
+            const BigDag& b = groups[c.group][c.member];
+            const BigPlan::Rolled& ro = c.plan->rolled;
+            bool ok = b.n == lb.n;
+            for (size_t x = 0; ok && x < sh.NXP; ++x) ok = leaf_ptr(b, ro.peeled.extra_leaf[sh.NXa + x]) == leaf_ptr(lb, lead.plan->rolled.peeled.extra_leaf[sh.NXa + x]) && leaf_ptr(b, ro.peeled.extra_leaf[sh.NXa + x]) != nullptr;
+            const size_t shift = lead.steps - c.steps;
+            for (size_t t = 0; ok && t < c.steps; ++t) { const float* p = seq_ptr(c, sh, t); ok = p != nullptr && p == seq_ptr(lead, sh, shift + t); }
+            // every scalar the shared denominators stand for carries the same bits
+            if (ok && any_shared) {
+                uint32_t want; std::memcpy(&want, &s_star, 4);
+                auto same = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u == want; };
+                for (uint32_t sl : sh.shared_pre) ok = ok && same(b.scalar_at(ro.peeled.pre_scal[sl]));
+                for (size_t r = 0; ok && r < ro.iterations; ++r) for (uint32_t sl : sh.shared_body) ok = ok && same(b.scalar_at(ro.begin + r * ro.period + ro.scal_pos[sl]));
+            }
+            if (!ok) continue;
+            fam.chain.push_back(q);
+            if (fam.chain.size() == 16) { families.push_back(std::move(fam)); fam = Family(); }
+        }
+        if (fam.chain.size() >= 2) families.push_back(std::move(fam));
+        i = j;
+    }
+    // (a family that starts with a chain other than `lead` after a split of 16 still has its own longest chain first: the sort above)
+    families.erase(std::remove_if(families.begin(), families.end(), [](const Family& f) { return f.chain.size() < 2; }), families.end());
+    if (families.empty()) return;
+    // kernels: one per (description, family size); a family whose kernel does not exist yet runs as before
+    struct Launch { std::string key; std::shared_ptr<JitSlot> slot; std::vector<size_t> rows; };
+    std::vector<Launch> launches;
+    std::unordered_map<std::string, size_t> launch_of;
+    for (size_t f = 0; f < families.size(); ++f) {
+        // a split family's later part must be a family of its own: its first chain is its longest, the others suffixes of the LEAD's sequence — hence of its own
+        const Chain& lead = chains[families[f].chain[0]];
+        const size_t K = families[f].chain.size();
+        std::string key = lead.plan->rolled.peeled.desc_red + " chains " + std::to_string(K) + " sden 1";
+        auto known = launch_of.find(key);
+        if (known == launch_of.end()) {
+            std::shared_ptr<JitSlot>& slot = merged_kernels_[key];
+            if (!slot || (jit_mode == FMHIP_JIT_SYNC && slot->state.load(std::memory_order_acquire) == JitSlot::QUEUED)) {
+                RolledBody body = shape_of(lead.plan).body;
+                body.chains = (uint32_t)K; body.shared_den = true;
+                std::string source = jit_generate_rolled_source(body);
+                if (source.empty()) continue;
+                jit().record(jit_describe(body));
+                slot = jit().request_source(std::move(source), 8, jit_mode == FMHIP_JIT_SYNC);
+            }
+            known = launch_of.emplace(key, launches.size()).first;
+            launches.push_back({ key, slot, {} });
+        }
+        launches[known->second].rows.push_back(f);
+    }
+    // the original of a replicated component and its copies go together or not at all: a copy left behind would have nobody to carry its
+    // order (run_plan), a copy taken without its original nobody to … — if any set is split, nothing is merged in this flush
+    std::vector<std::vector<char>> taken(groups.size());
+    for (size_t gi = 0; gi < groups.size(); ++gi) taken[gi].assign(groups[gi].size(), 0);
+    for (const Launch& l : launches) {
+        if (!l.slot || l.slot->state.load(std::memory_order_acquire) != JitSlot::READY) continue;
+        for (size_t f : l.rows) for (size_t q : families[f].chain) taken[chains[q].group][chains[q].member] = 1;
+    }
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const std::vector<BigDag>& g = groups[gi];
+        for (size_t mi = 0; mi < g.size(); ++mi) {
+            if (g[mi].described()) continue;
+            size_t e = mi + 1;
+            while (e < g.size() && g[e].described()) ++e;
+            for (size_t q = mi + 1; q < e; ++q) if (taken[gi][q] != taken[gi][mi]) return;
+        }
+    }
+    const int64_t n = groups[chains[0].group][chains[0].member].n;
+    for (Launch& l : launches) {
+        if (!l.slot || l.slot->state.load(std::memory_order_acquire) != JitSlot::READY || l.rows.empty()) continue;
+        const Shape& sh = shape_of(chains[families[l.rows[0]].chain[0]].plan);
+        const size_t K = families[l.rows[0]].chain.size();
+        const size_t P = chains[families[l.rows[0]].chain[0]].plan->rolled.period;
+        auto section_words = [&](const Chain& c) { return sh.NXO + (sh.NS0 + (size_t)c.plan->rolled.iterations * sh.LS + sh.NS2 + 1) / 2; };
+        size_t rw = 0;
+        for (size_t f : l.rows) {
+            size_t w = 1 + K + chains[families[f].chain[0]].steps + sh.NXP + 1;
+            for (size_t q : families[f].chain) w += section_words(chains[q]);
+            rw = std::max(rw, w);
+        }
+        const size_t max_rows = std::min((size_t)1024, ring_cap_ / (rw * 8 + 256));
+        if (max_rows == 0) continue;
+        for (size_t off = 0; off < l.rows.size(); off += max_rows) {
+            const size_t count = std::min(max_rows, l.rows.size() - off);
+            std::vector<uint64_t> table(count * rw, 0);
+            struct Out { size_t chain, pos; Buffer* buf; };
+            std::vector<Out> outs;
+            size_t n_ops = 0, n_vec_in = 0;
+            std::vector<fmhip_moments> all;
+            ReduceRequest every{ 0.0, nullptr, nullptr, false };
+            RedLaunch red;
+            try {
+                for (size_t r = 0; r < count; ++r) {
+                    const Family& fam = families[l.rows[off + r]];
+                    const Chain& lead = chains[fam.chain[0]];
+                    uint64_t* row = table.data() + r * rw;
+                    const size_t T = lead.steps;
+                    row[0] = (uint64_t)T;
+                    for (size_t t = 0; t < T; ++t) row[1 + K + t] = (uint64_t)(uintptr_t)seq_ptr(lead, sh, t);
+                    const BigDag& lb = groups[lead.group][lead.member];
+                    for (size_t x = 0; x < sh.NXP; ++x) row[1 + K + T + x] = (uint64_t)(uintptr_t)leaf_ptr(lb, lead.plan->rolled.peeled.extra_leaf[sh.NXa + x]);
+                    { bool any = false; float s_star = 0.f;
+                      if (!sh.shared_pre.empty()) { any = true; s_star = lb.scalar_at(lead.plan->rolled.peeled.pre_scal[sh.shared_pre[0]]); }
+                      else if (!sh.shared_body.empty()) { any = true; s_star = lb.scalar_at(lead.plan->rolled.begin + lead.plan->rolled.scal_pos[sh.shared_body[0]]); }
+                      uint32_t bits = 0; if (any) std::memcpy(&bits, &s_star, 4);
+                      row[1 + K + T + sh.NXP] = bits; }
+                    size_t at = 1 + K + T + sh.NXP + 1;
+                    n_vec_in += T + sh.NXP;
+                    for (size_t k = 0; k < K; ++k) {
+                        const Chain& c = chains[fam.chain[k]];
+                        BigDag& b = groups[c.group][c.member];
+                        const BigPlan::Rolled& ro = c.plan->rolled;
+                        const BigPlan::Rolled::Peeled& pe = ro.peeled;
+                        row[1 + k] = (uint64_t)(T - c.steps) | ((uint64_t)at << 32);
+                        uint64_t* sec = row + at;
+                        for (size_t m = 0; m < sh.NXO; ++m) { Buffer* nb = new_buffer(n); outs.push_back({ fam.chain[k], pe.post_out[m], nb }); sec[m] = (uint64_t)(uintptr_t)nb->ptr; }
+                        float* sc = reinterpret_cast<float*>(sec + sh.NXO);
+                        for (size_t i = 0; i < sh.NS0; ++i) sc[i] = b.scalar_at(pe.pre_scal[i]);
+                        for (size_t it = 0; it < ro.iterations; ++it)
+                            for (size_t m = 0; m < sh.LS; ++m) sc[sh.NS0 + it * sh.LS + m] = b.scalar_at(ro.begin + it * P + ro.scal_pos[m]);
+                        for (size_t i = 0; i < sh.NS2; ++i) sc[sh.NS0 + (size_t)ro.iterations * sh.LS + i] = b.scalar_at(pe.post_scal[i]);
+                        at += section_words(c);
+                        n_ops += pe.n_ops;
+                    }
+                }
+                const int64_t tiles = (n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS;
+                if (async_moments_) { every.dev_out = arena_alloc(count * K); if (!every.dev_out) { for (Out& o : outs) buffer_unref(o.buf); continue; } }
+                else { all.resize(count * K); every.host_out = all.data(); }
+                DevRolledArgs args{};
+                args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = 0; args.pad = (uint32_t)K;
+                args.dump = (uint64_t)(uintptr_t)dump_dev_;
+                const size_t table_bytes = table.size() * 8;
+                const size_t ring_off = ring_reserve(table_bytes);
+                std::memcpy((char*)ring_host_ + ring_off, table.data(), table_bytes);
+                hip_check(hipMemcpyAsync((char*)ring_dev_ + ring_off, (char*)ring_host_ + ring_off, table_bytes, hipMemcpyHostToDevice, stream_), "merged row table H2D");
+                const uint64_t* rows_arg = (const uint64_t*)((char*)ring_dev_ + ring_off);
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
+                void* params[] = { &args, &rows_arg };
+                red_begin(red, (int)count, (int)K, (size_t)tiles, every.host_out, every.dev_out);
+                args.shift = 0.0; args.partials = (double*)red.partials; args.results = (double*)red.results; args.counters = counters_dev_;
+                args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
+                hip_check(hipModuleLaunchKernel(l.slot->fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch merged kernel");
+                if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
+                                  profile_tags_.push_back({ (int)(n_ops / count), (int)(n_vec_in / count), (int)(K * sh.NXO), (int)K, (int)count, 4, n }); }
+                n_launches_++; n_jit_launches_++; n_rolled_launches_++; n_merged_launches_++; n_merged_chains_ += (int64_t)(count * K);
+                n_ops_executed_ += (int64_t)n_ops;
+                algorithmic_bytes_ += 4 * n * (int64_t)(n_vec_in + outs.size());
+                bytes_written_ += 4 * n * (int64_t)outs.size();
+                every.done = true;
+                red_wait(red, (int)count, (int)K, every.host_out);
+            } catch (...) { red_release(red); for (Out& o : outs) buffer_unref(o.buf); throw; }
+            red_release(red);
+            // the moments go to the chains' roots; stored values become vectors; expressions are dismantled
+            for (size_t r = 0; r < count; ++r) {
+                const Family& fam = families[l.rows[off + r]];
+                for (size_t k = 0; k < K; ++k) {
+                    Node* root = chains[fam.chain[k]].root;
+                    if (every.dev_out) arena_assign(root, (double*)every.dev_out + (r * K + k) * 4);
+                    else { const fmhip_moments& m = all[r * K + k]; root->moments[0] = m.sum; root->moments[1] = m.sumsq; root->moments[2] = m.min; root->moments[3] = m.max; root->has_moments = true; }
+                }
+            }
+            std::vector<Node*> done;
+            for (Out& o : outs) {
+                const Chain& c = chains[o.chain];
+                BigDag& b = groups[c.group][c.member];
+                if (b.described()) commit_described(b, o.pos, o.buf);
+                else { Node* nd = b.order[o.pos]; commit_node(nd, o.buf); done.push_back(nd); }
+            }
+            for (Node* nd : done) nd->refs_int++;
+            for (Node* nd : done) drop_expression(nd);
+            for (Node* nd : done) { nd->refs_int--; node_maybe_free(nd); }
+            for (size_t r = 0; r < count; ++r)
+                for (size_t q : families[l.rows[off + r]].chain) {
+                    const Chain& c = chains[q];
+                    BigDag& b = groups[c.group][c.member];
+                    if (c.plan->discards_root && !c.root->buf) { c.root->discarded = true; c.root->refs_int++; drop_expression(c.root); c.root->refs_int--; }
+                    if (b.described()) for (Buffer*& t : b.temp) if (t) { buffer_unref(t); t = nullptr; }
+                    taken[c.group][c.member] = 2;                       // has run
+                }
+        }
+    }
+    // what has run leaves its group (the others keep their order: the first member of a group carries the order for its copies)
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        std::vector<BigDag>& g = groups[gi];
+        bool any = false;
+        for (char t : taken[gi]) any |= t == 2;
+        if (!any) continue;
+        std::vector<BigDag> rest;
+        for (size_t mi = 0; mi < g.size(); ++mi) if (taken[gi][mi] != 2) rest.push_back(std::move(g[mi]));
+        g.swap(rest);
+    }
+}
+
 void Engine::run_big_group(std::vector<BigDag>& group, ReduceRequest* rr) {
     HostTimer timer(HostProfile::RUN_BIG);
     BigDag& g0 = group[0];
@@ -3005,10 +3296,13 @@ void Engine::flush_all() {
                 members.push_back(std::move(b));
             }
             if (expanded) continue;
-            for (uint64_t key : big_group_order) {
-                std::vector<BigDag>& originals = big_groups[key];
-                std::vector<BigDag> members;
-                std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done;
+            // members of every group: its components, each followed by its copies that exist as a description
+            std::vector<std::vector<BigDag>> all_members(big_group_order.size());
+            std::vector<std::vector<std::pair<ReplicaGroup*, std::vector<int>>>> all_done(big_group_order.size());
+            for (size_t ki = 0; ki < big_group_order.size(); ++ki) {
+                std::vector<BigDag>& originals = big_groups[big_group_order[ki]];
+                std::vector<BigDag>& members = all_members[ki];
+                std::vector<std::pair<ReplicaGroup*, std::vector<int>>>& done = all_done[ki];
                 for (BigDag& b : originals) {
                     ReplicaGroup* rg = b.rep_any ? clean_replica_group(b.rep_id, b.rep_uniform) : nullptr;
                     if (!rg) { members.push_back(std::move(b)); continue; }
@@ -3035,9 +3329,16 @@ void Engine::flush_all() {
                         members.push_back(std::move(r));
                     }
                 }
-                try { run_big_group(members); }
-                catch (...) { replicas_after_failure(done); throw; }
-                for (auto& kv : done) replica_roots_done(kv.first, kv.second);
+            }
+            // components of one loop shape that read the same vectors, one a suffix of the other's: one launch per family size (merge_families)
+            try { merge_families(all_members); }
+            catch (...) { for (auto& done : all_done) replicas_after_failure(done); throw; }
+            for (size_t ki = 0; ki < big_group_order.size(); ++ki) {
+                if (!all_members[ki].empty()) {
+                    try { run_big_group(all_members[ki]); }
+                    catch (...) { for (size_t kj = ki; kj < big_group_order.size(); ++kj) replicas_after_failure(all_done[kj]); throw; }
+                }
+                for (auto& kv : all_done[ki]) replica_roots_done(kv.first, kv.second);
             }
         }
     }
@@ -3547,6 +3848,7 @@ void Engine::engine_stats(fmhip_engine_stats_t* out) {
     out->pending_operations = (int64_t)n_pending_;
     out->peak_bytes_reserved = pool_.peak_reserved;
     out->late_releases_while_waiting = n_late_waiting_; out->late_releases_at_once = n_late_at_once_; out->late_release_nanoseconds = late_ns_;
+    out->merged_launches = n_merged_launches_; out->merged_chains = n_merged_chains_;
 }
 
 void Engine::pool_stats(fmhip_pool_stats_t* out) {
@@ -3587,7 +3889,7 @@ void Engine::profile_read(double* ms_total, int64_t* n) {
         if (dump && i < profile_tags_.size()) {
             const ProfileTag& t = profile_tags_[i];
             char key[128];
-            std::snprintf(key, sizeof key, "ops %3d in %2d out %d red %d rows %4d n %9lld %s", t.n_ops, t.n_in, t.n_out, t.n_red, t.batch, (long long)t.n, t.tier == 3 ? "fm_bm_kernel" : t.tier ? "specialised" : "interpreter");
+            std::snprintf(key, sizeof key, "ops %3d in %2d out %d red %d rows %4d n %9lld %s", t.n_ops, t.n_in, t.n_out, t.n_red, t.batch, (long long)t.n, t.tier == 4 ? "merged chains" : t.tier == 3 ? "fm_bm_kernel" : t.tier ? "specialised" : "interpreter");
             Agg& a = agg[key];
             a.launches++; a.ms += ms; a.bytes += 4.0 * (double)t.n * (t.n_in + t.n_out) * t.batch;
         }

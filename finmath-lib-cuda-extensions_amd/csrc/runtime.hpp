@@ -503,6 +503,8 @@ private:
                 std::vector<char> final_store;                          // per final value: stored?
                 // the variant that also takes the moments of the component's root (RolledBody::Peel::reduce); compiled when first asked for
                 std::string source_red; std::shared_ptr<JitSlot> jit_red;
+                std::string desc_red;                                   // its one-line description (jit.hpp): what the merged form (merge_families) is derived from
+                int mergeable = -1;                                     // -1: not looked at yet; 0 / 1: this shape may be a chain of a merged launch
             } peeled;
             std::vector<uint32_t> out_pos, scal_pos;                    // positions stored per iteration; positions with a scalar operand
             std::vector<uint32_t> final_pos;                            // positions whose value of the LAST iteration is stored behind the loop
@@ -597,6 +599,13 @@ private:
     bool plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, const RolledBody& body);
     void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr);
     int64_t n_rolled_launches_ = 0;
+    // Components of ONE loop shape whose vectors are the same sequence, the shorter ones reading a suffix of the longest one's (the swaptions
+    // of one exercise date: every tenor reads the forward rates from its last period back to the exercise date), as ONE launch that loads
+    // every vector once (jit.hpp: RolledBody::chains).  Looked for among the large components of a flush that takes the moments of all
+    // pending roots along; whatever does not fit — a kernel not compiled yet, a family of one — runs as before.  FMHIP_MERGE_CHAINS=0: off.
+    void merge_families(std::vector<std::vector<BigDag>>& groups);
+    std::unordered_map<std::string, std::shared_ptr<JitSlot>> merged_kernels_;        // by description of the merged body
+    int64_t n_merged_launches_ = 0, n_merged_chains_ = 0;
     // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)
     std::unordered_map<uint32_t, ReplicaGroup*> replicas_;
     uint32_t next_replica_id_ = 1;

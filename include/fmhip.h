@@ -448,6 +448,9 @@ typedef struct fmhip_engine_stats_t {
     /* releases that arrived from a thread which only ever releases (a collector's cleaner): queued, and performed by a driving thread
      * while it waited for the device / at once because too many waited; the time the driving threads spent on them */
     int64_t late_releases_while_waiting, late_releases_at_once, late_release_nanoseconds;
+    /* launches that served several components of one loop shape reading the same sequence of vectors (each vector loaded once for all of
+     * them: the swaptions of one exercise date), and how many components they served */
+    int64_t merged_launches, merged_chains;
 } fmhip_engine_stats_t;
 int fmhip_engine_stats(fmhip_engine_stats_t* out);
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);

@@ -130,7 +130,7 @@ hipError_t hipModuleLaunchKernel(hipFunction_t f, unsigned, unsigned gy, unsigne
     ++g_launches;
     if (reinterpret_cast<NullFunction*>(f)->rolled) {
         const fm::DevRolledArgs& a = *reinterpret_cast<const fm::DevRolledArgs*>(params[0]);
-        if (a.results) write_moments(a.results, gy, a.n, a.done_flag, a.done_value);
+        if (a.results) write_moments(a.results, (size_t)gy * (a.pad ? a.pad : 1u), a.n, a.done_flag, a.done_value);      // (pad: chains per row of a merged launch)
     } else {
         const fm::DevProgramArgs& a = *reinterpret_cast<const fm::DevProgramArgs*>(params[0]);
         touch_rows(a, *reinterpret_cast<const uint64_t* const*>(params[1]), gy);
