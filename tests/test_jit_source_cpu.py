@@ -100,6 +100,52 @@ def test_kernel_pack_is_built_from_its_descriptions():
     assert out.stdout.startswith(f"{len(lines)} descriptions, 0 round-trip differences")
 
 
+VALUATION = ("rolled elems 8 log 0 globals 0 inputs 1 carried 3 final 3 out body 14:l0:-:-:s 16:v0:-:-:s 22:c0:v1:-:- 30:v2:l0:-:s peel 2 1 init p6 preout postout 1 "
+             "finalstore 0 pre 14:x0:-:-:s 16:p0:-:-:s 30:p1:x0:-:s 14:x1:-:-:s 16:p3:-:-:s 22:p2:p4:-:- 30:p5:x1:-:s post 12:F0:-:-:s 26:q0:x2:-:- reduce q1")
+
+
+def test_merged_chain_kernel_source(tmp_path):
+    """The merged form of a loop shape (jit.hpp: RolledBody::chains; the swaption's backward induction of SwaptionSimple): K chains over one
+    sequence of vectors.  Every step loads its vector once and prepares the discount denominator once; each chain runs the head's two
+    stages, then the loop body, on that vector; the tails share the numeraire; K reductions, one hand-off.  A shape that does not meet the
+    preconditions has no merged form (empty source: the engine then leaves its components alone).  The source compiles for gfx950."""
+    import shutil
+    import subprocess
+    import pytest
+    pkg = os.path.join(ROOT, "finmath-lib-cuda-extensions_amd")
+    tool = os.path.join(pkg, "build", "jit_pack_tool")
+    if not os.path.exists(tool):
+        import __graft_entry__
+        __graft_entry__.build()
+    K = 5
+    desc = tmp_path / "merged.txt"
+    desc.write_text(VALUATION + f" chains {K} sden 1\n")
+    chk = subprocess.run([tool, "--check", str(desc)], capture_output=True, text=True, timeout=60)
+    assert chk.returncode == 0 and chk.stdout.startswith("1 descriptions, 0 round-trip differences"), chk.stdout + chk.stderr
+    src = subprocess.run([tool, "--source", str(desc), "rolled"], capture_output=True, text=True, timeout=60).stdout
+    assert f"merged loop: {K} chains" in src and "shared denominators" in src
+    assert src.count("load_stream(p, i4c[t])") == 3                       # the first step's vector, the next step's inside the loop, the numeraire: nothing per chain
+    assert src.count("div_prepare_discount<E>(D, l, sden)") == 1            # the denominator of every discount of a step, once
+    assert src.count("ueval_div_prepared<E>(") == 3 * K                   # head stage 0, head stage 1, body: per chain
+    assert src.count("ueval_div_all<26u, E>(") == K                       # the tail's division by the numeraire
+    assert src.count("red_chain_unit<K, E>(") == K and src.count("block_combine_values<K>(") == 1
+    assert src.count("if (t >= t0_") == K and src.count("__builtin_nontemporal_store(") == K      # a chain joins at its own first step; its root is stored once
+    # no merged form: a shape whose loop stores a value in every iteration
+    bad = tmp_path / "bad.txt"
+    bad.write_text(VALUATION.replace(" out body", " out 3 body") + f" chains {K} sden 1\n")
+    assert subprocess.run([tool, "--source", str(bad), "rolled"], capture_output=True, text=True, timeout=60).stdout == ""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    f = tmp_path / "merged.hip"
+    f.write_text(src)
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-structurizecfg-skip-uniform-regions",
+                          "-I", os.path.join(pkg, "csrc"), "--cuda-device-only", "-S", "-o", str(tmp_path / "merged.s"), str(f)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    asm = (tmp_path / "merged.s").read_text()
+    assert ".private_segment_fixed_size: 0" in asm.split("fm_jit_table", 1)[1]        # nothing spills
+
+
 def test_cross_workgroup_hand_off_in_the_machine_code(tmp_path):
     """The hand-off of the reduction partials between workgroups (fm_kernel_parts.hpp: block_combine), checked where it counts — in the
     gfx950 instructions hipcc emits for the same header both tiers are built from: every arrival-counter add is preceded by a full drain

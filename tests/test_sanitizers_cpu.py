@@ -118,6 +118,8 @@ def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_p
         r = run(asan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (args, r.stdout[-500:] + r.stderr[-6000:])
         assert '"evaluations"' in r.stdout
+        # the swaptions of an exercise date run as merged launches (runtime.cpp: merge_families) in every one of these forms
+        assert int(r.stdout.split('"merged_launches": ')[1].split(",")[0]) > 0, (args, r.stdout[-800:])
     for args in (cases[0], cases[2], cases[4], cases[5]):
         t = run(tsan, tmp_path, *base, *args, FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
         assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
