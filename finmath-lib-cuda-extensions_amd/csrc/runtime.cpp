@@ -2829,12 +2829,119 @@ void Engine::plan_loop(BigPlan& plan, const BigDag& g) {
 // first step; per chain the same operations on the same operands in the same order as in its own launch, and its moments by the same
 // tree — bit-identical results, a fifth of the bytes.  Nothing is assumed about the caller: the family is read off the pending graph.
 static const bool MERGE_CHAINS = [] { const char* e = std::getenv("FMHIP_MERGE_CHAINS"); return !(e && e[0] == '0'); }();
+static const bool MERGE_SMALL = [] { const char* e = std::getenv("FMHIP_MERGE_SMALL"); return !(e && e[0] == '0'); }();      // =0: components that fit one launch never join a family
 
-void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
+struct Engine::SmallGroup { std::vector<Dag> members; Dag proto; const SmallMatch* match = nullptr; std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done; };
+
+// Is this single-launch component, position by position, head + R iterations of the body + tail of a mergeable loop shape?  (The walk
+// that lists its operations — depth first from the root, operands in order — and the schedule of the large components of the same shape
+// list a chain the same way; where they do not, the answer is no and the component runs on its own as before.)
+const Engine::SmallMatch* Engine::match_small(const Dag& d)
 {
-    if (!MERGE_CHAINS || !want_root_moments_ || jit_mode == FMHIP_JIT_OFF || groups.size() < 2) return;
-    struct Chain { size_t group, member; BigPlan* plan; Node* root; uint32_t steps; const float* last; };
+    if (!MERGE_SMALL || merge_shapes_.empty()) return nullptr;
+    auto known = small_match_.find(d.sig);
+    if (known != small_match_.end()) {
+        if (known->second.ok) return &known->second;
+        if (known->second.shape == (int)merge_shapes_.size()) return nullptr;      // (no, with every shape known today)
+    }
+    if (small_match_.size() > 4096) small_match_.clear();
+    SmallMatch& out = small_match_[d.sig];
+    out = SmallMatch();
+    out.shape = (int)merge_shapes_.size();                      // (looked at with these shapes known: asked again when another one appears)
+    const size_t m = d.order.size(), n_in = d.leaves.size();
+    if (d.roots.size() != 1 || d.outs.size() != 1 || m == 0 || d.order.back() != d.roots[0] || d.ops.size() != m) return nullptr;
+    for (size_t si = 0; si < merge_shapes_.size() && !out.ok; ++si) {
+        const RolledBody& B = merge_shape_bodies_[si];
+        const RolledBody::Peel& PL = B.peel;
+        const size_t n_pre = PL.pre.size(), n_post = PL.post.size(), P = B.ops.size(), NXa = PL.extra_pre, NXP = PL.extra_post;
+        if (m < n_pre + n_post || (m - n_pre - n_post) % P != 0) continue;
+        // the tail stores nothing but the component's root, or nothing at all
+        if (!(PL.post_out.empty() || (PL.post_out.size() == 1 && PL.post_out[0] + 1 == n_post)) || PL.reduce != "q" + std::to_string(n_post - 1)) continue;
+        const size_t R = (m - n_pre - n_post) / P;
+        std::vector<int> seq(NXa + R, -1), post(NXP, -1);
+        bool ok = true;
+        // an operand by name → what it must be here: position of an operation (>= 0), or a sequence / tail vector (checked against the leaf)
+        auto check = [&](const RolledBody::Op& op, size_t i, auto&& resolve) {
+            const SsaOp& a = d.ops[i];
+            UVariant uv{};
+            if (!variant_for(a.opcode, 0, &uv)) return false;
+            uint32_t uop = uv.uop;
+            if (math_mode == FMHIP_MATH_FAST) { if (uop == U_EXP) uop = U_EXP_FAST; else if (uop == U_LOG) uop = U_LOG_FAST; }
+            if (uop != op.uop || op_info(a.opcode).scalar != op.scalar) return false;
+            const int ids[3] = { a.a, a.b, a.c };
+            const std::string* names[3] = { &op.x0, &op.x1, &op.x2 };
+            const int pos[3] = { 0, uv.r1_pos, uv.r2_pos };
+            for (int k = 0; k < 3; ++k) {
+                if (names[k]->empty()) { if (k > 0 && pos[k] >= 0) return false; continue; }
+                if (pos[k] < 0 || ids[pos[k]] < 0) return false;
+                if (!resolve(*names[k], ids[pos[k]])) return false;
+            }
+            return true;
+        };
+        auto is_op = [&](int id, size_t position) { return id >= (int)n_in && (size_t)(id - (int)n_in) == position; };
+        auto is_leaf = [&](int id, int& slot) { if (id < 0 || id >= (int)n_in) return false; if (slot < 0) slot = id; return slot == id; };
+        for (size_t i = 0; i < n_pre && ok; ++i)
+            ok = check(PL.pre[i], i, [&](const std::string& nm, int id) {
+                const size_t idx = (size_t)std::atoi(nm.c_str() + 1);
+                if (nm[0] == 'x') return idx < NXa && is_leaf(id, seq[idx]);
+                if (nm[0] == 'p') return idx < i && is_op(id, idx);
+                return false; });
+        for (size_t r = 0; r < R && ok; ++r)
+            for (size_t q = 0; q < P && ok; ++q) {
+                const size_t base = n_pre + r * P;
+                ok = check(B.ops[q], base + q, [&](const std::string& nm, int id) {
+                    const size_t idx = (size_t)std::atoi(nm.c_str() + 1);
+                    if (nm[0] == 'v') return idx < q && is_op(id, base + idx);
+                    if (nm[0] == 'c') {
+                        if (idx >= B.carried.size()) return false;
+                        if (r > 0) return is_op(id, base - P + B.carried[idx]);
+                        const std::string& init = PL.carried_init[idx];
+                        return init[0] == 'p' && is_op(id, (size_t)std::atoi(init.c_str() + 1)); }
+                    if (nm == "l0") return is_leaf(id, seq[NXa + r]);
+                    return false; });
+            }
+        for (size_t i = 0; i < n_post && ok; ++i) {
+            const size_t base = n_pre + R * P;
+            ok = check(PL.post[i], base + i, [&](const std::string& nm, int id) {
+                const size_t idx = (size_t)std::atoi(nm.c_str() + 1);
+                if (nm[0] == 'q') return idx < i && is_op(id, base + idx);
+                if (nm[0] == 'x') return idx >= NXa && idx < NXa + NXP && is_leaf(id, post[idx - NXa]);
+                if (nm[0] == 'F') {
+                    if (idx >= B.final_pos.size()) return false;
+                    if (R > 0) return is_op(id, base - P + B.final_pos[idx]);
+                    for (size_t c = 0; c < B.carried.size(); ++c)
+                        if (B.carried[c] == B.final_pos[idx]) { const std::string& init = PL.carried_init[c]; return init[0] == 'p' && is_op(id, (size_t)std::atoi(init.c_str() + 1)); }
+                    return false; }
+                return false; });
+        }
+        // every vector of the sequence is a vector of its own step (the kernel loads one per step), every leaf is accounted for
+        for (int v : seq) ok = ok && v >= 0;
+        for (int v : post) ok = ok && v >= 0;
+        if (ok) { std::vector<int> all(seq); all.insert(all.end(), post.begin(), post.end()); std::sort(all.begin(), all.end()); ok = all.size() == n_in && std::adjacent_find(all.begin(), all.end()) == all.end(); }
+        if (!ok) continue;
+        out.ok = true; out.shape = (int)si; out.R = (uint32_t)R;
+        out.seq_leaf.assign(seq.begin(), seq.end()); out.post_leaf.assign(post.begin(), post.end());
+    }
+    if (!out.ok) { out.shape = (int)merge_shapes_.size(); return nullptr; }
+    return &out;
+}
+
+void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vector<SmallGroup>& small)
+{
+    if (!MERGE_CHAINS || !want_root_moments_ || jit_mode == FMHIP_JIT_OFF) return;
+    // a chain: a large component (group, member: its plan says where its vectors and scalars are) or a small one (sgroup, smember: its match does)
+    struct Chain { size_t group, member; BigPlan* plan; int shape; Node* root; uint32_t steps, R; const float* last; bool small; };
     std::vector<Chain> chains;
+    auto shape_index = [&](BigPlan::Rolled::Peeled& pe) -> int {
+        for (size_t i = 0; i < merge_shapes_.size(); ++i) if (merge_shapes_[i] == pe.desc_red) return (int)i;
+        RolledBody body;
+        if (!jit_parse_description(pe.desc_red, body)) return -1;
+        RolledBody probe = body; probe.chains = 2; probe.shared_den = true;
+        if (jit_generate_rolled_source(probe).empty()) return -1;
+        merge_shapes_.push_back(pe.desc_red); merge_shape_bodies_.push_back(std::move(body));
+        return (int)merge_shapes_.size() - 1;
+    };
+    std::vector<BigPlan*> plan_of_shape;                         // a plan of every shape met in this flush (what its large chains are described by)
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         std::vector<BigDag>& g = groups[gi];
         if (g.empty() || g[0].described() || g[0].n <= 0) continue;
@@ -2844,16 +2951,14 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
         BigPlan::Rolled& ro = plan.rolled;
         BigPlan::Rolled::Peeled& pe = ro.peeled;
         if (!ro.present || !pe.present || pe.desc_red.empty() || pe.elems != 8) continue;
-        if (pe.mergeable < 0) {
-            RolledBody body;
-            pe.mergeable = 0;
-            if (jit_parse_description(pe.desc_red, body)) { body.chains = 2; body.shared_den = true; pe.mergeable = jit_generate_rolled_source(body).empty() ? 0 : 1; }
-        }
+        if (pe.mergeable < 0) pe.mergeable = shape_index(pe) >= 0 ? 1 : 0;
         if (!pe.mergeable) continue;
-        const size_t tiles = (size_t)((g[0].n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS);
-        if (tiles > (size_t)FM_SPAN_UNITS * 65536) continue;
-        const size_t NXa = pe.extra_leaf.size() - 0;      // (split into head / tail inputs below)
-        (void)NXa;
+        const int shape = shape_index(pe);
+        if (shape < 0) continue;
+        if ((size_t)((g[0].n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS) > (size_t)FM_SPAN_UNITS * 65536) continue;
+        if (plan_of_shape.size() <= (size_t)shape) plan_of_shape.resize((size_t)shape + 1, nullptr);
+        if (!plan_of_shape[(size_t)shape]) plan_of_shape[(size_t)shape] = &plan;
+        const uint32_t steps = (uint32_t)(merge_shape_bodies_[(size_t)shape].peel.extra_pre + ro.iterations);
         for (size_t mi = 0; mi < g.size(); ++mi) {
             const BigDag& b = g[mi];
             Node* r = single_root(b, g[0]);
@@ -2861,37 +2966,77 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
             const int32_t last_leaf = ro.iter_leaf[(size_t)(ro.iterations - 1) * ro.leaf_in.size()];
             const Buffer* lb = b.leaves[(size_t)last_leaf]->buf;
             if (!lb) continue;
-            chains.push_back({ gi, mi, &plan, r, 0u, lb->ptr });
+            chains.push_back({ gi, mi, &plan, shape, r, steps, ro.iterations, lb->ptr, false });
+        }
+    }
+    for (size_t gi = 0; gi < small.size(); ++gi) {
+        SmallGroup& sg = small[gi];
+        if (!sg.match || sg.members.empty()) continue;
+        const int shape = sg.match->shape;
+        if ((size_t)shape >= plan_of_shape.size() || !plan_of_shape[(size_t)shape]) continue;      // no large chain of this shape in this flush: nobody to join
+        const RolledBody& body = merge_shape_bodies_[(size_t)shape];
+        const bool stores_root = !body.peel.post_out.empty();
+        const uint32_t steps = (uint32_t)(body.peel.extra_pre + sg.match->R);
+        for (size_t mi = 0; mi < sg.members.size(); ++mi) {
+            const Dag& d = sg.members[mi];
+            if (d.outs.size() != 1 || d.leaves.size() != sg.proto.leaves.size() || d.outs[0]->n <= 0) continue;
+            Node* r = d.outs[0];
+            // (as run_dags: a root that is held; given up — and held by nobody else, a copy's root but by its group — exactly when the shape stores nothing)
+            const bool given_up = r->discard && r->refs_int == ((r->rep_id && r->rep_copy && replica_of(r)) ? 1 : 0);
+            if (r->moments_blocked || r->buf || r->refs_ext <= 0 || (stores_root ? r->discard : !given_up)) continue;
+            const Buffer* lb = d.leaves[(size_t)sg.match->seq_leaf.back()]->buf;
+            if (!lb) continue;
+            chains.push_back({ gi, mi, plan_of_shape[(size_t)shape], shape, r, steps, sg.match->R, lb->ptr, true });
         }
     }
     if (chains.size() < 2) return;
-    // head inputs per description (the generator's numbers): parsed once per plan
-    struct Shape { RolledBody body; size_t NXa = 0, NXP = 0, NS0 = 0, NS2 = 0, LS = 0, NXO = 0; std::vector<uint32_t> shared_pre, shared_body; };
-    std::unordered_map<const BigPlan*, Shape> shapes;
-    auto shape_of = [&](BigPlan* plan) -> Shape& {
-        auto it = shapes.find(plan);
+    struct Shape { const RolledBody* body = nullptr; size_t NXa = 0, NXP = 0, NS0 = 0, NS2 = 0, LS = 0, NXO = 0, P = 0; std::vector<uint32_t> shared_pre, shared_body; };
+    std::unordered_map<int, Shape> shapes;
+    auto shape_of = [&](int shape) -> Shape& {
+        auto it = shapes.find(shape);
         if (it != shapes.end()) return it->second;
-        Shape& sh = shapes[plan];
-        jit_parse_description(plan->rolled.peeled.desc_red, sh.body);
-        sh.NXa = sh.body.peel.extra_pre; sh.NXP = sh.body.peel.extra_post;
-        sh.NS0 = plan->rolled.peeled.n_pre_scal; sh.NS2 = plan->rolled.peeled.n_post_scal; sh.LS = plan->rolled.scal_pos.size(); sh.NXO = plan->rolled.peeled.post_out.size();
-        jit_merged_shared_scalars(sh.body, sh.shared_pre, sh.shared_body);
+        Shape& sh = shapes[shape];
+        sh.body = &merge_shape_bodies_[(size_t)shape];
+        sh.NXa = sh.body->peel.extra_pre; sh.NXP = sh.body->peel.extra_post; sh.NXO = sh.body->peel.post_out.size(); sh.P = sh.body->ops.size();
+        for (const RolledBody::Op& op : sh.body->peel.pre) sh.NS0 += op.scalar ? 1 : 0;
+        for (const RolledBody::Op& op : sh.body->peel.post) sh.NS2 += op.scalar ? 1 : 0;
+        for (const RolledBody::Op& op : sh.body->ops) sh.LS += op.scalar ? 1 : 0;
+        jit_merged_shared_scalars(*sh.body, sh.shared_pre, sh.shared_body);
         return sh;
     };
-    auto leaf_ptr = [](const BigDag& b, int32_t leaf) -> const float* { const Buffer* x = b.leaves[(size_t)leaf]->buf; return x ? x->ptr : nullptr; };
-    // the vector a chain reads at step i of its own sequence (head inputs first, then one per iteration)
+    auto vec_ptr = [](const Node* leaf) -> const float* { return leaf->buf ? leaf->buf->ptr : nullptr; };
+    auto chain_n = [&](const Chain& c) -> int64_t { return c.small ? small[c.group].members[c.member].outs[0]->n : groups[c.group][c.member].n; };
+    // the vector a chain reads at step i of its own sequence (head inputs first, then one per iteration); the vectors of its tail
     auto seq_ptr = [&](const Chain& c, const Shape& sh, size_t i) -> const float* {
+        if (c.small) { const SmallGroup& sg = small[c.group]; return vec_ptr(sg.members[c.member].leaves[(size_t)sg.match->seq_leaf[i]]); }
         const BigDag& b = groups[c.group][c.member];
         const BigPlan::Rolled& ro = c.plan->rolled;
-        return i < sh.NXa ? leaf_ptr(b, ro.peeled.extra_leaf[i]) : leaf_ptr(b, ro.iter_leaf[(i - sh.NXa) * ro.leaf_in.size()]);
+        return vec_ptr(b.leaves[(size_t)(i < sh.NXa ? ro.peeled.extra_leaf[i] : ro.iter_leaf[(i - sh.NXa) * ro.leaf_in.size()])]);
     };
-    for (Chain& c : chains) c.steps = (uint32_t)(shape_of(c.plan).NXa + c.plan->rolled.iterations);
-    // candidates by (description, last vector, tail inputs, length of the vectors): longest first
+    auto post_ptr = [&](const Chain& c, const Shape& sh, size_t x) -> const float* {
+        if (c.small) { const SmallGroup& sg = small[c.group]; return vec_ptr(sg.members[c.member].leaves[(size_t)sg.match->post_leaf[x]]); }
+        return vec_ptr(groups[c.group][c.member].leaves[(size_t)c.plan->rolled.peeled.extra_leaf[sh.NXa + x]]);
+    };
+    // scalar number i of the chain's head / of iteration `it` / of its tail, in the order of the operations
+    auto pre_scalar = [&](const Chain& c, const Shape&, size_t i) -> float {
+        if (c.small) return small[c.group].members[c.member].scalars[i];
+        return groups[c.group][c.member].scalar_at(c.plan->rolled.peeled.pre_scal[i]);
+    };
+    auto body_scalar = [&](const Chain& c, const Shape& sh, size_t it, size_t i) -> float {
+        if (c.small) return small[c.group].members[c.member].scalars[sh.NS0 + it * sh.LS + i];
+        const BigPlan::Rolled& ro = c.plan->rolled;
+        return groups[c.group][c.member].scalar_at(ro.begin + it * ro.period + ro.scal_pos[i]);
+    };
+    auto post_scalar = [&](const Chain& c, const Shape& sh, size_t i) -> float {
+        if (c.small) return small[c.group].members[c.member].scalars[sh.NS0 + (size_t)c.R * sh.LS + i];
+        return groups[c.group][c.member].scalar_at(c.plan->rolled.peeled.post_scal[i]);
+    };
+    // candidates by (shape, last vector): longest first
     std::sort(chains.begin(), chains.end(), [&](const Chain& a, const Chain& b) {
-        const std::string& da = a.plan->rolled.peeled.desc_red; const std::string& db = b.plan->rolled.peeled.desc_red;
-        if (da != db) return da < db;
+        if (a.shape != b.shape) return a.shape < b.shape;
         if (a.last != b.last) return a.last < b.last;
         if (a.steps != b.steps) return a.steps > b.steps;
+        if (a.small != b.small) return !a.small;
         if (a.group != b.group) return a.group < b.group;
         return a.member < b.member;
     });
@@ -2899,37 +3044,27 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
     std::vector<Family> families;
     for (size_t i = 0; i < chains.size();) {
         size_t j = i + 1;
-        while (j < chains.size() && chains[j].last == chains[i].last && chains[j].plan->rolled.peeled.desc_red == chains[i].plan->rolled.peeled.desc_red) ++j;
-        // [i, j): same description, same last vector.  Those whose whole sequence is a suffix of the longest one's and whose tail inputs
-        // and shared scalars agree with it form families of at most 16.
+        while (j < chains.size() && chains[j].last == chains[i].last && chains[j].shape == chains[i].shape) ++j;
+        // [i, j): same shape, same last vector.  Those whose whole sequence is a suffix of the longest one's and whose tail inputs and
+        // shared scalars agree with it form families of at most 16 (a family of small components only has nobody to carry it: skipped).
         const Chain& lead = chains[i];
-        const Shape& sh = shape_of(lead.plan);
-        const BigDag& lb = groups[lead.group][lead.member];
-        auto first_shared = [&](const Chain& c, bool* any) -> float {
-            const BigDag& b = groups[c.group][c.member];
-            const BigPlan::Rolled& ro = c.plan->rolled;
-            *any = !(sh.shared_pre.empty() && sh.shared_body.empty());
-            if (!sh.shared_pre.empty()) return b.scalar_at(ro.peeled.pre_scal[sh.shared_pre[0]]);
-            if (!sh.shared_body.empty()) return b.scalar_at(ro.begin + ro.scal_pos[sh.shared_body[0]]);
-            return 0.f;
-        };
-        bool any_shared = false;
-        const float s_star = first_shared(lead, &any_shared);
+        const Shape& sh = shape_of(lead.shape);
+        const bool any_shared = !(sh.shared_pre.empty() && sh.shared_body.empty());
+        float s_star = 0.f;
+        if (!sh.shared_pre.empty()) s_star = pre_scalar(lead, sh, sh.shared_pre[0]);
+        else if (!sh.shared_body.empty() && lead.R > 0) s_star = body_scalar(lead, sh, 0, sh.shared_body[0]);
+        uint32_t want; std::memcpy(&want, &s_star, 4);
+        auto same = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u == want; };
         Family fam;
-        for (size_t q = i; q < j; ++q) {
+        for (size_t q = i; q < j && !lead.small; ++q) {
             const Chain& c = chains[q];
-            const BigDag& b = groups[c.group][c.member];
-            const BigPlan::Rolled& ro = c.plan->rolled;
-            bool ok = b.n == lb.n;
-            for (size_t x = 0; ok && x < sh.NXP; ++x) ok = leaf_ptr(b, ro.peeled.extra_leaf[sh.NXa + x]) == leaf_ptr(lb, lead.plan->rolled.peeled.extra_leaf[sh.NXa + x]) && leaf_ptr(b, ro.peeled.extra_leaf[sh.NXa + x]) != nullptr;
+            bool ok = chain_n(c) == chain_n(lead);
+            for (size_t x = 0; ok && x < sh.NXP; ++x) { const float* p = post_ptr(c, sh, x); ok = p != nullptr && p == post_ptr(lead, sh, x); }
             const size_t shift = lead.steps - c.steps;
             for (size_t t = 0; ok && t < c.steps; ++t) { const float* p = seq_ptr(c, sh, t); ok = p != nullptr && p == seq_ptr(lead, sh, shift + t); }
-            // every scalar the shared denominators stand for carries the same bits
-            if (ok && any_shared) {
-                uint32_t want; std::memcpy(&want, &s_star, 4);
-                auto same = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u == want; };
-                for (uint32_t sl : sh.shared_pre) ok = ok && same(b.scalar_at(ro.peeled.pre_scal[sl]));
-                for (size_t r = 0; ok && r < ro.iterations; ++r) for (uint32_t sl : sh.shared_body) ok = ok && same(b.scalar_at(ro.begin + r * ro.period + ro.scal_pos[sl]));
+            if (ok && any_shared) {              // every scalar the shared denominators stand for carries the same bits
+                for (uint32_t sl : sh.shared_pre) ok = ok && same(pre_scalar(c, sh, sl));
+                for (size_t r = 0; ok && r < c.R; ++r) for (uint32_t sl : sh.shared_body) ok = ok && same(body_scalar(c, sh, r, sl));
             }
             if (!ok) continue;
             fam.chain.push_back(q);
@@ -2938,41 +3073,43 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
         if (fam.chain.size() >= 2) families.push_back(std::move(fam));
         i = j;
     }
-    // (a family that starts with a chain other than `lead` after a split of 16 still has its own longest chain first: the sort above)
-    families.erase(std::remove_if(families.begin(), families.end(), [](const Family& f) { return f.chain.size() < 2; }), families.end());
+    // (after a split at 16 the later part is a family of its own: its first chain is its longest, the others suffixes of it)
+    families.erase(std::remove_if(families.begin(), families.end(), [&](const Family& f) { return f.chain.size() < 2 || chains[f.chain[0]].small; }), families.end());
     if (families.empty()) return;
-    // kernels: one per (description, family size); a family whose kernel does not exist yet runs as before
-    struct Launch { std::string key; std::shared_ptr<JitSlot> slot; std::vector<size_t> rows; };
+    // kernels: one per (shape, family size); a family whose kernel does not exist yet runs as before
+    struct Launch { std::shared_ptr<JitSlot> slot; std::vector<size_t> rows; };
     std::vector<Launch> launches;
-    std::unordered_map<std::string, size_t> launch_of;
+    std::unordered_map<uint64_t, size_t> launch_of;
     for (size_t f = 0; f < families.size(); ++f) {
-        // a split family's later part must be a family of its own: its first chain is its longest, the others suffixes of the LEAD's sequence — hence of its own
         const Chain& lead = chains[families[f].chain[0]];
         const size_t K = families[f].chain.size();
-        std::string key = lead.plan->rolled.peeled.desc_red + " chains " + std::to_string(K) + " sden 1";
-        auto known = launch_of.find(key);
+        const uint64_t lkey = ((uint64_t)lead.shape << 8) | K;
+        auto known = launch_of.find(lkey);
         if (known == launch_of.end()) {
+            const std::string key = merge_shapes_[(size_t)lead.shape] + " chains " + std::to_string(K) + " sden 1";
             std::shared_ptr<JitSlot>& slot = merged_kernels_[key];
             if (!slot || (jit_mode == FMHIP_JIT_SYNC && slot->state.load(std::memory_order_acquire) == JitSlot::QUEUED)) {
-                RolledBody body = shape_of(lead.plan).body;
+                RolledBody body = merge_shape_bodies_[(size_t)lead.shape];
                 body.chains = (uint32_t)K; body.shared_den = true;
                 std::string source = jit_generate_rolled_source(body);
                 if (source.empty()) continue;
                 jit().record(jit_describe(body));
                 slot = jit().request_source(std::move(source), 8, jit_mode == FMHIP_JIT_SYNC);
             }
-            known = launch_of.emplace(key, launches.size()).first;
-            launches.push_back({ key, slot, {} });
+            known = launch_of.emplace(lkey, launches.size()).first;
+            launches.push_back({ slot, {} });
         }
         launches[known->second].rows.push_back(f);
     }
     // the original of a replicated component and its copies go together or not at all: a copy left behind would have nobody to carry its
-    // order (run_plan), a copy taken without its original nobody to … — if any set is split, nothing is merged in this flush
-    std::vector<std::vector<char>> taken(groups.size());
+    // order (run_plan, run_dags) — if any set is split, nothing is merged in this flush
+    std::vector<std::vector<char>> taken(groups.size()), staken(small.size());
     for (size_t gi = 0; gi < groups.size(); ++gi) taken[gi].assign(groups[gi].size(), 0);
+    for (size_t gi = 0; gi < small.size(); ++gi) staken[gi].assign(small[gi].members.size(), 0);
+    auto mark = [&](const Chain& c) -> char& { return c.small ? staken[c.group][c.member] : taken[c.group][c.member]; };
     for (const Launch& l : launches) {
         if (!l.slot || l.slot->state.load(std::memory_order_acquire) != JitSlot::READY) continue;
-        for (size_t f : l.rows) for (size_t q : families[f].chain) taken[chains[q].group][chains[q].member] = 1;
+        for (size_t f : l.rows) for (size_t q : families[f].chain) mark(chains[q]) = 1;
     }
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         const std::vector<BigDag>& g = groups[gi];
@@ -2983,13 +3120,21 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
             for (size_t q = mi + 1; q < e; ++q) if (taken[gi][q] != taken[gi][mi]) return;
         }
     }
-    const int64_t n = groups[chains[0].group][chains[0].member].n;
+    for (size_t gi = 0; gi < small.size(); ++gi) {
+        const std::vector<Dag>& g = small[gi].members;
+        for (size_t mi = 0; mi < g.size(); ++mi) {
+            if (g[mi].order.empty()) continue;                           // (a copy that exists as a description: vectors, outputs and scalars only)
+            size_t e = mi + 1;
+            while (e < g.size() && g[e].order.empty()) ++e;
+            for (size_t q = mi + 1; q < e; ++q) if (staken[gi][q] != staken[gi][mi]) return;
+        }
+    }
     for (Launch& l : launches) {
         if (!l.slot || l.slot->state.load(std::memory_order_acquire) != JitSlot::READY || l.rows.empty()) continue;
-        const Shape& sh = shape_of(chains[families[l.rows[0]].chain[0]].plan);
+        const Shape& sh = shape_of(chains[families[l.rows[0]].chain[0]].shape);
         const size_t K = families[l.rows[0]].chain.size();
-        const size_t P = chains[families[l.rows[0]].chain[0]].plan->rolled.period;
-        auto section_words = [&](const Chain& c) { return sh.NXO + (sh.NS0 + (size_t)c.plan->rolled.iterations * sh.LS + sh.NS2 + 1) / 2; };
+        const int64_t n = chain_n(chains[families[l.rows[0]].chain[0]]);
+        auto section_words = [&](const Chain& c) { return sh.NXO + (sh.NS0 + (size_t)c.R * sh.LS + sh.NS2 + 1) / 2; };
         size_t rw = 0;
         for (size_t f : l.rows) {
             size_t w = 1 + K + chains[families[f].chain[0]].steps + sh.NXP + 1;
@@ -2998,10 +3143,14 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
         }
         const size_t max_rows = std::min((size_t)1024, ring_cap_ / (rw * 8 + 256));
         if (max_rows == 0) continue;
-        for (size_t off = 0; off < l.rows.size(); off += max_rows) {
-            const size_t count = std::min(max_rows, l.rows.size() - off);
+        // (rows of one launch have vectors of one length: families are looked for within a flush, whose components of a shape and length
+        // share a group; a launch over rows of another length would be a different grid)
+        std::vector<size_t> rows_n;
+        for (size_t f : l.rows) if (chain_n(chains[families[f].chain[0]]) == n) rows_n.push_back(f);
+        for (size_t off = 0; off < rows_n.size(); off += max_rows) {
+            const size_t count = std::min(max_rows, rows_n.size() - off);
             std::vector<uint64_t> table(count * rw, 0);
-            struct Out { size_t chain, pos; Buffer* buf; };
+            struct Out { size_t chain; Buffer* buf; };
             std::vector<Out> outs;
             size_t n_ops = 0, n_vec_in = 0;
             std::vector<fmhip_moments> all;
@@ -3009,36 +3158,32 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
             RedLaunch red;
             try {
                 for (size_t r = 0; r < count; ++r) {
-                    const Family& fam = families[l.rows[off + r]];
+                    const Family& fam = families[rows_n[off + r]];
                     const Chain& lead = chains[fam.chain[0]];
                     uint64_t* row = table.data() + r * rw;
                     const size_t T = lead.steps;
                     row[0] = (uint64_t)T;
                     for (size_t t = 0; t < T; ++t) row[1 + K + t] = (uint64_t)(uintptr_t)seq_ptr(lead, sh, t);
-                    const BigDag& lb = groups[lead.group][lead.member];
-                    for (size_t x = 0; x < sh.NXP; ++x) row[1 + K + T + x] = (uint64_t)(uintptr_t)leaf_ptr(lb, lead.plan->rolled.peeled.extra_leaf[sh.NXa + x]);
-                    { bool any = false; float s_star = 0.f;
-                      if (!sh.shared_pre.empty()) { any = true; s_star = lb.scalar_at(lead.plan->rolled.peeled.pre_scal[sh.shared_pre[0]]); }
-                      else if (!sh.shared_body.empty()) { any = true; s_star = lb.scalar_at(lead.plan->rolled.begin + lead.plan->rolled.scal_pos[sh.shared_body[0]]); }
+                    for (size_t x = 0; x < sh.NXP; ++x) row[1 + K + T + x] = (uint64_t)(uintptr_t)post_ptr(lead, sh, x);
+                    { float s_star = 0.f; bool any = false;
+                      if (!sh.shared_pre.empty()) { any = true; s_star = pre_scalar(lead, sh, sh.shared_pre[0]); }
+                      else if (!sh.shared_body.empty() && lead.R > 0) { any = true; s_star = body_scalar(lead, sh, 0, sh.shared_body[0]); }
                       uint32_t bits = 0; if (any) std::memcpy(&bits, &s_star, 4);
                       row[1 + K + T + sh.NXP] = bits; }
                     size_t at = 1 + K + T + sh.NXP + 1;
                     n_vec_in += T + sh.NXP;
                     for (size_t k = 0; k < K; ++k) {
                         const Chain& c = chains[fam.chain[k]];
-                        BigDag& b = groups[c.group][c.member];
-                        const BigPlan::Rolled& ro = c.plan->rolled;
-                        const BigPlan::Rolled::Peeled& pe = ro.peeled;
                         row[1 + k] = (uint64_t)(T - c.steps) | ((uint64_t)at << 32);
                         uint64_t* sec = row + at;
-                        for (size_t m = 0; m < sh.NXO; ++m) { Buffer* nb = new_buffer(n); outs.push_back({ fam.chain[k], pe.post_out[m], nb }); sec[m] = (uint64_t)(uintptr_t)nb->ptr; }
+                        for (size_t m = 0; m < sh.NXO; ++m) { Buffer* nb = new_buffer(n); outs.push_back({ fam.chain[k], nb }); sec[m] = (uint64_t)(uintptr_t)nb->ptr; }
                         float* sc = reinterpret_cast<float*>(sec + sh.NXO);
-                        for (size_t i = 0; i < sh.NS0; ++i) sc[i] = b.scalar_at(pe.pre_scal[i]);
-                        for (size_t it = 0; it < ro.iterations; ++it)
-                            for (size_t m = 0; m < sh.LS; ++m) sc[sh.NS0 + it * sh.LS + m] = b.scalar_at(ro.begin + it * P + ro.scal_pos[m]);
-                        for (size_t i = 0; i < sh.NS2; ++i) sc[sh.NS0 + (size_t)ro.iterations * sh.LS + i] = b.scalar_at(pe.post_scal[i]);
+                        for (size_t i = 0; i < sh.NS0; ++i) sc[i] = pre_scalar(c, sh, i);
+                        for (size_t it = 0; it < c.R; ++it)
+                            for (size_t m = 0; m < sh.LS; ++m) sc[sh.NS0 + it * sh.LS + m] = body_scalar(c, sh, it, m);
+                        for (size_t i = 0; i < sh.NS2; ++i) sc[sh.NS0 + (size_t)c.R * sh.LS + i] = post_scalar(c, sh, i);
                         at += section_words(c);
-                        n_ops += pe.n_ops;
+                        n_ops += sh.body->peel.pre.size() + (size_t)c.R * sh.P + sh.body->peel.post.size();
                     }
                 }
                 const int64_t tiles = (n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS;
@@ -3071,7 +3216,7 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
             red_release(red);
             // the moments go to the chains' roots; stored values become vectors; expressions are dismantled
             for (size_t r = 0; r < count; ++r) {
-                const Family& fam = families[l.rows[off + r]];
+                const Family& fam = families[rows_n[off + r]];
                 for (size_t k = 0; k < K; ++k) {
                     Node* root = chains[fam.chain[k]].root;
                     if (every.dev_out) arena_assign(root, (double*)every.dev_out + (r * K + k) * 4);
@@ -3079,22 +3224,23 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
                 }
             }
             std::vector<Node*> done;
-            for (Out& o : outs) {
+            for (Out& o : outs) {                                       // (the one value a chain stores is its root)
                 const Chain& c = chains[o.chain];
+                if (c.small) { commit_node(c.root, o.buf); done.push_back(c.root); continue; }
                 BigDag& b = groups[c.group][c.member];
-                if (b.described()) commit_described(b, o.pos, o.buf);
-                else { Node* nd = b.order[o.pos]; commit_node(nd, o.buf); done.push_back(nd); }
+                const size_t pos = c.plan->rolled.peeled.post_out[0];
+                if (b.described()) commit_described(b, pos, o.buf);
+                else { Node* nd = b.order[pos]; commit_node(nd, o.buf); done.push_back(nd); }
             }
             for (Node* nd : done) nd->refs_int++;
             for (Node* nd : done) drop_expression(nd);
             for (Node* nd : done) { nd->refs_int--; node_maybe_free(nd); }
             for (size_t r = 0; r < count; ++r)
-                for (size_t q : families[l.rows[off + r]].chain) {
+                for (size_t q : families[rows_n[off + r]].chain) {
                     const Chain& c = chains[q];
-                    BigDag& b = groups[c.group][c.member];
-                    if (c.plan->discards_root && !c.root->buf) { c.root->discarded = true; c.root->refs_int++; drop_expression(c.root); c.root->refs_int--; }
-                    if (b.described()) for (Buffer*& t : b.temp) if (t) { buffer_unref(t); t = nullptr; }
-                    taken[c.group][c.member] = 2;                       // has run
+                    if (sh.NXO == 0 && !c.root->buf) { c.root->discarded = true; c.root->refs_int++; drop_expression(c.root); c.root->refs_int--; }
+                    if (!c.small) { BigDag& b = groups[c.group][c.member]; if (b.described()) for (Buffer*& t : b.temp) if (t) { buffer_unref(t); t = nullptr; } }
+                    mark(c) = 2;                                        // has run
                 }
         }
     }
@@ -3106,6 +3252,15 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups)
         if (!any) continue;
         std::vector<BigDag> rest;
         for (size_t mi = 0; mi < g.size(); ++mi) if (taken[gi][mi] != 2) rest.push_back(std::move(g[mi]));
+        g.swap(rest);
+    }
+    for (size_t gi = 0; gi < small.size(); ++gi) {
+        std::vector<Dag>& g = small[gi].members;
+        bool any = false;
+        for (char t : staken[gi]) any |= t == 2;
+        if (!any) continue;
+        std::vector<Dag> rest;
+        for (size_t mi = 0; mi < g.size(); ++mi) if (staken[gi][mi] != 2) rest.push_back(std::move(g[mi]));
         g.swap(rest);
     }
 }
@@ -3235,12 +3390,28 @@ void Engine::flush_all() {
             groups[key].push_back(std::move(d));
         }
         if (expanded) continue;
+        std::vector<SmallGroup> waiting;                                  // groups whose components may be chains of a merged launch (merge_families): run behind the large components
+        auto run_small = [&](std::vector<Dag>& members, const Dag& proto, std::vector<std::pair<ReplicaGroup*, std::vector<int>>>& done, bool late) {
+            const size_t max_batch = 1024;
+            bool ran = true;
+            try {
+                for (size_t off = 0; off < members.size(); off += max_batch) {
+                    std::vector<Dag> part(std::make_move_iterator(members.begin() + off), std::make_move_iterator(members.begin() + std::min(members.size(), off + max_batch)));
+                    if (!run_dags(part, nullptr, nullptr, nullptr, &proto)) {
+                        ran = false;
+                        for (Dag& d : part) for (Node* r : d.roots) { if (late) { if (!r->buf) materialize({ r }); } else leftovers.push_back(r); }
+                    }
+                }
+            } catch (...) { replicas_after_failure(done); throw; }
+            if (ran) for (auto& kv : done) replica_roots_done(kv.first, kv.second);
+        };
         for (const std::string& key : group_order) {
             std::vector<Dag>& g = groups[key];
             // members: every component of this structure, each followed by its copies that exist as a description
             std::vector<Dag> members;
             std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done;
             const Dag proto = g[0];                                   // carries the structure for launches that start with another member
+            const SmallMatch* chain_of = (MERGE_CHAINS && want_root_moments_ && jit_mode != FMHIP_JIT_OFF) ? match_small(proto) : nullptr;
             for (Dag& d : g) {
                 ReplicaGroup* rg = d.rep_any ? clean_replica_group(d.rep_id, d.rep_uniform) : nullptr;
                 if (rg) {
@@ -3252,16 +3423,16 @@ void Engine::flush_all() {
                     for (int j = 0; j < rg->n_copies; ++j) members.push_back(replica_dag(members[at], rg, j));
                 } else members.push_back(std::move(d));
             }
-            const size_t max_batch = 1024;
-            bool ran = true;
-            try {
-                for (size_t off = 0; off < members.size(); off += max_batch) {
-                    std::vector<Dag> part(std::make_move_iterator(members.begin() + off), std::make_move_iterator(members.begin() + std::min(members.size(), off + max_batch)));
-                    if (!run_dags(part, nullptr, nullptr, nullptr, &proto)) { ran = false; for (Dag& d : part) for (Node* r : d.roots) leftovers.push_back(r); }
-                }
-            } catch (...) { replicas_after_failure(done); throw; }
-            if (ran) for (auto& kv : done) replica_roots_done(kv.first, kv.second);
+            if (chain_of) {
+                waiting.emplace_back();
+                SmallGroup& sg = waiting.back();
+                sg.members = std::move(members); sg.proto = proto; sg.match = chain_of; sg.done = std::move(done);
+                continue;
+            }
+            run_small(members, proto, done, false);
         }
+        // (nothing large in this flush: the waiting groups have no family to join)
+        if (leftovers.empty()) { for (SmallGroup& sg : waiting) run_small(sg.members, sg.proto, sg.done, true); waiting.clear(); }
         // components that do not fit one launch: cut into segments; components of identical shape share the cuts and the launches
         if (!leftovers.empty()) {
             std::unordered_map<Node*, int> comp_of;                      // root -> component key
@@ -3295,7 +3466,7 @@ void Engine::flush_all() {
                 }
                 members.push_back(std::move(b));
             }
-            if (expanded) continue;
+            if (expanded) { for (SmallGroup& sg : waiting) run_small(sg.members, sg.proto, sg.done, true); continue; }
             // members of every group: its components, each followed by its copies that exist as a description
             std::vector<std::vector<BigDag>> all_members(big_group_order.size());
             std::vector<std::vector<std::pair<ReplicaGroup*, std::vector<int>>>> all_done(big_group_order.size());
@@ -3331,8 +3502,13 @@ void Engine::flush_all() {
                 }
             }
             // components of one loop shape that read the same vectors, one a suffix of the other's: one launch per family size (merge_families)
-            try { merge_families(all_members); }
-            catch (...) { for (auto& done : all_done) replicas_after_failure(done); throw; }
+            try { merge_families(all_members, waiting); }
+            catch (...) { for (auto& done : all_done) replicas_after_failure(done); for (SmallGroup& sg : waiting) replicas_after_failure(sg.done); throw; }
+            for (SmallGroup& sg : waiting) {
+                if (!sg.members.empty()) run_small(sg.members, sg.proto, sg.done, true);
+                else for (auto& kv : sg.done) replica_roots_done(kv.first, kv.second);
+            }
+            waiting.clear();
             for (size_t ki = 0; ki < big_group_order.size(); ++ki) {
                 if (!all_members[ki].empty()) {
                     try { run_big_group(all_members[ki]); }

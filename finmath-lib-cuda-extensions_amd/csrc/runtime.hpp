@@ -603,7 +603,16 @@ private:
     // of one exercise date: every tenor reads the forward rates from its last period back to the exercise date), as ONE launch that loads
     // every vector once (jit.hpp: RolledBody::chains).  Looked for among the large components of a flush that takes the moments of all
     // pending roots along; whatever does not fit — a kernel not compiled yet, a family of one — runs as before.  FMHIP_MERGE_CHAINS=0: off.
-    void merge_families(std::vector<std::vector<BigDag>>& groups);
+    // A component small enough for one launch of its own (a Dag: the swaptions of few periods) may be a chain of such a family too: its
+    // operations are, position by position, the head of a mergeable shape, R >= 0 iterations of its body and its tail (match_small;
+    // remembered per Dag signature).  Groups of such components wait for the families (SmallGroup) instead of running at once.
+    struct SmallMatch { bool ok = false; int shape = -1; uint32_t R = 0; std::vector<uint16_t> seq_leaf, post_leaf; };
+    struct SmallGroup;
+    void merge_families(std::vector<std::vector<BigDag>>& groups, std::vector<SmallGroup>& small);
+    const SmallMatch* match_small(const Dag& d);
+    std::vector<std::string> merge_shapes_;                                          // descriptions (desc_red) of the mergeable loop shapes met so far …
+    std::vector<RolledBody> merge_shape_bodies_;                                     // … and their bodies
+    std::unordered_map<std::string, SmallMatch> small_match_;
     std::unordered_map<std::string, std::shared_ptr<JitSlot>> merged_kernels_;        // by description of the merged body
     int64_t n_merged_launches_ = 0, n_merged_chains_ = 0;
     // replica groups: live descriptions by id (ids are never reused: a stale stamp on a recycled node finds nothing)

@@ -408,6 +408,7 @@ inline std::vector<Valuation> evaluateMany(const Market& m, const std::vector<Pa
 
 struct CalibrationResult {
     Parameters parameters{}; int iterations = 0, evaluations = 0, accepted = 0;
+    int speculative_discarded = 0;           // parameter sets valued beside a trial point that was then rejected (speculative Jacobians, see calibrate)
     double meanDeviation = 0, rmsDeviation = 0, initialRms = 0, seconds = 0, seconds_simulation = 0, seconds_valuation = 0;
     std::vector<double> modelVolatility;      // of the final valuation on the calibrated model (NaN: dropped product)
 };
@@ -431,8 +432,21 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
     std::vector<double> valueCurrent, J;
     double errorCurrent = std::numeric_limits<double>::infinity(), change = std::numeric_limits<double>::infinity();
     bool derivativeValid = false;
+    // SPECULATIVE JACOBIAN (lock-step back ends: jacobianBatch >= 8 and replication).  Nine of ten trial points are accepted, and an
+    // accepted point needs its finite-difference Jacobian next: the eight bumped sets AROUND THE TRIAL POINT are valued beside it, as rows of
+    // the same launches — the simulation is recorded once per iteration instead of twice (the recording through the mirror classes, 29 k
+    // methods per simulation, is what this calibration waits for at the reference's path counts: 0.47 s for 60 recordings).  Accepted: the
+    // Jacobian is there, from the same arithmetic (rows do not see each other).  Rejected: the eight are dropped (counted apart) and the
+    // Jacobian of the current point stays.  The optimiser's path — points, values, steps — is unchanged to the last bit.
+    // FMHIP_SMILE_SPECULATE=0: trial first, Jacobian afterwards (rounds 1–4).
+    static const bool speculateEnv = [] { const char* e = std::getenv("FMHIP_SMILE_SPECULATE"); return !(e && e[0] == '0'); }();
+    const bool speculate = speculateEnv && be.jacobianBatch >= NP && static_cast<bool>(be.clone);
+    std::vector<Valuation> unusedJacobian;
     for (int iteration = 1; ; ++iteration) {
-        const Valuation v = evaluateMany(m, { test }, be, fullHorizon)[0];
+        std::vector<Parameters> sets{ test };
+        if (speculate) for (int a = 0; a < NP; ++a) { Parameters bumped = test; bumped[(size_t)a] += parameterStep; sets.push_back(bumped); }
+        const std::vector<Valuation> trial = evaluateMany(m, sets, be, fullHorizon);
+        const Valuation& v = trial[0];
         account(v);
         const std::vector<double> valueTest = deviations(m, v);
         const double errorTest = meanSquared(valueTest);
@@ -441,13 +455,25 @@ inline CalibrationResult calibrate(const Market& m, const Backend& be, int maxIt
             change = std::sqrt(errorCurrent) - std::sqrt(errorTest);
             current = test; valueCurrent = valueTest; errorCurrent = errorTest; derivativeValid = false;
             lambda /= 1.3; res.accepted++;
+            if (speculate) {                                           // the Jacobian of the new current point has been computed beside it
+                J.assign((size_t)nr * NP, 0.0);
+                for (int a = 0; a < NP; ++a) {
+                    const std::vector<double> up = deviations(m, trial[(size_t)a + 1]);
+                    for (int k = 0; k < nr; ++k) J[(size_t)k * NP + a] = (up[(size_t)k] - valueCurrent[(size_t)k]) / parameterStep;
+                }
+                derivativeValid = true;
+                unusedJacobian.assign(trial.begin() + 1, trial.end());   // counted as evaluations when the optimiser takes a step with it (as if computed then)
+            }
         } else {
             change = std::sqrt(errorTest) - std::sqrt(errorCurrent);
             lambda *= 2.0;
+            if (speculate) res.speculative_discarded += NP;
         }
         res.iterations = iteration;
         if (verbose) std::fprintf(stderr, "  LM iteration %d: rms %.6e (trial %.6e)  lambda %.3g  evaluations %d\n", iteration, std::sqrt(errorCurrent), std::sqrt(errorTest), lambda, res.evaluations);
-        if (iteration > maxIterations || !(change > tolerance) || std::isinf(lambda)) break;
+        if (iteration > maxIterations || !(change > tolerance) || std::isinf(lambda)) { res.speculative_discarded += (int)unusedJacobian.size(); break; }
+        for (const Valuation& u : unusedJacobian) account(u);
+        unusedJacobian.clear();
         if (!derivativeValid) {                                       // forward differences: the 8 bumped sets as ONE lock-step batch
             std::vector<Parameters> bumped((size_t)NP, current);
             for (int a = 0; a < NP; ++a) bumped[(size_t)a][(size_t)a] += parameterStep;

@@ -85,9 +85,9 @@ inline void runAndReport(const Options& o, const Backend& be, const char* backen
     const CalibrationResult r = calibrate(m, be, o.maxIterations, 1e-6, 0.1, 1e-4, o.fullHorizon, o.verbose);
     int valid = 0; for (const Product& p : m.products) valid += p.valid;
     std::printf("{\"backend\": \"%s\", \"mode\": \"calibrate\", \"paths\": %lld, \"products\": %zu, \"products_valued\": %d, \"parameters_calibrated\": 8, "
-                "\"iterations\": %d, \"accepted_points\": %d, \"evaluations\": %d, \"seconds\": %.4f, \"seconds_simulation\": %.4f, \"seconds_valuation\": %.4f, "
+                "\"iterations\": %d, \"accepted_points\": %d, \"evaluations\": %d, \"speculative_evaluations_discarded\": %d, \"seconds\": %.4f, \"seconds_simulation\": %.4f, \"seconds_valuation\": %.4f, "
                 "\"initial_rms\": %.6e, \"rms_deviation\": %.6e, \"mean_deviation\": %.6e%s, \"parameters\": {",
-                backendName, (long long)o.paths, m.products.size(), valid, r.iterations, r.accepted, r.evaluations, r.seconds, r.seconds_simulation, r.seconds_valuation,
+                backendName, (long long)o.paths, m.products.size(), valid, r.iterations, r.accepted, r.evaluations, r.speculative_discarded, r.seconds, r.seconds_simulation, r.seconds_valuation,
                 r.initialRms, r.rmsDeviation, r.meanDeviation, extraJson().c_str());
     for (int k = 0; k < 8; ++k) std::printf("%s\"%s\": %.10g", k ? ", " : "", parameterName(k), r.parameters[(size_t)k]);
     std::printf("}, \"model_volatility\": [");
