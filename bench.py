@@ -290,7 +290,29 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                         "device_busy_fraction_of_wall": kernel_s / rp["seconds"],
                         "host_idle_s": rp["seconds"] - kernel_s, "host_time_top3": host_top,
                         "timing": "one HIP event pair per launch on the runtime stream, summed"}}
+    eng = rp.get("engine") or {}
+    lmm["roofline"]["merged_launches"] = eng.get("merged_launches")
+    lmm["roofline"]["merged_chains"] = eng.get("merged_chains")
     if world == 1:
+        # Round 5: the swaptions of one exercise date run as ONE launch that loads every forward rate once (runtime.cpp: merge_families) — a third
+        # of the bytes of one launch per tenor, and kernels that are bound by their arithmetic (the correctly rounded division per chain and
+        # period), no longer by HBM.  `frac` above counts, as always, the bytes the launches that RAN have to move; the same calibration with
+        # one launch per shape (FMHIP_MERGE_CHAINS=0: rounds 1-4) is measured beside it, and `frac_at_the_bytes_of_one_launch_per_shape`
+        # sets ITS bytes against this run's kernel time: what the merged launches are worth in the old currency.
+        try:
+            u, _ = run(base, env=dict(os.environ, FMHIP_MERGE_CHAINS="0"))
+            up, _ = run(base + ["--profile"], env=dict(os.environ, FMHIP_MERGE_CHAINS="0"))
+            lmm["roofline"]["one_launch_per_shape"] = {
+                "seconds": u["seconds"], "kernel_launches": u["kernel_launches"], "algorithmic_bytes": up["algorithmic_bytes"], "summed_kernel_s": up["kernel_ms_total"] / 1e3,
+                "achieved": up["achieved_GBps"], "frac": up["achieved_GBps"] / HBM_PEAK_GBS, "mean_deviation": u["mean_deviation"],
+                "identical_to_the_merged_run": u["mean_deviation"] == r["mean_deviation"] and u["rms_deviation"] == r["rms_deviation"] and u["parameters"] == r["parameters"],
+                "what": "FMHIP_MERGE_CHAINS=0: every component shape its own launch, as in rounds 1-4 (HBM-bound throughout)"}
+            lmm["roofline"]["frac_at_the_bytes_of_one_launch_per_shape"] = up["algorithmic_bytes"] / kernel_s / 1e9 / HBM_PEAK_GBS
+            lmm["roofline"]["bytes_over_one_launch_per_shape"] = rp["algorithmic_bytes"] / up["algorithmic_bytes"]
+            lmm["roofline"]["bound_note"] = ("simulation launches (two thirds of the kernel time): HBM / VALU issue as in round 4; merged valuation launches: VALU-bound "
+                                             "(8 issue slots per chain, period and pair of paths, 3 of them the division's; DESIGN.md 4.6) at about 0.4 of the HBM peak on their own, smaller, byte count")
+        except Exception as e:
+            lmm["roofline"]["one_launch_per_shape"] = {"error": str(e)[-500:]}
         env = dict(os.environ, FMHIP_JIT="sync")
         for key, batch in (("replay_one_at_a_time", 1), ("replay_8_in_lock_step", 8)):
             pj, _ = run([LMM_HIP, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", str(batch), "--warmup-evaluations", str(batch), "--profile"], env=env)
@@ -312,6 +334,9 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                             "19 swaptions in log-normal volatility (15 within the 20y horizon), 8 parameters, at most 30 LM iterations",
                 "paths": 163840, "seconds": s1["seconds"], "seconds_warm_code_object_cache_profiled": s2["seconds"],
                 "objective_evaluations": s1["evaluations"], "lm_iterations": s1["iterations"], "kernel_launches": s1["kernel_launches"],
+                "speculative_evaluations_discarded": s1.get("speculative_evaluations_discarded"),
+                "speculation": "the eight bumped parameter sets around every trial point are valued beside it (rows of the same launches): an accepted point has its "
+                               "Jacobian already, a rejected one wastes eight rows - one recording of the simulation per iteration instead of two; the optimiser's path is unchanged",
                 "mean_deviation": s1["mean_deviation"], "rms_deviation": s1["rms_deviation"],
                 "acceptance": "abs(mean_deviation) < 1e-2 (LIBORMarketModelCalibrationTest.java:358)", "accepted": abs(s1["mean_deviation"]) < 1e-2,
                 "achieved_GBps_all_launches": s2.get("achieved_GBps"),
