@@ -8,6 +8,8 @@
 // its kernels take.  Built by tests/nulldev/Makefile, driven by tests/nulldev/drive.cpp, run by tests/test_sanitizers_cpu.py.
 #include <hip/hip_runtime_api.h>
 #include <hip/hiprtc.h>
+#include <ctime>
+#include <cstdlib>
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
@@ -148,6 +150,9 @@ hiprtcResult hiprtcCreateProgram(hiprtcProgram* prog, const char* src, const cha
 }
 hiprtcResult hiprtcCompileProgram(hiprtcProgram prog, int, const char* const*) {
     NullProgram* p = reinterpret_cast<NullProgram*>(prog);
+    // FMNULL_COMPILE_MS: a compilation takes that long (the real hiprtc needs seconds per kernel: callers that meet a kernel another
+    // thread is compiling have to wait for it, and be woken)
+    if (const char* e = std::getenv("FMNULL_COMPILE_MS")) { timespec ts{ 0, 0 }; const long ms = std::atol(e); ts.tv_sec = ms / 1000; ts.tv_nsec = (ms % 1000) * 1000000L; nanosleep(&ts, nullptr); }
     p->code = std::string("FMNULLCO") + (p->source.find("DevRolledArgs") != std::string::npos ? "R" : "P") + std::string(7, '\0');
     return HIPRTC_SUCCESS;
 }

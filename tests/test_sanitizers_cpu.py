@@ -125,6 +125,17 @@ def test_the_native_lmm_driver_is_clean_under_both_sanitizer_builds(built, tmp_p
         assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, (args, t.stdout[-500:] + t.stderr[-6000:])
 
 
+def test_a_kernel_another_caller_thread_is_compiling_is_waited_for_and_the_waiter_is_woken(built, tmp_path):
+    """Thread engines share one compiler.  With FMHIP_JIT=sync a caller compiles on its own thread; a second thread that asks for the same
+    kernel meanwhile waits for it — and must be woken when the first is done (until round 5 only the compiler's worker thread woke such
+    waiters: four thread engines that met the merged kernels, which take tens of seconds each, waited for good: the kernel pack recording
+    was killed after seven silent minutes).  The null device's hiprtc takes FMNULL_COMPILE_MS per kernel here; no code-object cache."""
+    t = run(os.path.join(built, "lmm_tsan"), tmp_path, "--paths", "3000", "--mode", "calibrate", "--max-iterations", "2", "--finmath-like", "--threads", "4",
+            FMHIP_JIT="sync", FMHIP_JIT_CACHE_DIR="off", FMNULL_COMPILE_MS="15", FMHIP_RING_BYTES="1048576", FMHIP_ARENA_BYTES="65536")
+    assert t.returncode == 0 and "ThreadSanitizer" not in t.stderr, t.stdout[-500:] + t.stderr[-4000:]
+    assert '"evaluations"' in t.stdout
+
+
 def test_thread_engines_are_clean_under_both_sanitizer_builds(built, tmp_path):
     """Every scenario again with an engine per caller thread (fmhip_set_thread_engines; csrc/abi.cpp, namespace te): the eight threads of
     `threads` record into engines of their own; `shared` crosses them — a pending vector of the main thread as an operand of six threads
