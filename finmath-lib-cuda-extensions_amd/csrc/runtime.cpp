@@ -1142,7 +1142,9 @@ static int FUSION_MAX_WEIGHT = 40;    // pending ops below one node before it is
                                        // recording of the next methods, and that path is host-bound
 
 void fusion_max_weight_override(int v) { FUSION_MAX_WEIGHT = v; }
-static const size_t SPECULATE_PENDING = [] { const char* e = std::getenv("FMHIP_SPECULATE_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)5000; }();   // operations recorded since the last time step; 0 = off
+static const size_t SPECULATE_PENDING = [] { const char* e = std::getenv("FMHIP_SPECULATE_PENDING"); return e ? (size_t)std::atoll(e) : (size_t)2000; }();   // operations recorded since the last time step; 0 = off.  5000 until the second half of round 5, when the device was what the hint-free calibration waited for; with the
+                                                         // swaptions of an exercise date merged (merge_families) it is the host, and what counts is how little is left to run when the caller asks for its first expectation: 1500 / 2000 / 2500 / 3000 / 4000 / 5000
+                                                         // methods: 3.48 / 3.37–3.45 / 3.46–3.55 / 3.56 / 3.63 / 3.66–3.70 s on one box (profiles/round05b_merged_chains.txt)
 static const size_t SPECULATE_IDLE_MIN = [] { const char* e = std::getenv("FMHIP_SPECULATE_IDLE_MIN"); return e ? (size_t)std::atoll(e) : (size_t)0; }();   // 0 (default) = the device's idleness is not looked at.  Measured, lmm_hip --finmath-like at 1 M paths on one box: off 4.68 s; 512 / 1024 / 2048 / 4096: 5.26 / 4.89 / 4.96 / 4.90 s —
                                                          // chains cut wherever the device happens to run dry are shapes that never repeat (70 kernels compiled instead of 38, 4–12 k launches on the interpreter)
 static const size_t FUSION_SOFT_CAP = 32768;     // pending operations at which a SOFT hold (fmhip_fusion_hold(2)) executes everything
