@@ -59,7 +59,7 @@ class EngineStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "size", "kernel_launches", "specialised_launches", "interpreter_launches", "algorithmic_bytes", "algorithmic_bytes_written",
         "values_deferred", "values_deferred_now", "values_demanded", "pending_operations", "peak_bytes_reserved",
-        "late_releases_while_waiting", "late_releases_at_once", "late_release_nanoseconds", "merged_launches", "merged_chains")]
+        "late_releases_while_waiting", "late_releases_at_once", "late_release_nanoseconds", "merged_launches", "merged_chains", "common_rows")]
 
 
 class FmhipError(RuntimeError):

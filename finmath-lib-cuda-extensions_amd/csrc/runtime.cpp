@@ -595,6 +595,18 @@ void Engine::read(fmhip_vec h, void* dst, bool as_double, int64_t n) {
     }
 }
 
+// Vectors are immutable but for two doors: a raw device pointer handed out, and fmhip_program_run_into.  Storage that several vectors share
+// (rows of a batched launch that were identical and were computed once: run_peeled, merge_families) is copied before either opens.
+void Engine::make_private(Node* nd) {
+    Buffer* b = nd->buf;
+    if (!b || b->refs <= 1 || b->parent || b->foreign >= 0) return;
+    Buffer* own = new_buffer(nd->n);
+    hipError_t e = hipMemcpyAsync(own->ptr, b->ptr, (size_t)nd->n * 4, hipMemcpyDeviceToDevice, stream_);
+    if (e != hipSuccess) { buffer_unref(own); hip_check(e, "copy of a shared vector before it is written in place"); }
+    nd->buf = own;
+    buffer_unref(b);
+}
+
 void* Engine::device_ptr(fmhip_vec h) {
     require_init();
     end_step_group();
@@ -604,6 +616,7 @@ void* Engine::device_ptr(fmhip_vec h) {
     // the caller may write through the pointer: whoever still reads this vector — pending expressions, recipes of deferred values — is computed first
     if (nd->refs_int > 0) { flush_all(); materialize_deferred(); }
     nd->has_moments = false; nd->moments_slot = nullptr; nd->moments_blocked = true;
+    make_private(nd);
     return nd->buf->ptr;
 }
 
@@ -2151,6 +2164,7 @@ void Engine::run_planned_segment(const BigPlan::Seg& seg, std::vector<BigDag>& g
 // same ueval<> functions in the same order per element as in the segmented launches: results are bit-identical, and until the
 // kernel is compiled (or with FMHIP_JIT=off / FMHIP_ROLL=0) the segmented launches run.
 
+static bool MERGE_CHAINS_ON() { static const bool v = [] { const char* e = std::getenv("FMHIP_MERGE_CHAINS"); return !(e && e[0] == '0'); }(); return v; }
 static inline uint64_t mix64(uint64_t h, uint64_t v) { h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdull; }
 
 #define ROLL_TRACE(...) do { if (roll_trace) std::fprintf(stderr, __VA_ARGS__); } while (0)
@@ -2396,7 +2410,8 @@ bool Engine::plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>
     if (body.elems == 8) {
         if (n > end) pl.reduce = "q" + std::to_string(n - 1 - end);
         else if (final_of[(n - 1 - begin) % P] >= 0) pl.reduce = "F" + std::to_string(final_of[(n - 1 - begin) % P]);
-        if (!pl.reduce.empty()) { pe.desc_red = jit_describe(body); jit().record(pe.desc_red); pe.source_red = jit_generate_rolled_source(body); }
+        if (!pl.reduce.empty()) { pe.desc_red = jit_describe(body); jit().record(pe.desc_red); pe.source_red = jit_generate_rolled_source(body);
+                                  if (MERGE_CHAINS_ON()) pe.mergeable = merge_shape_index(pe.desc_red) >= 0 ? 1 : 0; }
     }
     ro.peeled = std::move(pe);
     return true;
@@ -2477,7 +2492,9 @@ void Engine::run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
 }
 
 // The whole component of every member of a group as ONE launch of its peeled kernel (plan_peel): row tables by index, launch, commit.
-void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr)
+static const bool COMMON_ROWS = [] { const char* e = std::getenv("FMHIP_COMMON_ROWS"); return !(e && e[0] == '0'); }();     // =0: identical rows of a launch are all computed (A/B)
+
+void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr, std::vector<uint32_t>* row_of_out)
 {
     const BigPlan::Rolled::Peeled& pe = ro.peeled;
     const size_t NX = pe.extra_leaf.size(), G = ro.global_leaf.size(), CO = ro.final_pos.size(), NXO = pe.pre_out.size() + pe.post_out.size();
@@ -2493,27 +2510,57 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
         if (!b) throw Error(FMHIP_ERR_PROGRAM_LIMIT, "peeled loop reads a value that has not been computed");
         return (uint64_t)(uintptr_t)b->ptr;
     };
+    // COMMON ROWS.  What a row computes is a function of the vectors it reads and of its scalars: members whose rows agree in both —
+    // the parameter sets of a Jacobian batch up to the time step at which their bumped parameter is first used, which read the very same
+    // vectors because THEIR predecessors were common rows too — are computed once; the others' values are the same vectors (shared
+    // storage, copied if anybody writes into one in place: make_private).  A row's inputs and scalars are written first (output slots
+    // zero), compared with the rows before it, and only a row that is new gets output vectors.
+    std::vector<uint32_t> row_of(count);
+    std::vector<size_t> member_of_row;                          // launch row → the member (offset from `first`) that it computes
+    const bool dedup = COMMON_ROWS && count > 1 && (!rr || row_of_out);
+    std::unordered_multimap<uint64_t, uint32_t> seen;
+    std::vector<uint64_t> keys;                                 // the rows as they were compared: inputs and scalars, output slots still zero
     try {
         for (size_t c = 0; c < count; ++c) {
             BigDag& big = group[first + c];
-            uint64_t* row = table.data() + c * rw;
-            auto fresh = [&](size_t pos) { Buffer* b = new_buffer(n); outs.push_back({ first + c, pos, b }); return (uint64_t)(uintptr_t)b->ptr; };
+            const size_t r_new = member_of_row.size();
+            uint64_t* row = table.data() + r_new * rw;
+            std::fill(row, row + rw, (uint64_t)0);
             for (size_t k = 0; k < NX; ++k) row[k] = ptr_of(big.leaves[(size_t)pe.extra_leaf[k]]->buf);
             for (size_t k = 0; k < G; ++k) row[oG + k] = ptr_of(big.leaves[(size_t)ro.global_leaf[k]]->buf);
-            for (size_t k = 0; k < CO; ++k) if (pe.final_store[k]) row[oCO + k] = fresh(ro.begin + (R - 1) * P + ro.final_pos[k]);
-            for (size_t k = 0; k < pe.pre_out.size(); ++k) row[oXO + k] = fresh(pe.pre_out[k]);
-            for (size_t k = 0; k < pe.post_out.size(); ++k) row[oXO + pe.pre_out.size() + k] = fresh(pe.post_out[k]);
             float* sc = reinterpret_cast<float*>(row + oIT + R * (LI + LO));
             for (size_t k = 0; k < NS0; ++k) sc[k] = big.scalar_at(pe.pre_scal[k]);
             for (size_t r = 0; r < R; ++r) {
                 uint64_t* ip = row + oIT + r * (LI + LO);
                 const size_t base = ro.begin + r * P;
                 for (size_t m = 0; m < LI; ++m) ip[m] = ptr_of(big.leaves[(size_t)ro.iter_leaf[r * LI + m]]->buf);
-                for (size_t m = 0; m < LO; ++m) ip[LI + m] = fresh(base + ro.out_pos[m]);
                 for (size_t m = 0; m < LS; ++m) sc[NS0 + r * LS + m] = big.scalar_at(base + ro.scal_pos[m]);
             }
             for (size_t k = 0; k < NS2; ++k) sc[NS0 + R * LS + k] = big.scalar_at(pe.post_scal[k]);
+            if (dedup) {
+                uint64_t h = 0x9e3779b97f4a7c15ull;
+                for (size_t w = 0; w < rw; ++w) { h = (h ^ row[w]) * 0xff51afd7ed558ccdull; h ^= h >> 31; }
+                bool common = false;
+                auto range = seen.equal_range(h);
+                for (auto it = range.first; it != range.second && !common; ++it)
+                    if (std::memcmp(keys.data() + (size_t)it->second * rw, row, rw * 8) == 0) { row_of[c] = it->second; common = true; }
+                if (common) { ++n_common_rows_; continue; }
+                seen.emplace(h, (uint32_t)r_new);
+                keys.insert(keys.end(), row, row + rw);
+            }
+            row_of[c] = (uint32_t)r_new;
+            member_of_row.push_back(c);
+            auto fresh = [&](size_t pos) { Buffer* b = new_buffer(n); outs.push_back({ first + c, pos, b }); return (uint64_t)(uintptr_t)b->ptr; };
+            for (size_t k = 0; k < CO; ++k) if (pe.final_store[k]) row[oCO + k] = fresh(ro.begin + (R - 1) * P + ro.final_pos[k]);
+            for (size_t k = 0; k < pe.pre_out.size(); ++k) row[oXO + k] = fresh(pe.pre_out[k]);
+            for (size_t k = 0; k < pe.post_out.size(); ++k) row[oXO + pe.pre_out.size() + k] = fresh(pe.post_out[k]);
+            for (size_t r = 0; r < R; ++r) {
+                uint64_t* ip = row + oIT + r * (LI + LO);
+                for (size_t m = 0; m < LO; ++m) ip[LI + m] = fresh(ro.begin + r * P + ro.out_pos[m]);
+            }
         }
+        const size_t rows = member_of_row.size();
+        table.resize(rows * rw);
         if (n > 0) {
             const int64_t elems_per_pass = (int64_t)FM_BLOCK * pe.jit->elems;
             const int64_t tiles = (n + elems_per_pass - 1) / elems_per_pass;
@@ -2543,32 +2590,51 @@ void Engine::run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, s
             int64_t grid_x = (tiles + tiles_per_wg - 1) / tiles_per_wg;
             if ((tiles + grid_x - 1) / grid_x != tiles_per_wg) { tiles_per_wg = 1; grid_x = tiles; }       // (the kernel derives its stretch from the grid: it must come out as asked)
             RedLaunch red;
-            if (rr) {                           // the kernel with the fused reduction of the root (rr->host_out: one entry per row)
-                red_begin(red, (int)count, 1, (size_t)tiles, rr->host_out, rr->dev_out);
+            std::vector<fmhip_moments> by_row;                                     // host moments arrive per ROW; the caller's array is per member
+            if (rr) {                           // the kernel with the fused reduction of the root (rr->host_out: one entry per member; rr->dev_out: one slot per row)
+                fmhip_moments* host_rows = rr->host_out;
+                if (rr->host_out && rows != count) { by_row.resize(rows); host_rows = by_row.data(); }
+                red_begin(red, (int)rows, 1, (size_t)tiles, host_rows, rr->dev_out);
                 args.shift = rr->shift; args.partials = (double*)red.partials; args.results = (double*)red.results; args.counters = counters_dev_;
                 args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
             }
             try {
                 const JitSlot& slot = rr ? *pe.jit_red : *pe.jit;
-                hip_check(hipModuleLaunchKernel(inline_rows ? slot.fn_inline : slot.fn_table, (unsigned)grid_x, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
+                hip_check(hipModuleLaunchKernel(inline_rows ? slot.fn_inline : slot.fn_table, (unsigned)grid_x, (unsigned)rows, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch peeled kernel");
                 const size_t stored = R * LO + NXO + (size_t)std::count(pe.final_store.begin(), pe.final_store.end(), (char)1);
                 if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
-                                  profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, rr ? 1 : 0, (int)count, 2, n }); }
+                                  profile_tags_.push_back({ (int)pe.n_ops, (int)(NX + G + R * LI), (int)stored, rr ? 1 : 0, (int)rows, 2, n }); }
                 n_launches_++; n_jit_launches_++; n_rolled_launches_++;
-                n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)count;
-                algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)count;
-                bytes_written_ += 4 * n * (int64_t)stored * (int64_t)count;
+                n_ops_executed_ += (int64_t)pe.n_ops * (int64_t)rows;
+                algorithmic_bytes_ += 4 * n * (int64_t)(NX + G + R * LI + stored) * (int64_t)rows;
+                bytes_written_ += 4 * n * (int64_t)stored * (int64_t)rows;
                 if (rr) {
                     rr->done = true;
                     if (count == 1 && defer_red_ && !defer_red_->pending && rr->host_out && red.on_host) {
                         red.pending = true; red.batch = 1; red.n_red = 1; red.host = rr->host_out;
                         *defer_red_ = red; red = RedLaunch();      // reduce() waits and releases
-                    } else red_wait(red, (int)count, 1, rr->host_out);
+                    } else {
+                        red_wait(red, (int)rows, 1, by_row.empty() ? rr->host_out : by_row.data());
+                        if (!by_row.empty()) for (size_t c = 0; c < count; ++c) rr->host_out[c] = by_row[row_of[c]];
+                    }
                 }
             } catch (...) { red_release(red); throw; }
             red_release(red);
         } else if (rr) rr = nullptr;
     } catch (...) { for (Out& o : outs) buffer_unref(o.buf); throw; }
+    if (row_of_out) *row_of_out = row_of;
+    // the members of a common row receive the vectors its first member stored (one more reference each)
+    if (member_of_row.size() != count) {
+        std::vector<std::pair<size_t, size_t>> span(member_of_row.size(), { 0, 0 });   // per row: its outs [begin, end)
+        { size_t k = 0;
+          for (size_t r = 0; r < member_of_row.size(); ++r) { const size_t b = k; while (k < outs.size() && outs[k].member == first + member_of_row[r]) ++k; span[r] = { b, k }; } }
+        const size_t n_first = outs.size();
+        for (size_t c = 0; c < count; ++c) {
+            const size_t r = row_of[c];
+            if (member_of_row[r] == c) continue;
+            for (size_t k = span[r].first; k < span[r].second && k < n_first; ++k) { Buffer* b = outs[k].buf; b->refs++; outs.push_back({ first + c, outs[k].pos, b }); }
+        }
+    }
     // commit: every stored value becomes a materialised vector; the rest of the component goes away with their expressions
     std::vector<Node*> done;
     done.reserve(outs.size());
@@ -2657,9 +2723,10 @@ void Engine::run_plan(BigPlan& plan, std::vector<BigDag>& group, ReduceRequest* 
                 if (!plan.discards_root || fused == &every) {
                 std::vector<Node*> root_nodes;
                 if (fused == &every) for (const BigDag& b : group) root_nodes.push_back(single_root(b, group[0]));
-                run_peeled(plan.rolled, group, 0, group.size(), fused);
+                std::vector<uint32_t> row_of;
+                run_peeled(plan.rolled, group, 0, group.size(), fused, &row_of);
                 if (fused == &every && every.done && every.dev_out)
-                    for (size_t i = 0; i < root_nodes.size(); ++i) arena_assign(root_nodes[i], (double*)every.dev_out + i * 4);
+                    for (size_t i = 0; i < root_nodes.size(); ++i) arena_assign(root_nodes[i], (double*)every.dev_out + (size_t)row_of[i] * 4);      // (members of a common row: the same slot)
                 else if (fused == &every && every.done)
                     for (size_t i = 0; i < root_nodes.size(); ++i) {
                         Node* r = root_nodes[i];
@@ -2928,21 +2995,27 @@ const Engine::SmallMatch* Engine::match_small(const Dag& d)
     return &out;
 }
 
+// The number of a mergeable loop shape (by its description), registered at its first sight — when its plan is made (plan_peel), so that
+// single-launch components of the flush after can be recognised as its chains; -1: the shape has no merged form.
+int Engine::merge_shape_index(const std::string& desc)
+{
+    if (desc.empty()) return -1;
+    for (size_t i = 0; i < merge_shapes_.size(); ++i) if (merge_shapes_[i] == desc) return (int)i;
+    RolledBody body;
+    if (!jit_parse_description(desc, body)) return -1;
+    RolledBody probe = body; probe.chains = 2; probe.shared_den = true;
+    if (jit_generate_rolled_source(probe).empty()) return -1;
+    merge_shapes_.push_back(desc); merge_shape_bodies_.push_back(std::move(body));
+    return (int)merge_shapes_.size() - 1;
+}
+
 void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vector<SmallGroup>& small)
 {
     if (!MERGE_CHAINS || !want_root_moments_ || jit_mode == FMHIP_JIT_OFF) return;
     // a chain: a large component (group, member: its plan says where its vectors and scalars are) or a small one (sgroup, smember: its match does)
     struct Chain { size_t group, member; BigPlan* plan; int shape; Node* root; uint32_t steps, R; const float* last; bool small; };
     std::vector<Chain> chains;
-    auto shape_index = [&](BigPlan::Rolled::Peeled& pe) -> int {
-        for (size_t i = 0; i < merge_shapes_.size(); ++i) if (merge_shapes_[i] == pe.desc_red) return (int)i;
-        RolledBody body;
-        if (!jit_parse_description(pe.desc_red, body)) return -1;
-        RolledBody probe = body; probe.chains = 2; probe.shared_den = true;
-        if (jit_generate_rolled_source(probe).empty()) return -1;
-        merge_shapes_.push_back(pe.desc_red); merge_shape_bodies_.push_back(std::move(body));
-        return (int)merge_shapes_.size() - 1;
-    };
+    auto shape_index = [&](BigPlan::Rolled::Peeled& pe) -> int { return merge_shape_index(pe.desc_red); };
     std::vector<BigPlan*> plan_of_shape;                         // a plan of every shape met in this flush (what its large chains are described by)
     for (size_t gi = 0; gi < groups.size(); ++gi) {
         std::vector<BigDag>& g = groups[gi];
@@ -3049,7 +3122,18 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
         while (j < chains.size() && chains[j].last == chains[i].last && chains[j].shape == chains[i].shape) ++j;
         // [i, j): same shape, same last vector.  Those whose whole sequence is a suffix of the longest one's and whose tail inputs and
         // shared scalars agree with it form families of at most 16 (a family of small components only has nobody to carry it: skipped).
-        const Chain& lead = chains[i];
+        // Chains of the SAME length that end in the same vector — the same product valued for several parameter sets whose simulations
+        // were common rows up to this exercise date (run_peeled) — belong to different families: the m-th chain of every length forms
+        // layer m; the layers are rows of one launch (and, reading the same vectors with the same scalars, one common row of it).
+        std::vector<std::vector<size_t>> layers;
+        { size_t occurrence = 0;
+          for (size_t q = i; q < j; ++q) {
+              occurrence = (q > i && chains[q].steps == chains[q - 1].steps) ? occurrence + 1 : 0;
+              if (layers.size() <= occurrence) layers.resize(occurrence + 1);
+              layers[occurrence].push_back(q);
+          } }
+        for (const std::vector<size_t>& layer : layers) {
+        const Chain& lead = chains[layer[0]];
         const Shape& sh = shape_of(lead.shape);
         const bool any_shared = !(sh.shared_pre.empty() && sh.shared_body.empty());
         float s_star = 0.f;
@@ -3058,7 +3142,8 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
         uint32_t want; std::memcpy(&want, &s_star, 4);
         auto same = [&](float v) { uint32_t u; std::memcpy(&u, &v, 4); return u == want; };
         Family fam;
-        for (size_t q = i; q < j && !lead.small; ++q) {
+        for (size_t q : layer) {
+            if (lead.small) break;
             const Chain& c = chains[q];
             bool ok = chain_n(c) == chain_n(lead);
             for (size_t x = 0; ok && x < sh.NXP; ++x) { const float* p = post_ptr(c, sh, x); ok = p != nullptr && p == post_ptr(lead, sh, x); }
@@ -3073,6 +3158,7 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
             if (fam.chain.size() == 16) { families.push_back(std::move(fam)); fam = Family(); }
         }
         if (fam.chain.size() >= 2) families.push_back(std::move(fam));
+        }
         i = j;
     }
     // (after a split at 16 the later part is a family of its own: its first chain is its longest, the others suffixes of it)
@@ -3158,11 +3244,20 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
             std::vector<fmhip_moments> all;
             ReduceRequest every{ 0.0, nullptr, nullptr, false };
             RedLaunch red;
+            // common rows (as run_peeled): families that read the same vectors with the same scalars — the parameter sets of a Jacobian
+            // batch at an exercise date before their bumped parameter matters — are ONE row; their chains share moments and stored values
+            std::vector<uint32_t> row_of(count);
+            std::vector<size_t> family_of_row;                           // launch row → index into rows_n (offset from `off`)
+            std::unordered_multimap<uint64_t, uint32_t> seen;
+            std::vector<uint64_t> keys;
+            std::vector<std::pair<size_t, size_t>> out_span;             // per launch row: its outs [begin, end)
             try {
                 for (size_t r = 0; r < count; ++r) {
                     const Family& fam = families[rows_n[off + r]];
                     const Chain& lead = chains[fam.chain[0]];
-                    uint64_t* row = table.data() + r * rw;
+                    const size_t r_new = family_of_row.size();
+                    uint64_t* row = table.data() + r_new * rw;
+                    std::fill(row, row + rw, (uint64_t)0);
                     const size_t T = lead.steps;
                     row[0] = (uint64_t)T;
                     for (size_t t = 0; t < T; ++t) row[1 + K + t] = (uint64_t)(uintptr_t)seq_ptr(lead, sh, t);
@@ -3173,24 +3268,45 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
                       uint32_t bits = 0; if (any) std::memcpy(&bits, &s_star, 4);
                       row[1 + K + T + sh.NXP] = bits; }
                     size_t at = 1 + K + T + sh.NXP + 1;
-                    n_vec_in += T + sh.NXP;
                     for (size_t k = 0; k < K; ++k) {
                         const Chain& c = chains[fam.chain[k]];
                         row[1 + k] = (uint64_t)(T - c.steps) | ((uint64_t)at << 32);
                         uint64_t* sec = row + at;
-                        for (size_t m = 0; m < sh.NXO; ++m) { Buffer* nb = new_buffer(n); outs.push_back({ fam.chain[k], nb }); sec[m] = (uint64_t)(uintptr_t)nb->ptr; }
                         float* sc = reinterpret_cast<float*>(sec + sh.NXO);
                         for (size_t i = 0; i < sh.NS0; ++i) sc[i] = pre_scalar(c, sh, i);
                         for (size_t it = 0; it < c.R; ++it)
                             for (size_t m = 0; m < sh.LS; ++m) sc[sh.NS0 + it * sh.LS + m] = body_scalar(c, sh, it, m);
                         for (size_t i = 0; i < sh.NS2; ++i) sc[sh.NS0 + (size_t)c.R * sh.LS + i] = post_scalar(c, sh, i);
                         at += section_words(c);
+                    }
+                    if (COMMON_ROWS && count > 1) {
+                        uint64_t h = 0x9e3779b97f4a7c15ull;
+                        for (size_t w = 0; w < rw; ++w) { h = (h ^ row[w]) * 0xff51afd7ed558ccdull; h ^= h >> 31; }
+                        bool common = false;
+                        auto range = seen.equal_range(h);
+                        for (auto it = range.first; it != range.second && !common; ++it)
+                            if (std::memcmp(keys.data() + (size_t)it->second * rw, row, rw * 8) == 0) { row_of[r] = it->second; common = true; }
+                        if (common) { ++n_common_rows_; continue; }
+                        seen.emplace(h, (uint32_t)r_new);
+                        keys.insert(keys.end(), row, row + rw);
+                    }
+                    row_of[r] = (uint32_t)r_new;
+                    family_of_row.push_back(r);
+                    n_vec_in += T + sh.NXP;
+                    const size_t out_begin = outs.size();
+                    for (size_t k = 0; k < K; ++k) {
+                        const Chain& c = chains[fam.chain[k]];
+                        uint64_t* sec = row + (size_t)(row[1 + k] >> 32);
+                        for (size_t m = 0; m < sh.NXO; ++m) { Buffer* nb = new_buffer(n); outs.push_back({ fam.chain[k], nb }); sec[m] = (uint64_t)(uintptr_t)nb->ptr; }
                         n_ops += sh.body->peel.pre.size() + (size_t)c.R * sh.P + sh.body->peel.post.size();
                     }
+                    out_span.push_back({ out_begin, outs.size() });
                 }
+                const size_t launch_rows = family_of_row.size();
+                table.resize(launch_rows * rw);
                 const int64_t tiles = (n + FM_UNIT_ELEMS - 1) / FM_UNIT_ELEMS;
-                if (async_moments_) { every.dev_out = arena_alloc(count * K); if (!every.dev_out) { for (Out& o : outs) buffer_unref(o.buf); continue; } }
-                else { all.resize(count * K); every.host_out = all.data(); }
+                if (async_moments_) { every.dev_out = arena_alloc(launch_rows * K); if (!every.dev_out) { for (Out& o : outs) buffer_unref(o.buf); continue; } }
+                else { all.resize(launch_rows * K); every.host_out = all.data(); }
                 DevRolledArgs args{};
                 args.n = n; args.tiles_per_row = (uint32_t)tiles; args.row_words = (uint32_t)rw; args.iterations = 0; args.pad = (uint32_t)K;
                 args.dump = (uint64_t)(uintptr_t)dump_dev_;
@@ -3202,27 +3318,38 @@ void Engine::merge_families(std::vector<std::vector<BigDag>>& groups, std::vecto
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 if (profiling_) { hip_check(hipEventCreate(&ev0), "hipEventCreate"); hip_check(hipEventCreate(&ev1), "hipEventCreate"); hip_check(hipEventRecord(ev0, stream_), "hipEventRecord"); }
                 void* params[] = { &args, &rows_arg };
-                red_begin(red, (int)count, (int)K, (size_t)tiles, every.host_out, every.dev_out);
+                red_begin(red, (int)launch_rows, (int)K, (size_t)tiles, every.host_out, every.dev_out);
                 args.shift = 0.0; args.partials = (double*)red.partials; args.results = (double*)red.results; args.counters = counters_dev_;
                 args.done_flag = const_cast<uint64_t*>(red.poll_flag); args.done_value = red.done_value;
-                hip_check(hipModuleLaunchKernel(l.slot->fn_table, (unsigned)tiles, (unsigned)count, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch merged kernel");
+                hip_check(hipModuleLaunchKernel(l.slot->fn_table, (unsigned)tiles, (unsigned)launch_rows, 1, FM_BLOCK, 1, 1, 0, stream_, params, nullptr), "launch merged kernel");
                 if (profiling_) { hip_check(hipEventRecord(ev1, stream_), "hipEventRecord"); profile_events_.push_back({ ev0, ev1 });
-                                  profile_tags_.push_back({ (int)(n_ops / count), (int)(n_vec_in / count), (int)(K * sh.NXO), (int)K, (int)count, 4, n }); }
+                                  profile_tags_.push_back({ (int)(n_ops / launch_rows), (int)(n_vec_in / launch_rows), (int)(K * sh.NXO), (int)K, (int)launch_rows, 4, n }); }
                 n_launches_++; n_jit_launches_++; n_rolled_launches_++; n_merged_launches_++; n_merged_chains_ += (int64_t)(count * K);
                 n_ops_executed_ += (int64_t)n_ops;
                 algorithmic_bytes_ += 4 * n * (int64_t)(n_vec_in + outs.size());
                 bytes_written_ += 4 * n * (int64_t)outs.size();
                 every.done = true;
-                red_wait(red, (int)count, (int)K, every.host_out);
+                red_wait(red, (int)launch_rows, (int)K, every.host_out);
             } catch (...) { red_release(red); for (Out& o : outs) buffer_unref(o.buf); throw; }
             red_release(red);
+            // the chains of a family that was a common row receive the vectors its first family stored (one more reference each)
+            if (family_of_row.size() != count) {
+                const size_t n_first = outs.size();
+                for (size_t r = 0; r < count; ++r) {
+                    const size_t lr = row_of[r];
+                    if (family_of_row[lr] == r) continue;
+                    const Family& fam = families[rows_n[off + r]];
+                    size_t k = 0;
+                    for (size_t o = out_span[lr].first; o < out_span[lr].second && o < n_first; ++o, ++k) { Buffer* b = outs[o].buf; b->refs++; outs.push_back({ fam.chain[k / std::max<size_t>(1, sh.NXO)], b }); }
+                }
+            }
             // the moments go to the chains' roots; stored values become vectors; expressions are dismantled
             for (size_t r = 0; r < count; ++r) {
                 const Family& fam = families[rows_n[off + r]];
                 for (size_t k = 0; k < K; ++k) {
                     Node* root = chains[fam.chain[k]].root;
-                    if (every.dev_out) arena_assign(root, (double*)every.dev_out + (r * K + k) * 4);
-                    else { const fmhip_moments& m = all[r * K + k]; root->moments[0] = m.sum; root->moments[1] = m.sumsq; root->moments[2] = m.min; root->moments[3] = m.max; root->has_moments = true; }
+                    if (every.dev_out) arena_assign(root, (double*)every.dev_out + ((size_t)row_of[r] * K + k) * 4);
+                    else { const fmhip_moments& m = all[(size_t)row_of[r] * K + k]; root->moments[0] = m.sum; root->moments[1] = m.sumsq; root->moments[2] = m.min; root->moments[3] = m.max; root->has_moments = true; }
                 }
             }
             std::vector<Node*> done;
@@ -3922,6 +4049,7 @@ void Engine::program_run(fmhip_program h, int batch, const fmhip_vec* inputs, fm
                     if (!o->buf) materialize({ o });
                     if (o->refs_int > 0) { flush_all(); materialize_deferred(); }      // overwritten in place: whoever still reads the old contents (pending expressions, recipes of deferred values) is computed first
                     o->has_moments = false; o->moments_slot = nullptr;      // overwritten
+                    make_private(o);
                     rows[b].out.push_back(o->buf->ptr);
                 } else {
                     Buffer* bf = new_buffer(n);
@@ -4026,7 +4154,7 @@ void Engine::engine_stats(fmhip_engine_stats_t* out) {
     out->pending_operations = (int64_t)n_pending_;
     out->peak_bytes_reserved = pool_.peak_reserved;
     out->late_releases_while_waiting = n_late_waiting_; out->late_releases_at_once = n_late_at_once_; out->late_release_nanoseconds = late_ns_;
-    out->merged_launches = n_merged_launches_; out->merged_chains = n_merged_chains_;
+    out->merged_launches = n_merged_launches_; out->merged_chains = n_merged_chains_; out->common_rows = n_common_rows_;
 }
 
 void Engine::pool_stats(fmhip_pool_stats_t* out) {

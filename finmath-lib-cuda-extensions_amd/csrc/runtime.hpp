@@ -597,7 +597,12 @@ private:
     bool detect_loop(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& out, std::string* source, int* elems, RolledBody* body_out = nullptr);
     void run_rolled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count);
     bool plan_peel(const BigDag& g, const std::vector<std::array<int32_t, 3>>& operand, BigPlan::Rolled& ro, const RolledBody& body);
-    void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr);
+    // row_of (optional): per member, the row of the launch that computed it.  Members whose row would be IDENTICAL — the same input
+    // vectors and the same scalars — are computed once and share the stored vectors (common rows: the parameter sets of a Jacobian batch
+    // before the time their bumped parameter first matters); with a fused reduction only when the caller can take the mapping.
+    void run_peeled(const BigPlan::Rolled& ro, std::vector<BigDag>& group, size_t first, size_t count, ReduceRequest* rr = nullptr, std::vector<uint32_t>* row_of = nullptr);
+    void make_private(Node* nd);                              // a vector about to be written in place: storage of its own if it shares it (common rows)
+    int64_t n_common_rows_ = 0;
     int64_t n_rolled_launches_ = 0;
     // Components of ONE loop shape whose vectors are the same sequence, the shorter ones reading a suffix of the longest one's (the swaptions
     // of one exercise date: every tenor reads the forward rates from its last period back to the exercise date), as ONE launch that loads
@@ -610,6 +615,7 @@ private:
     struct SmallGroup;
     void merge_families(std::vector<std::vector<BigDag>>& groups, std::vector<SmallGroup>& small);
     const SmallMatch* match_small(const Dag& d);
+    int merge_shape_index(const std::string& desc);
     std::vector<std::string> merge_shapes_;                                          // descriptions (desc_red) of the mergeable loop shapes met so far …
     std::vector<RolledBody> merge_shape_bodies_;                                     // … and their bodies
     std::unordered_map<std::string, SmallMatch> small_match_;

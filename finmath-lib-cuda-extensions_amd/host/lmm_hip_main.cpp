@@ -215,10 +215,10 @@ int main(int argc, char** argv) {
             char eb[768];
             std::snprintf(eb, sizeof eb, ", \"engine\": {\"interpreter_launches\": %lld, \"algorithmic_bytes_written\": %lld, \"values_deferred\": %lld, \"values_deferred_now\": %lld, "
                           "\"values_demanded\": %lld, \"peak_bytes_reserved\": %lld, \"late_releases_while_waiting\": %lld, \"late_releases_at_once\": %lld, \"late_release_seconds\": %.3f, "
-                          "\"merged_launches\": %lld, \"merged_chains\": %lld}",
+                          "\"merged_launches\": %lld, \"merged_chains\": %lld, \"common_rows\": %lld}",
                           (long long)es.interpreter_launches, (long long)es.algorithmic_bytes_written, (long long)es.values_deferred, (long long)es.values_deferred_now,
                           (long long)es.values_demanded, (long long)es.peak_bytes_reserved, (long long)es.late_releases_while_waiting, (long long)es.late_releases_at_once, (double)es.late_release_nanoseconds * 1e-9,
-                          (long long)es.merged_launches, (long long)es.merged_chains);
+                          (long long)es.merged_launches, (long long)es.merged_chains, (long long)es.common_rows);
             return std::string(buf) + prof + lag + eb;
         };
         if (o.rank == 0) lmm::runAndReport(o, be, "hip", extra);

@@ -451,6 +451,9 @@ typedef struct fmhip_engine_stats_t {
     /* launches that served several components of one loop shape reading the same sequence of vectors (each vector loaded once for all of
      * them: the swaptions of one exercise date), and how many components they served */
     int64_t merged_launches, merged_chains;
+    /* rows of batched launches that were not computed because an earlier row of the same launch read the same vectors with the same
+     * scalars (the parameter sets of a finite-difference batch before their bumped parameter matters): they share its vectors */
+    int64_t common_rows;
 } fmhip_engine_stats_t;
 int fmhip_engine_stats(fmhip_engine_stats_t* out);
 int fmhip_profile_read(double* kernel_ms_total, int64_t* n_launches);

@@ -114,8 +114,8 @@ final class Native {
 	static native int profileEnable(int enabled);
 	static native int trafficStats(long[] algorithmicBytesAndSpecialisedLaunches);
 	/** {size, kernelLaunches, specialisedLaunches, interpreterLaunches, algorithmicBytes, algorithmicBytesWritten, valuesDeferred, valuesDeferredNow, valuesDemanded, pendingOperations, peakBytesReserved,
-	 *  lateReleasesWhileWaiting, lateReleasesAtOnce, lateReleaseNanoseconds, mergedLaunches, mergedChains} */
-	static native int engineStats(long[] stats16);
+	 *  lateReleasesWhileWaiting, lateReleasesAtOnce, lateReleaseNanoseconds, mergedLaunches, mergedChains, commonRows} */
+	static native int engineStats(long[] stats17);
 	static native int profileRead(double[] kernelMsTotal, long[] launches);
 
 	// ---- helpers (plain Java)

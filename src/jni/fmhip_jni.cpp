@@ -329,11 +329,11 @@ FMJ(jint, trafficStats)(JNIEnv* env, jclass, jlongArray algorithmicBytesAndSpeci
     if (st == FMHIP_OK && algorithmicBytesAndSpecialisedLaunches && env->GetArrayLength(algorithmicBytesAndSpecialisedLaunches) >= 2) { const jlong v[2] = { (jlong)bytes, (jlong)launches }; env->SetLongArrayRegion(algorithmicBytesAndSpecialisedLaunches, 0, 2, v); }
     return st;
 }
-FMJ(jint, engineStats)(JNIEnv* env, jclass, jlongArray stats16) {
+FMJ(jint, engineStats)(JNIEnv* env, jclass, jlongArray stats17) {
     fmhip_engine_stats_t s;
     const int st = fmhip_engine_stats(&s);
-    static_assert(sizeof(fmhip_engine_stats_t) == 16 * sizeof(int64_t), "engine statistics travel as 16 longs");
-    if (st == FMHIP_OK && stats16) { const jsize len = env->GetArrayLength(stats16); env->SetLongArrayRegion(stats16, 0, len < 16 ? len : 16, (const jlong*)&s); }
+    static_assert(sizeof(fmhip_engine_stats_t) == 17 * sizeof(int64_t), "engine statistics travel as 17 longs");
+    if (st == FMHIP_OK && stats17) { const jsize len = env->GetArrayLength(stats17); env->SetLongArrayRegion(stats17, 0, len < 17 ? len : 17, (const jlong*)&s); }
     return st;
 }
 FMJ(jint, profileRead)(JNIEnv* env, jclass, jdoubleArray kernelMsTotal, jlongArray launches) {

@@ -132,3 +132,57 @@ def test_chains_that_do_not_share_their_vectors_are_left_alone(gpu, oracle):
             gpu.set_jit(prev_jit)
     finally:
         gpu.set_fusion(prev_fusion)
+
+
+@pytest.mark.parametrize("with_moments", [False, True])
+def test_common_rows_are_computed_once_and_share_their_vectors(gpu, oracle, with_moments):
+    """Rows of a batched launch that read the SAME vectors with the SAME scalars — the bumped parameter sets of a finite-difference
+    Jacobian before the time step at which their bump first matters (LIBORMarketModelCalibrationATMTest.java:314-340: one re-simulation
+    per parameter) — are computed once (runtime.cpp: run_peeled / merge_families, common rows); the other members receive the same
+    vectors.  Storage that is shared is copied before anybody writes into it in place (make_private): the two doors through which a
+    vector can be written, fmhip_program_run_into and a raw device pointer, leave the other holders' values alone."""
+    n = 20011
+    rng = np.random.default_rng(5)
+    L_h = [oracle.f_from_double(rng.uniform(-0.01, 0.05, n)) for _ in range(40)]
+    num_h = oracle.f_from_double(rng.uniform(0.9, 1.4, n))
+    prev_fusion = gpu.set_fusion(False)
+    try:
+        L = [gpu.DeviceVector.from_host(x) for x in L_h]
+        num = gpu.DeviceVector.from_host(num_h)
+        # three "parameter sets": two of them identical in everything they read, the third with other strikes; two tenors each
+        def build():
+            return [swaption(L, num, periods, rate) for rates in ((0.02, 0.021), (0.02, 0.021), (0.03, 0.031)) for periods, rate in zip((40, 24), rates)]
+        want = [(v.to_float32(), moments_tuple(v.moments())) for v in build()]
+        gpu.set_fusion(True)
+        prev_jit = gpu.set_jit(gpu.JIT_SYNC)
+        prev_hold = gpu.fusion_hold(2)
+        try:
+            for round_ in range(3):
+                values = build()
+                before = gpu.engine_stats()
+                if with_moments:
+                    got = [moments_tuple(v.moments()) for v in values]         # everything pending runs, moments taken along (merged families from round 1 on)
+                    for i in range(len(values)):
+                        assert got[i] == want[i][1], (round_, i)
+                else:
+                    gpu.flush()                                                  # one launch per shape, rows = the three sets
+                after = gpu.engine_stats()
+                assert after["common_rows"] > before["common_rows"], "the two identical parameter sets were not recognised as common rows"
+                for i, v in enumerate(values):
+                    assert_bits_equal(v.to_float32(), want[i][0], f"round {round_}, value {i}")
+                # values 0 and 2 (sets 0 and 1, 40 periods) are the same numbers and, computed once, the same storage: overwrite one in place
+                p = gpu.Program(1)
+                p.output(p.op("MULT_S", 0, s=3.0))
+                p.compile()
+                p.run_into([[values[2]]], [[values[2]]])
+                assert_bits_equal(values[2].to_float32(), oracle.f_v1s1("MULT_S", want[2][0], 3.0), "the vector written in place")
+                assert_bits_equal(values[0].to_float32(), want[0][0], "its former twin")
+                values[1].device_ptr()                                           # a raw pointer handed out: storage of its own from here on
+                assert_bits_equal(values[1].to_float32(), want[1][0], "after a device pointer was handed out")
+                assert_bits_equal(values[3].to_float32(), want[3][0], "its twin")
+                del values, p
+        finally:
+            gpu.fusion_hold(prev_hold)
+            gpu.set_jit(prev_jit)
+    finally:
+        gpu.set_fusion(prev_fusion)
