@@ -293,20 +293,22 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
     eng = rp.get("engine") or {}
     lmm["roofline"]["merged_launches"] = eng.get("merged_launches")
     lmm["roofline"]["merged_chains"] = eng.get("merged_chains")
+    lmm["roofline"]["common_rows"] = eng.get("common_rows")        # rows that were not computed: an earlier row of the launch read the same vectors with the same scalars
     if world == 1:
         # Round 5: the swaptions of one exercise date run as ONE launch that loads every forward rate once (runtime.cpp: merge_families) — a third
         # of the bytes of one launch per tenor, and kernels that are bound by their arithmetic (the correctly rounded division per chain and
-        # period), no longer by HBM.  `frac` above counts, as always, the bytes the launches that RAN have to move; the same calibration with
+        # period), no longer by HBM; and rows of a launch that read the same vectors with the same scalars (the bumped parameter sets of a
+        # Jacobian batch before their bump matters) are computed once (common rows): fewer path-ops, not faster ones.  `frac` above counts, as always, the bytes the launches that RAN have to move; the same calibration with
         # one launch per shape (FMHIP_MERGE_CHAINS=0: rounds 1-4) is measured beside it, and `frac_at_the_bytes_of_one_launch_per_shape`
         # sets ITS bytes against this run's kernel time: what the merged launches are worth in the old currency.
         try:
-            u, _ = run(base, env=dict(os.environ, FMHIP_MERGE_CHAINS="0"))
-            up, _ = run(base + ["--profile"], env=dict(os.environ, FMHIP_MERGE_CHAINS="0"))
+            u, _ = run(base, env=dict(os.environ, FMHIP_MERGE_CHAINS="0", FMHIP_COMMON_ROWS="0"))
+            up, _ = run(base + ["--profile"], env=dict(os.environ, FMHIP_MERGE_CHAINS="0", FMHIP_COMMON_ROWS="0"))
             lmm["roofline"]["one_launch_per_shape"] = {
                 "seconds": u["seconds"], "kernel_launches": u["kernel_launches"], "algorithmic_bytes": up["algorithmic_bytes"], "summed_kernel_s": up["kernel_ms_total"] / 1e3,
                 "achieved": up["achieved_GBps"], "frac": up["achieved_GBps"] / HBM_PEAK_GBS, "mean_deviation": u["mean_deviation"],
                 "identical_to_the_merged_run": u["mean_deviation"] == r["mean_deviation"] and u["rms_deviation"] == r["rms_deviation"] and u["parameters"] == r["parameters"],
-                "what": "FMHIP_MERGE_CHAINS=0: every component shape its own launch, as in rounds 1-4 (HBM-bound throughout)"}
+                "what": "FMHIP_MERGE_CHAINS=0 FMHIP_COMMON_ROWS=0: every component shape its own launch, every row of a launch computed, as in rounds 1-4 (HBM-bound throughout)"}
             lmm["roofline"]["frac_at_the_bytes_of_one_launch_per_shape"] = up["algorithmic_bytes"] / kernel_s / 1e9 / HBM_PEAK_GBS
             lmm["roofline"]["bytes_over_one_launch_per_shape"] = rp["algorithmic_bytes"] / up["algorithmic_bytes"]
             lmm["roofline"]["bound_note"] = ("simulation launches (two thirds of the kernel time): HBM / VALU issue as in round 4; merged valuation launches: VALU-bound "
