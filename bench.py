@@ -315,7 +315,8 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
                                              "(8 issue slots per chain, period and pair of paths, 3 of them the division's; DESIGN.md 4.6) at about 0.4 of the HBM peak on their own, smaller, byte count")
         except Exception as e:
             lmm["roofline"]["one_launch_per_shape"] = {"error": str(e)[-500:]}
-        env = dict(os.environ, FMHIP_JIT="sync")
+        # (the replays value ONE parameter set eight times: with common rows on, eight identical rows would be one — what a launch SHAPE is worth is measured with every row computed)
+        env = dict(os.environ, FMHIP_JIT="sync", FMHIP_COMMON_ROWS="0")
         for key, batch in (("replay_one_at_a_time", 1), ("replay_8_in_lock_step", 8)):
             pj, _ = run([LMM_HIP, "--paths", str(paths), "--mode", "evaluate", "--evaluations", "8", "--jacobian-batch", str(batch), "--warmup-evaluations", str(batch), "--profile"], env=env)
             lmm["roofline"][key] = {"achieved": pj["achieved_GBps"], "frac": pj["achieved_GBps"] / HBM_PEAK_GBS, "launches_per_evaluation": pj["profiled_launches"] / 8,

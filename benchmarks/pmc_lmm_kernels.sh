@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 L=$GRAFT_REPO_ROOT/finmath-lib-cuda-extensions_amd/bin/lmm_hip
 export FMHIP_JIT=sync
+export FMHIP_COMMON_ROWS=0      # the replay values one parameter set eight times: identical rows would be computed once (runtime.cpp: common rows) and the launches would be one row tall
 ARGS="--paths 1000000 --mode evaluate --evaluations 16 --jacobian-batch 8 --warmup-evaluations 8"
 $L $ARGS > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES --output-format csv -d $OUT/pmc_a -o a -- $L $ARGS > /dev/null 2> $OUT/pmc_a.err

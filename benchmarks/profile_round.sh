@@ -16,10 +16,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write 
 python3 $GRAFT_REPO_ROOT/benchmarks/hbm_traffic_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json
 L=$GRAFT_REPO_ROOT/finmath-lib-cuda-extensions_amd/bin/lmm_hip
 export FMHIP_JIT=sync
+export FMHIP_COMMON_ROWS=0      # (the lock-step replay values one parameter set eight times: every row computed)
 $L --paths 1000000 --mode evaluate --evaluations 8 --jacobian-batch 8 > /dev/null 2>&1
 # 16 evaluations in lock-step batches of 8 behind one untimed batch (the first batch meets every graph shape for the first time)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_stats -o lmm -- $L --paths 1000000 --mode evaluate --evaluations 16 --jacobian-batch 8 --warmup-evaluations 8 > $OUT/lmm_profiled_line.json 2> $OUT/lmm_stats.err
-unset FMHIP_JIT
+unset FMHIP_JIT FMHIP_COMMON_ROWS
 # the whole calibration (621 evaluations), warm code-object cache
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lmm_calib_stats -o calib -- $L --paths 1000000 --mode calibrate --max-iterations 12 > $OUT/lmm_calib_line.json 2> $OUT/lmm_calib_stats.err
 # the reference's smile calibration at its larger published path count (context workload)
