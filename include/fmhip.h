@@ -193,7 +193,9 @@ int fmhip_vec_size(fmhip_vec v, int64_t* n_out);
 /* getRealizations(): materialise, D2H, widen float→double (RandomVariableCuda.java:1116-1123). */
 int fmhip_vec_read_double(fmhip_vec v, double* host_out, int64_t n);
 int fmhip_vec_read_float(fmhip_vec v, float* host_out, int64_t n);
-/* Raw device pointer of the (materialised) fp32 storage; valid until the handle is released. */
+/* Raw device pointer of the (materialised) fp32 storage; valid until the handle is released.  Vectors that were computed as identical
+ * rows of one launch share their storage (the same inputs, the same scalars: computed once); a vector that shares it receives storage
+ * of its own here, and in fmhip_program_run_into, before the pointer is handed out — writing through it never changes another vector. */
 int fmhip_vec_device_ptr(fmhip_vec v, void** device_ptr_out);
 
 /* ---------------------------------------------------------------- eager ops, one per reference launch helper */
