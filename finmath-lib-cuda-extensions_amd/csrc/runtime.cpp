@@ -2897,7 +2897,7 @@ void Engine::plan_loop(BigPlan& plan, const BigDag& g) {
 // one's.  One launch per (shape, family size): a row per family, a step per vector of the longest chain, every chain joining at its own
 // first step; per chain the same operations on the same operands in the same order as in its own launch, and its moments by the same
 // tree — bit-identical results, a fifth of the bytes.  Nothing is assumed about the caller: the family is read off the pending graph.
-static const bool MERGE_CHAINS = [] { const char* e = std::getenv("FMHIP_MERGE_CHAINS"); return !(e && e[0] == '0'); }();
+static const bool MERGE_CHAINS = MERGE_CHAINS_ON();         // FMHIP_MERGE_CHAINS=0: off
 static const bool MERGE_SMALL = [] { const char* e = std::getenv("FMHIP_MERGE_SMALL"); return !(e && e[0] == '0'); }();      // =0: components that fit one launch never join a family
 
 struct Engine::SmallGroup { std::vector<Dag> members; Dag proto; const SmallMatch* match = nullptr; std::vector<std::pair<ReplicaGroup*, std::vector<int>>> done; };
