@@ -406,6 +406,7 @@ Engine::Exported Engine::export_vector(fmhip_vec h, hipEvent_t ready) {
     Node* nd = node(h);
     touch(nd);
     if (!nd->buf) materialize({ nd });
+    make_private(nd);               // (the importer aliases the storage by its address and is kept safe by a reference on THIS vector: storage shared with other vectors — common rows — could be given up by an in-place write here)
     nd->refs_ext++;
     hip_check(hipEventRecord(ready, stream_), "hipEventRecord(export)");
     Exported x;
