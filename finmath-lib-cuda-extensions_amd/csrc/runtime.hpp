@@ -78,8 +78,6 @@ struct Node {
     // pending roots along: Engine::reduce); vectors are immutable — the two ways to write into one (fmhip_program_run_into, a raw device
     // pointer handed out) clear and block this
     bool    has_moments = false, moments_blocked = false;
-    double  moments[4] = { 0.0, 0.0, 0.0, 0.0 };
-    volatile uint64_t* moments_slot = nullptr;   // the same four values still on their way from a launch (pinned memory, Engine::moments_arena_)
     // fmhip_vec_give_up_values: the caller wants this pending value's moments and will never read the value itself.  `discard`: marked
     // (a root nobody else references); `discarded`: a flush took the moments in the launch that computed the value and did NOT store
     // it — the node stays without storage, is not a root of later flushes, and reading it is an error.
@@ -109,6 +107,9 @@ struct Node {
     // a Brownian increment (fmhip_bm_generate): which generation it belongs to, its time index, the number of time steps
     uint32_t bm_id = 0;
     int32_t  bm_step = -1, bm_steps = 0;
+    // (behind everything that recording, releasing and walking a pending graph touch: the moments themselves)
+    double  moments[4] = { 0.0, 0.0, 0.0, 0.0 };
+    volatile uint64_t* moments_slot = nullptr;   // the same four values still on their way from a launch (pinned memory, Engine::moments_arena_)
 };
 
 // Copies of a pending graph that exist as a DESCRIPTION until the graph runs (fmhip_graph_clone).  A copy differs from the
