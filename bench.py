@@ -391,6 +391,10 @@ def lmm_leg(args, world, rank, nonce, cpu_base=True, store=None):
         # (last of the driver runs: a process that held most of the device leaves the next one a device still busy giving the memory back)
         try:
             def gc_block(extra):
+                # (a process that held ~100 GB — the vectors of dead wrappers a collector has not released yet — leaves the NEXT process a device
+                # that is still giving that memory back: its allocations crawl, 4.4 s become 6.8 s.  Measured, benchmarks/round5/lag_window.sh and
+                # profiles/round05b_merged_chains.txt; eight seconds between the processes and the figures are those of a process on its own.)
+                time.sleep(8.0)
                 g, _ = run(base + ["--finmath-like"] + extra)
                 e, e0 = g.get("engine", {}), fl.get("engine", {})
                 return {"seconds": g["seconds"], "seconds_over_raii": round(g["seconds"] / fl["seconds"], 3), "kernel_launches": g["kernel_launches"], "mean_deviation": g["mean_deviation"],
